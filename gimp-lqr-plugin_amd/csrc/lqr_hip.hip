@@ -1,0 +1,1414 @@
+// lqr_hip.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the seam-carving
+// engine and the C-ABI shim of include/lqr_hip.h that launches them.
+//
+// The stages replace liblqr-1's CPU engine as reached from the plug-in's
+// render path (gimp-lqr-plugin src/render.c:318,328,529 -> lqr_carver_resize):
+// energy (E3/E4/E6), cumulative-min DP (E5/E9), seam pick + backtrack (E7),
+// carve (E8), visibility map, inflate/flatten/transpose (E11/E14), read-out
+// (E12).  Stage numbering: SURVEY.md section 8(a).
+//
+// Data layout.  liblqr keeps every plane indexed by pixel
+// id and moves only an index map; that is hostile to coalescing, so this engine
+// keeps two representations:
+//   * base layout  (w0 x h0): rgb0 u8*ch, vs i32, bias0/rig0 f32 -- the
+//     multi-size image; touched only by the one-off passes;
+//   * working planes (row stride S, h rows): pix u32 (packed channels), en f32,
+//     m f32, least i8 (back-pointer as dx), optional bias/rig f32 -- physically
+//     COMPACTED: carving a seam shifts the right part of every row left by one.
+// All floating point is done with explicitly rounded operations (no FMA
+// contraction, IEEE division and sqrt) so that results are bit-identical to the
+// C arithmetic of the CPU path.  No MFMA: this is stencil + scan + shift work
+// bounded by HBM bandwidth and by the H-step dependency chains.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/lqr_hip.h"
+
+// ---------------------------------------------------------------------------
+// constants / descriptors
+// ---------------------------------------------------------------------------
+#define LEAST_INVALID (-128)
+#define FLAG_OVF_ROW 0          // first row the band kernel could not handle (h = none)
+#define FLAG_COUNT 8
+#define DP_THREADS 1024
+#define VPATH_THREADS 256
+#define BAND_PXL 4
+#define BAND_WIN (64 * BAND_PXL)
+
+struct DevCarver {
+    // base layout
+    uint8_t *rgb0;
+    int32_t *vs;
+    float *bias0;
+    float *rig0;
+    // working planes
+    uint32_t *pix;
+    float *en;
+    float *m;
+    int8_t *least;
+    float *bias;
+    float *rig;
+    int32_t *seam_x;
+    int32_t *seam_log;
+    int32_t *flags;
+};
+
+struct DpK {
+    int delta;
+    int use_rig;
+    float rigmap[2 * LQRHIP_MAX_DELTA + 1];
+    int nrg;
+    int radius;
+    int w_start;
+    int ch;
+};
+
+static thread_local std::string g_err;
+static int g_device = -1;
+
+#define HIPCK(expr)                                                                   \
+    do {                                                                              \
+        hipError_t e__ = (expr);                                                      \
+        if (e__ != hipSuccess) {                                                      \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(e__);               \
+            (void) hipGetLastError();                                                 \
+            return (e__ == hipErrorOutOfMemory) ? LQRHIP_ENOMEM : LQRHIP_EHIP;        \
+        }                                                                             \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// exactly-rounded helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double norm255(uint32_t v) { return __ddiv_rn((double) v, 255.0); }
+
+// brightness / luma of one packed pixel, in double, times alpha (E3)
+__device__ __forceinline__ double px_bright(uint32_t p, int ch, bool luma)
+{
+    double b;
+    uint32_t c0 = p & 0xffu, c1 = (p >> 8) & 0xffu, c2 = (p >> 16) & 0xffu, c3 = p >> 24;
+    if (ch <= 2) {
+        b = norm255(c0);
+        if (ch == 2) b = __dmul_rn(b, norm255(c1));
+    } else {
+        double r = norm255(c0), g = norm255(c1), bl = norm255(c2);
+        if (luma)
+            b = __dadd_rn(__dadd_rn(__dmul_rn(0.2126, r), __dmul_rn(0.7152, g)), __dmul_rn(0.0722, bl));
+        else
+            b = __ddiv_rn(__dadd_rn(__dadd_rn(r, g), bl), 3.0);
+        if (ch == 4) b = __dmul_rn(b, norm255(c3));
+    }
+    return b;
+}
+
+// gradient energy of carved-frame pixel (x,y) on a w x h frame (E4/compute_e).
+// NRG (LqrEnergyFuncBuiltinType) is a template parameter: with a run-time
+// energy selector hipcc (ROCm 7.2, gfx950) miscompiled the XABS branch of this
+// function (it returned an un-normalised channel value; scripts/dbg/t_energy2.hip
+// reproduces it), so every kernel that evaluates the energy is instantiated
+// once per energy function and the selector is resolved at launch.
+template <int NRG>
+__device__ __forceinline__ float grad_energy(const uint32_t *pix, int stride, int x, int y, int w, int h, int ch)
+{
+    if (NRG == 6) return 0.0f;
+    constexpr bool luma = (NRG >= 3);
+    constexpr int kind = NRG % 3;          // 0 norm, 1 sumabs, 2 xabs
+    const uint32_t *row = pix + (size_t) y * stride;
+    double gx, gy = 0.0;
+    if (kind != 2) {
+        if (h == 1) gy = 0.0;
+        else if (y == 0) gy = __dsub_rn(px_bright(row[stride + x], ch, luma), px_bright(row[x], ch, luma));
+        else if (y < h - 1) gy = __dmul_rn(__dsub_rn(px_bright(row[stride + x], ch, luma), px_bright(row[x - stride], ch, luma)), 0.5);
+        else gy = __dsub_rn(px_bright(row[x], ch, luma), px_bright(row[x - stride], ch, luma));
+    }
+    if (w == 1) gx = 0.0;
+    else if (x == 0) gx = __dsub_rn(px_bright(row[1], ch, luma), px_bright(row[0], ch, luma));
+    else if (x < w - 1) gx = __dmul_rn(__dsub_rn(px_bright(row[x + 1], ch, luma), px_bright(row[x - 1], ch, luma)), 0.5);
+    else gx = __dsub_rn(px_bright(row[x], ch, luma), px_bright(row[x - 1], ch, luma));
+    double g;
+    if (kind == 0) g = __dsqrt_rn(__dadd_rn(__dmul_rn(gx, gx), __dmul_rn(gy, gy)));
+    else if (kind == 1) g = __dmul_rn(__dadd_rn(fabs(gx), fabs(gy)), 0.5);
+    else g = fabs(gx);
+    return __double2float_rn(g);
+}
+
+template <int NRG>
+__device__ __forceinline__ float energy_at(const DevCarver &c, const DpK &p, int stride, int x, int y, int w, int h)
+{
+    float e = grad_energy<NRG>(c.pix, stride, x, y, w, h, p.ch);
+    if (c.bias) e = __fadd_rn(e, __fdiv_rn(c.bias[(size_t) y * stride + x], (float) p.w_start));
+    return e;
+}
+
+// resolve the run-time energy selector to a kernel instantiation
+#define NRG_DISPATCH(nrg, LAUNCH)                 \
+    switch (nrg) {                                \
+        case 0: { LAUNCH(0); break; }             \
+        case 1: { LAUNCH(1); break; }             \
+        case 2: { LAUNCH(2); break; }             \
+        case 3: { LAUNCH(3); break; }             \
+        case 4: { LAUNCH(4); break; }             \
+        case 5: { LAUNCH(5); break; }             \
+        default: { LAUNCH(6); break; }            \
+    }
+
+// ---------------------------------------------------------------------------
+// one-off kernels: working-plane init, full energy map, masks
+// ---------------------------------------------------------------------------
+__global__ void k_wk_init(const DevCarver *cs, int w, int h, int stride, int ch)
+{
+    const DevCarver c = cs[blockIdx.z];
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= stride) return;
+    size_t o = (size_t) y * stride + x;
+    uint32_t p = 0;
+    float b = 0.0f, r = 0.0f;
+    if (x < w) {
+        const uint8_t *s = c.rgb0 + ((size_t) y * w + x) * ch;
+        for (int k = 0; k < ch; k++) p |= (uint32_t) s[k] << (8 * k);
+        if (c.bias0) b = c.bias0[(size_t) y * w + x];
+        if (c.rig0) r = c.rig0[(size_t) y * w + x];
+    }
+    c.pix[o] = p;
+    if (c.bias) c.bias[o] = b;
+    if (c.rig) c.rig[o] = r;
+}
+
+template <int NRG>
+__global__ void k_emap_full(const DevCarver *cs, DpK p, int w, int h, int stride)
+{
+    const DevCarver c = cs[blockIdx.z];
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    c.en[(size_t) y * stride + x] = energy_at<NRG>(c, p, stride, x, y, w, h);
+}
+
+// E2: mask value = mean(colour)/255 * alpha/255 (help/en/index.wiki:48)
+__global__ void k_mask_add(float *plane, int w0, const uint8_t *mask, int channels, int mw, int x0, int y0, int x1, int y1,
+                           int nx, int ny, int transposed, int is_rig, int bias_factor)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= nx || y >= ny) return;
+    const uint8_t *px = mask + ((size_t) (y - y0) * mw + (x - x0)) * channels;
+    const bool has_alpha = (channels == 2 || channels >= 4);
+    const int cc = channels - (has_alpha ? 1 : 0);
+    int sum = 0;
+    for (int k = 0; k < cc; k++) sum += px[k];
+    int xc = transposed ? y + y1 : x + x1;
+    int yc = transposed ? x + x1 : y + y1;
+    size_t o = (size_t) yc * w0 + xc;
+    if (is_rig) {
+        double v = __ddiv_rn((double) sum, (double) (255 * cc));
+        if (has_alpha) v = __dmul_rn(v, __ddiv_rn((double) px[channels - 1], 255.0));
+        plane[o] = __double2float_rn(v);
+    } else {
+        double b = __ddiv_rn(__dmul_rn((double) bias_factor, (double) sum), (double) (2 * 255 * cc));
+        if (has_alpha) b = __dmul_rn(b, __ddiv_rn((double) px[channels - 1], 255.0));
+        plane[o] = __fadd_rn(plane[o], __double2float_rn(b));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// E5 / E9 (full width): cumulative-min DP row sweep, one persistent workgroup
+// per image.  The previous row of m lives in LDS (ping-pong), so the only HBM
+// traffic is en in, m + back-pointer out (9 B/px), all coalesced.  One
+// s_barrier per row.  UPDATE applies liblqr's update_mmap keep-rule to every
+// pixel of rows >= flags[FLAG_OVF_ROW]; applied to a superset of liblqr's band
+// it leaves identical memory contents (pixels outside the band have unchanged
+// inputs, float ops are deterministic).
+// ---------------------------------------------------------------------------
+template <int PXT, bool UPDATE>
+__global__ __launch_bounds__(DP_THREADS) void k_dp_sweep(const DevCarver *cs, DpK p, int w, int h, int stride, int lr)
+{
+    const DevCarver c = cs[blockIdx.x];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int wpad = (w + 3) & ~3;
+    float *prev = sm, *cur = sm + wpad;
+    const int tid = threadIdx.x;
+    int y0 = 0;
+    if (UPDATE) {
+        y0 = c.flags[FLAG_OVF_ROW];
+        if (y0 >= h) return;
+    }
+    if (y0 == 0) {
+        for (int x = tid; x < w; x += DP_THREADS) {
+            float e = c.en[x];
+            c.m[x] = e;
+            prev[x] = e;
+        }
+        y0 = 1;
+    } else {
+        for (int x = tid; x < w; x += DP_THREADS) prev[x] = c.m[(size_t) (y0 - 1) * stride + x];
+    }
+    __syncthreads();
+
+    float e_nx[PXT], mo_nx[PXT], rf_nx[PXT];
+    int lo_nx[PXT];
+    auto prefetch = [&](int y) {
+#pragma unroll
+        for (int k = 0; k < PXT; k++) {
+            int x = tid + k * DP_THREADS;
+            if (x < w && y < h) {
+                size_t o = (size_t) y * stride + x;
+                e_nx[k] = c.en[o];
+                if (UPDATE) { mo_nx[k] = c.m[o]; lo_nx[k] = c.least[o]; }
+                if (c.rig) rf_nx[k] = c.rig[o];
+            }
+        }
+    };
+    prefetch(y0);
+    for (int y = y0; y < h; y++) {
+        float e[PXT], mo[PXT], rf[PXT];
+        int lo[PXT];
+#pragma unroll
+        for (int k = 0; k < PXT; k++) { e[k] = e_nx[k]; mo[k] = mo_nx[k]; lo[k] = lo_nx[k]; rf[k] = rf_nx[k]; }
+        prefetch(y + 1);
+#pragma unroll
+        for (int k = 0; k < PXT; k++) {
+            int x = tid + k * DP_THREADS;
+            if (x < w) {
+                const int dlo = max(-x, -p.delta), dhi = min(w - 1 - x, p.delta);
+                const float rfact = c.rig ? rf[k] : 1.0f;
+                float best = prev[x + dlo];
+                if (p.use_rig) best = __fadd_rn(best, __fmul_rn(rfact, p.rigmap[dlo + p.delta]));
+                int bdx = dlo;
+                for (int dx = dlo + 1; dx <= dhi; dx++) {
+                    float cand = prev[x + dx];
+                    if (p.use_rig) cand = __fadd_rn(cand, __fmul_rn(rfact, p.rigmap[dx + p.delta]));
+                    if (cand < best || (cand == best && lr)) { best = cand; bdx = dx; }
+                }
+                float nm = __fadd_rn(e[k], best);
+                size_t o = (size_t) y * stride + x;
+                if (UPDATE) {
+                    if (lo[k] == bdx && (double) fabsf(__fsub_rn(mo[k], nm)) < 1e-5) nm = mo[k];
+                    else c.m[o] = nm;
+                } else {
+                    c.m[o] = nm;
+                }
+                c.least[o] = (int8_t) bdx;
+                cur[x] = nm;
+            }
+        }
+        __syncthreads();
+        float *t = prev; prev = cur; cur = t;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// E7 build_vpath: argmin of the last row of m with liblqr's tie rule, then the
+// backtrack through the back-pointer plane.  One workgroup per image.  The
+// backtrack stages a (2*R*delta+1) x R window of back-pointers in LDS per
+// chunk of R rows so that the H-step pointer chase never waits on HBM.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, int w, int h, int stride, int lr, int delta,
+                                                          int log_index)
+{
+    const DevCarver c = cs[blockIdx.x];
+    __shared__ float s_val[VPATH_THREADS];
+    __shared__ int s_idx[VPATH_THREADS];
+    __shared__ int s_x;
+    __shared__ int8_t tile[64 * 132];
+    const int tid = threadIdx.x;
+
+    // ---- argmin over the last row: leftmost (lr=0) / rightmost (lr=1) of equals
+    const float *mrow = c.m + (size_t) (h - 1) * stride;
+    float bv = __int_as_float(0x7f800000);    // +inf
+    int bi = -1;
+    for (int x = tid; x < w; x += VPATH_THREADS) {
+        float v = mrow[x];
+        if (v < bv || (v == bv && lr)) { bv = v; bi = x; }
+    }
+    s_val[tid] = bv; s_idx[tid] = bi;
+    __syncthreads();
+    for (int s = VPATH_THREADS / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            float v2 = s_val[tid + s]; int i2 = s_idx[tid + s];
+            float v1 = s_val[tid]; int i1 = s_idx[tid];
+            bool take2;
+            if (i2 < 0) take2 = false;
+            else if (i1 < 0) take2 = true;
+            else if (v2 < v1) take2 = true;
+            else if (v2 > v1) take2 = false;
+            else take2 = lr ? (i2 > i1) : (i2 < i1);
+            if (take2) { s_val[tid] = v2; s_idx[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        // liblqr starts from m = 2^29: a candidate must beat it (or tie it when lr == 1)
+        const float lim = 536870912.0f;
+        float v = s_val[0]; int i = s_idx[0];
+        bool ok = (i >= 0) && (v < lim || (v == lim && lr));
+        s_x = ok ? i : 0;
+    }
+    __syncthreads();
+
+    // ---- backtrack
+    int32_t *seam = c.seam_x;
+    int32_t *logp = c.seam_log + (size_t) log_index * h;
+    const int R = delta > 0 ? max(1, 64 / delta) : 64;      // rows per chunk, R*delta <= 64
+    const int half = (R > 64 ? 64 : R) * delta;
+    const int rows_per_chunk = R > 64 ? 64 : R;
+    const int tw = 2 * half + 1;                              // <= 129
+    int y_top = h - 1;
+    while (y_top >= 1) {
+        const int x0 = s_x;
+        const int nrows = min(rows_per_chunk, y_top);         // rows y_top .. y_top-nrows+1 (all >= 1)
+        for (int i = tid; i < nrows * tw; i += VPATH_THREADS) {
+            int r = i / tw, col = i - r * tw;
+            int x = x0 - half + col, y = y_top - r;
+            int8_t d = 0;
+            if (x >= 0 && x < w) d = c.least[(size_t) y * stride + x];
+            tile[r * 132 + col] = d;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int x = x0;
+            for (int r = 0; r < nrows; r++) {
+                int y = y_top - r;
+                seam[y] = x; logp[y] = x;
+                int d = tile[r * 132 + (x - x0 + half)];
+                if (d == LEAST_INVALID) d = 0;
+                x += d;
+            }
+            s_x = x;
+        }
+        __syncthreads();
+        y_top -= nrows;
+    }
+    if (tid == 0) { seam[0] = s_x; logp[0] = s_x; }
+}
+
+// ---------------------------------------------------------------------------
+// E8 carve: shift every working plane left by one from the seam on, one wave
+// per row, 16 B per lane, in place.  The dominant HBM kernel: algorithmic
+// traffic is (read + write) of the part of each row right of the seam.
+// The back-pointer plane is re-based on the fly: a stored dx stays valid unless
+// pixel and parent are on different sides of the seam.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void shift_row_u32(uint32_t *row, int v, int wnew, int lane)
+{
+    int base = v & ~3;
+    // 4 chunks of 256 px in flight: all loads of a group are issued before its stores
+    for (; base < wnew; base += 1024) {
+        uint4 a[4]; uint32_t nx[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int x = base + u * 256 + lane * 4;
+            if (x < wnew) { a[u] = *(const uint4 *) (row + x); nx[u] = row[x + 4]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int x = base + u * 256 + lane * 4;
+            if (x < wnew) {
+                uint4 o;
+                o.x = (x >= v) ? a[u].y : a[u].x;
+                o.y = (x + 1 >= v) ? a[u].z : a[u].y;
+                o.z = (x + 2 >= v) ? a[u].w : a[u].z;
+                o.w = (x + 3 >= v) ? nx[u] : a[u].w;
+                *(uint4 *) (row + x) = o;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void shift_row_least(int8_t *row, int v, int vprev, int y, int delta, int wnew, int lane)
+{
+    int start = (y > 0) ? min(v, vprev - delta) : v;
+    if (start < 0) start = 0;
+    uint32_t *row32 = (uint32_t *) row;
+    for (int base = start & ~3; base < wnew; base += 256) {
+        int x = base + lane * 4;
+        if (x < wnew) {
+            uint32_t a = row32[x >> 2], nx = row32[(x >> 2) + 1];
+            uint64_t both = ((uint64_t) nx << 32) | a;
+            uint32_t o = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int xx = x + j;
+                bool right = (xx >= v);
+                int dx = (int8_t) (both >> (8 * (j + (right ? 1 : 0))));
+                int xo = right ? xx + 1 : xx;
+                if (y > 0 && dx != LEAST_INVALID) {
+                    int q = xo + dx;
+                    if (q == vprev) dx = LEAST_INVALID;            // parent was the carved pixel
+                    else dx = q - (q > vprev ? 1 : 0) - xx;
+                }
+                o |= (uint32_t) (uint8_t) (int8_t) dx << (8 * j);
+            }
+            row32[x >> 2] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h, int stride, int delta, int move_dp)
+{
+    const DevCarver c = cs[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (y >= h) return;
+    const int v = c.seam_x[y];
+    const int wnew = w - 1;
+    size_t ro = (size_t) y * stride;
+    shift_row_u32(c.pix + ro, v, wnew, lane);
+    shift_row_u32((uint32_t *) (c.en + ro), v, wnew, lane);
+    if (c.bias) shift_row_u32((uint32_t *) (c.bias + ro), v, wnew, lane);
+    if (c.rig) shift_row_u32((uint32_t *) (c.rig + ro), v, wnew, lane);
+    if (move_dp) {
+        shift_row_u32((uint32_t *) (c.m + ro), v, wnew, lane);
+        int vprev = y > 0 ? c.seam_x[y - 1] : 0;
+        shift_row_least(c.least + ro, v, vprev, y, delta, wnew, lane);
+    }
+}
+
+// changed-energy interval of row y after carving (liblqr update_emap), w = new width
+__device__ __forceinline__ void nrg_interval(const int32_t *seam, int y, int h, int w, int radius, int &xmin, int &xmax)
+{
+    int y1a = max(y - radius, 0), y1b = min(y + radius, h - 1);
+    int lo = seam[y], hi = seam[y] - 1;
+    for (int y1 = y1a; y1 <= y1b; y1++) {
+        int x = seam[y1];
+        lo = min(lo, x - radius);
+        hi = max(hi, x + radius - 1);
+    }
+    xmin = max(0, lo);
+    xmax = min(w - 1, hi);
+}
+
+// E6 update_emap: recompute en next to the carved seam (w = new width)
+template <int NRG>
+__global__ void k_emap_update(const DevCarver *cs, DpK p, int w, int h, int stride)
+{
+    const DevCarver c = cs[blockIdx.y];
+    int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= h) return;
+    int xmin, xmax;
+    nrg_interval(c.seam_x, y, h, w, p.radius, xmin, xmax);
+    for (int x = xmin; x <= xmax; x++) c.en[(size_t) y * stride + x] = energy_at<NRG>(c, p, stride, x, y, w, h);
+}
+
+// ---------------------------------------------------------------------------
+// E9 update_mmap, band form: one wave per image walks the rows; lane L owns
+// BAND_PXL consecutive pixels of a BAND_WIN-wide window around the band.  The
+// previous row of m stays in LDS; rows are prefetched PF deep into registers so
+// the per-row critical path is LDS + VALU only.  If the band ever leaves /
+// outgrows the window the kernel records the row in flags[FLAG_OVF_ROW] and the
+// full-width sweep (k_dp_sweep<UPDATE>) finishes from there -- same results.
+// ---------------------------------------------------------------------------
+#define BAND_PF 4
+struct BandRow {
+    float mo[BAND_PXL];
+    float e[BAND_PXL];
+    float rf[BAND_PXL];
+    uint32_t lo;
+};
+
+__global__ __launch_bounds__(64) void k_band_update(const DevCarver *cs, DpK p, int w, int h, int stride, int lr)
+{
+    const DevCarver c = cs[blockIdx.x];
+    __shared__ __attribute__((aligned(16))) float prow[BAND_WIN + 2 * LQRHIP_MAX_DELTA + 8];
+    const int lane = threadIdx.x;
+    const int delta = p.delta;
+    const int32_t *seam = c.seam_x;
+    float *pr = prow + LQRHIP_MAX_DELTA + 4;      // pr[-delta .. BAND_WIN+delta) addressable
+
+    int a, b;                                     // current band (liblqr's x_min, x_max)
+    {
+        int n0, n1;
+        nrg_interval(seam, 0, h, w, p.radius, n0, n1);
+        a = max(n0, 0); b = min(n1, w - 1);
+        for (int x = a + lane; x <= b; x += 64) c.m[x] = c.en[x];      // row 0: m = en
+    }
+    if (h < 2) { if (lane == 0) c.flags[FLAG_OVF_ROW] = h; return; }
+
+    int y = 1;
+    int ovf = h;
+    const int wmax_base = max(0, ((w + 3) & ~3) - BAND_WIN);
+    while (y < h) {
+        // ---- (re)base the window for rows y.. : centre it on the band of row y
+        int na, nb;
+        {
+            int n0, n1;
+            nrg_interval(seam, y, h, w, p.radius, n0, n1);
+            na = max(min(a, n0) - delta, 0);
+            nb = min(max(b, n1) + delta, w - 1);
+        }
+        if (nb - na + 1 + 2 * delta > BAND_WIN - 8) { ovf = y; break; }
+        int centre = (na + nb) >> 1;
+        int B = min(max((centre - BAND_WIN / 2) & ~3, 0), wmax_base);
+        if (na - delta < B && B > 0) { ovf = y; break; }
+        if (nb + delta >= B + BAND_WIN && B + BAND_WIN < w) { ovf = y; break; }
+        const int x0 = B + lane * BAND_PXL;
+        // previous row of m over the window (+halo) into LDS.  Row y-1 was stored
+        // by this wave (or is untouched): make the stores visible first.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        {
+            const float *mp = c.m + (size_t) (y - 1) * stride;
+            for (int i = lane; i < BAND_WIN + 2 * delta; i += 64) {
+                int x = B - delta + i;
+                float v = 0.0f;
+                if (x >= 0 && x < w) v = __hip_atomic_load((float *) (mp + x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pr[i - delta] = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        BandRow q[BAND_PF];
+        auto load_row = [&](BandRow &r, int yy) {
+            if (yy < h) {
+                size_t o = (size_t) yy * stride + x0;
+                float4 mv = *(const float4 *) (c.m + o);
+                float4 ev = *(const float4 *) (c.en + o);
+                r.mo[0] = mv.x; r.mo[1] = mv.y; r.mo[2] = mv.z; r.mo[3] = mv.w;
+                r.e[0] = ev.x; r.e[1] = ev.y; r.e[2] = ev.z; r.e[3] = ev.w;
+                r.lo = *(const uint32_t *) (c.least + o);
+                if (c.rig) {
+                    float4 rv = *(const float4 *) (c.rig + o);
+                    r.rf[0] = rv.x; r.rf[1] = rv.y; r.rf[2] = rv.z; r.rf[3] = rv.w;
+                }
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < BAND_PF; d++) load_row(q[d], y + d);
+
+        bool rebase = false;
+        while (y < h && !rebase) {
+#pragma unroll
+            for (int d = 0; d < BAND_PF; d++) {
+                if (y < h && !rebase) {
+                    int n0, n1;
+                    nrg_interval(seam, y, h, w, p.radius, n0, n1);
+                    int ra = max(min(a, n0) - delta, 0);
+                    int rb = min(max(b, n1) + delta, w - 1);
+                    // the band (plus its parents) must sit inside the window
+                    bool fits = (ra - delta >= B || B == 0) && (rb + delta < B + BAND_WIN || B + BAND_WIN >= w);
+                    if (!fits) {
+                        rebase = true;
+                    } else {
+                        BandRow &r = q[d];
+                        float mc[BAND_PXL];
+                        uint32_t lnew = 0;
+                        uint32_t nonstop = 0;
+#pragma unroll
+                        for (int j = 0; j < BAND_PXL; j++) {
+                            const int x = x0 + j;
+                            const bool inband = (x >= ra && x <= rb);
+                            float outm = r.mo[j];
+                            int outl = (int8_t) (r.lo >> (8 * j));
+                            if (inband) {
+                                const int dlo = max(-x, -delta), dhi = min(w - 1 - x, delta);
+                                const float rfact = c.rig ? r.rf[j] : 1.0f;
+                                const int li = x - B;
+                                float best = pr[li + dlo];
+                                if (p.use_rig) best = __fadd_rn(best, __fmul_rn(rfact, p.rigmap[dlo + delta]));
+                                int bdx = dlo;
+                                for (int dx = dlo + 1; dx <= dhi; dx++) {
+                                    float cand = pr[li + dx];
+                                    if (p.use_rig) cand = __fadd_rn(cand, __fmul_rn(rfact, p.rigmap[dx + delta]));
+                                    if (cand < best || (cand == best && lr)) { best = cand; bdx = dx; }
+                                }
+                                float nm = __fadd_rn(r.e[j], best);
+                                bool stop = (outl == bdx) && ((double) fabsf(__fsub_rn(r.mo[j], nm)) < 1e-5);
+                                if (!stop) { outm = nm; nonstop |= 1u << j; }
+                                outl = bdx;
+                            }
+                            mc[j] = outm;
+                            lnew |= (uint32_t) (uint8_t) (int8_t) outl << (8 * j);
+                        }
+                        // all lanes have read pr[] for this row: overwrite it with row y
+                        __builtin_amdgcn_wave_barrier();
+                        *(float4 *) (pr + lane * BAND_PXL) = make_float4(mc[0], mc[1], mc[2], mc[3]);
+                        {
+                            size_t o = (size_t) y * stride + x0;
+                            if (x0 < stride) {
+                                *(float4 *) (c.m + o) = make_float4(mc[0], mc[1], mc[2], mc[3]);
+                                *(uint32_t *) (c.least + o) = lnew;
+                            }
+                        }
+                        // halo of pr (parents outside the window never matter: see `fits`)
+                        // ---- shrink the band: leading run of stops advances a, trailing run pulls b back
+                        unsigned long long bal = __ballot(nonstop != 0);
+                        if (bal == 0ull) {
+                            a = rb + 1; b = ra;
+                        } else {
+                            int fl = __ffsll((long long) bal) - 1;
+                            int ll = 63 - __clzll((long long) bal);
+                            uint32_t mf = (uint32_t) __shfl((int) nonstop, fl), ml = (uint32_t) __shfl((int) nonstop, ll);
+                            int first = B + fl * BAND_PXL + (__ffs((int) mf) - 1);
+                            int last = B + ll * BAND_PXL + (31 - __clz((int) ml));
+                            a = first;
+                            b = (last == rb) ? rb : last + 1;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        load_row(q[d], y + BAND_PF);
+                        y++;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) c.flags[FLAG_OVF_ROW] = ovf;
+    // band state for the continuation is not needed: the full-width sweep applies the rule everywhere
+}
+
+// ---------------------------------------------------------------------------
+// visibility map: seam log -> levels in the base layout (E8 update_vsmap for a
+// whole session), inflate (E14), flatten / read-out compaction (E11, E12),
+// transpose (E11)
+// ---------------------------------------------------------------------------
+// exclusive scan of 0/1 flags over a 256-thread block; returns rank, total via reference
+__device__ __forceinline__ int block_rank_256(bool flag, int *s_wave, int &total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long bal = __ballot(flag);
+    int r = __popcll(bal & ((1ull << lane) - 1ull));
+    __syncthreads();                 // protect s_wave reuse
+    if (lane == 0) s_wave[wv] = __popcll(bal);
+    __syncthreads();
+    int off = 0;
+    total = 0;
+    for (int i = 0; i < 4; i++) { int t = s_wave[i]; if (i < wv) off += t; total += t; }
+    return r + off;
+}
+
+__global__ __launch_bounds__(256) void k_vs_commit(const DevCarver *cs, int w0, int h0, int wc0, int n_seams, int first_level,
+                                                    int finish)
+{
+    const DevCarver c = cs[blockIdx.y];
+    extern __shared__ int smi[];
+    int *xs = smi;                      // [n_seams]
+    int *lvl = smi + n_seams;           // [wc0]
+    __shared__ int s_wave[4];
+    const int y = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < n_seams; k += 256) xs[k] = c.seam_log[(size_t) k * h0 + y];
+    for (int i = tid; i < wc0; i += 256) lvl[i] = 0;
+    __syncthreads();
+    // position of seam k in the session-start frame: undo the earlier removals
+    for (int k = tid; k < n_seams; k += 256) {
+        int pz = xs[k];
+        for (int j = k - 1; j >= 0; j--) if (xs[j] <= pz) pz++;
+        lvl[pz] = first_level + k;
+    }
+    __syncthreads();
+    int32_t *vrow = c.vs + (size_t) y * w0;
+    int carry = 0;
+    for (int base = 0; base < w0; base += 256) {
+        int col = base + tid;
+        bool z = (col < w0) && (vrow[col] == 0);
+        int total;
+        int rank = carry + block_rank_256(z, s_wave, total);
+        if (z) {
+            int l = lvl[rank];
+            if (l == 0 && finish) l = w0;       // liblqr finish_vsmap: the last column
+            if (l) vrow[col] = l;
+        }
+        carry += total;
+    }
+}
+
+// E14: one block per row.  dup(c) = the seam was computed in this session.
+__global__ __launch_bounds__(256) void k_inflate(const uint8_t *rgb, const int32_t *vs, const float *bias, const float *rig,
+                                                  uint8_t *nrgb, int32_t *nvs, float *nbias, float *nrig, int w0, int w1, int ch,
+                                                  int l, int max_level)
+{
+    __shared__ int s_wave[4];
+    const int y = blockIdx.x, tid = threadIdx.x;
+    const int32_t *vrow = vs + (size_t) y * w0;
+    const size_t ri = (size_t) y * w0, ro = (size_t) y * w1;
+    int carry = 0;
+    for (int base = 0; base < w0; base += 256) {
+        int col = base + tid;
+        int v = (col < w0) ? vrow[col] : 0;
+        bool dup = (col < w0) && v != 0 && v <= l + max_level - 1 && v >= 2 * max_level - 1;
+        int total;
+        int rank = carry + block_rank_256(dup, s_wave, total);   // dups strictly before col
+        if (col < w0) {
+            int z = col + rank;
+            int left = col > 0 ? col - 1 : col;
+            if (dup) {
+                for (int k = 0; k < ch; k++)
+                    nrgb[(ro + z) * ch + k] = (uint8_t) (((int) rgb[(ri + left) * ch + k] + (int) rgb[(ri + col) * ch + k]) / 2);
+                if (nbias) nbias[ro + z] = __fmul_rn(__fadd_rn(bias[ri + left], bias[ri + col]), 0.5f);
+                if (nrig) nrig[ro + z] = __fmul_rn(__fadd_rn(rig[ri + left], rig[ri + col]), 0.5f);
+                if (nvs) nvs[ro + z] = l - v + max_level;
+                z++;
+            }
+            for (int k = 0; k < ch; k++) nrgb[(ro + z) * ch + k] = rgb[(ri + col) * ch + k];
+            if (nbias) nbias[ro + z] = bias[ri + col];
+            if (nrig) nrig[ro + z] = rig[ri + col];
+            if (nvs) nvs[ro + z] = v ? v + l - max_level + 1 : 0;
+        }
+        carry += total;
+    }
+}
+
+// E11/E12: compaction of the pixels visible at `level`; any output may be null
+__global__ __launch_bounds__(256) void k_compact(const uint8_t *rgb, const int32_t *vs, const float *bias, const float *rig,
+                                                  uint8_t *nrgb, float *nbias, float *nrig, int32_t *nvmap, int w0, int w, int ch,
+                                                  int level, int depth)
+{
+    __shared__ int s_wave[4];
+    const int y = blockIdx.x, tid = threadIdx.x;
+    const int32_t *vrow = vs + (size_t) y * w0;
+    const size_t ri = (size_t) y * w0, ro = (size_t) y * w;
+    int carry = 0;
+    for (int base = 0; base < w0; base += 256) {
+        int col = base + tid;
+        int v = (col < w0) ? vrow[col] : 0;
+        bool keep = (col < w0) && (v == 0 || v >= level);
+        int total;
+        int rank = carry + block_rank_256(keep, s_wave, total);
+        if (keep && rank < w) {
+            if (nrgb) for (int k = 0; k < ch; k++) nrgb[(ro + rank) * ch + k] = rgb[(ri + col) * ch + k];
+            if (nbias) nbias[ro + rank] = bias[ri + col];
+            if (nrig) nrig[ro + rank] = rig[ri + col];
+            if (nvmap) nvmap[ro + rank] = v ? v - depth : 0;
+        }
+        carry += total;
+    }
+}
+
+__global__ void k_transpose(const uint8_t *rgb, const float *bias, const float *rig, uint8_t *nrgb, float *nbias, float *nrig,
+                            int w, int h, int ch)
+{
+    __shared__ uint32_t t32[32][33];
+    __shared__ float tb[32][33], tr[32][33];
+    int x = blockIdx.x * 32 + threadIdx.x;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        int y = blockIdx.y * 32 + i;
+        if (x < w && y < h) {
+            uint32_t p = 0;
+            for (int k = 0; k < ch; k++) p |= (uint32_t) rgb[((size_t) y * w + x) * ch + k] << (8 * k);
+            t32[i][threadIdx.x] = p;
+            if (bias) tb[i][threadIdx.x] = bias[(size_t) y * w + x];
+            if (rig) tr[i][threadIdx.x] = rig[(size_t) y * w + x];
+        }
+    }
+    __syncthreads();
+    int oy = blockIdx.y * 32 + threadIdx.x;        // output column index = old y
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        int ox = blockIdx.x * 32 + i;              // output row index = old x
+        if (ox < w && oy < h) {
+            uint32_t p = t32[threadIdx.x][i];
+            size_t o = (size_t) ox * h + oy;
+            for (int k = 0; k < ch; k++) nrgb[o * ch + k] = (uint8_t) (p >> (8 * k));
+            if (nbias) nbias[o] = tb[threadIdx.x][i];
+            if (nrig) nrig[o] = tr[threadIdx.x][i];
+        }
+    }
+}
+
+// ===========================================================================
+// host side of the shim
+// ===========================================================================
+struct LqrHipCarver {
+    int ch = 0;
+    int w0 = 0, h0 = 0;              // base layout dims
+    // base planes
+    uint8_t *rgb0 = nullptr;
+    int32_t *vs = nullptr;           // owned by roots only
+    float *bias0 = nullptr, *rig0 = nullptr;
+    // working planes
+    int active = 0;
+    int stride = 0, wk_h = 0;
+    uint32_t *pix = nullptr;
+    float *en = nullptr, *m = nullptr, *bias = nullptr, *rig = nullptr;
+    int8_t *least = nullptr;
+    int32_t *seam_x = nullptr, *seam_log = nullptr, *flags = nullptr;
+    int log_cap = 0, log_h = 0;
+    LqrHipCarver *root = nullptr;
+    std::vector<LqrHipCarver *> aux;
+    LqrHipBatch *batch = nullptr;
+};
+
+struct LqrHipBatch {
+    std::vector<LqrHipCarver *> cs;
+    DevCarver *d_desc = nullptr;
+    hipStream_t stream = nullptr;
+    bool dirty = true;
+};
+
+struct ProfRec {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    double bytes = 0;
+};
+static bool g_prof = false;
+static std::map<std::string, ProfRec> g_profrec;
+static hipStream_t g_stream0 = nullptr;
+
+extern "C" const char *lqrhip_last_error(void) { return g_err.c_str(); }
+
+extern "C" int lqrhip_init(void)
+{
+    if (g_device >= 0) return g_device;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        g_err = "no HIP device visible: the MI355X engine needs a gfx950 GPU (there is no CPU fallback)";
+        (void) hipGetLastError();
+        return LQRHIP_EHIP;
+    }
+    int dev = 0;
+    const char *lr = getenv("LOCAL_RANK");
+    if (lr) dev = atoi(lr) % n;
+    HIPCK(hipSetDevice(dev));
+    HIPCK(hipStreamCreateWithFlags(&g_stream0, hipStreamNonBlocking));
+    g_device = dev;
+    return dev;
+}
+
+template <typename T>
+static int dmalloc(T **p, size_t n)
+{
+    *p = nullptr;
+    HIPCK(hipMalloc((void **) p, (n ? n : 1) * sizeof(T)));
+    return 0;
+}
+template <typename T>
+static void dfree(T *&p)
+{
+    if (p) (void) hipFree(p);
+    p = nullptr;
+}
+
+static int batch_sync_of(LqrHipCarver *c)
+{
+    LqrHipCarver *r = c->root ? c->root : c;
+    if (r->batch) HIPCK(hipStreamSynchronize(r->batch->stream));
+    return 0;
+}
+
+extern "C" LqrHipCarver *lqrhip_carver_create(const unsigned char *rgb, int w, int h, int channels)
+{
+    if (lqrhip_init() < 0) return nullptr;
+    LqrHipCarver *c = new LqrHipCarver();
+    c->ch = channels; c->w0 = w; c->h0 = h;
+    size_t n = (size_t) w * h;
+    if (dmalloc(&c->rgb0, n * channels) || dmalloc(&c->vs, n)) { lqrhip_carver_destroy(c); return nullptr; }
+    if (hipMemcpy(c->rgb0, rgb, n * channels, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(c->vs, 0, n * sizeof(int32_t)) != hipSuccess) {
+        g_err = "upload failed";
+        lqrhip_carver_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+static void free_working(LqrHipCarver *c)
+{
+    dfree(c->pix); dfree(c->en); dfree(c->m); dfree(c->least); dfree(c->bias); dfree(c->rig);
+    dfree(c->seam_x); dfree(c->seam_log); dfree(c->flags);
+    c->log_cap = 0;
+}
+
+extern "C" void lqrhip_carver_destroy(LqrHipCarver *c)
+{
+    if (!c) return;
+    (void) hipDeviceSynchronize();
+    dfree(c->rgb0);
+    if (!c->root) dfree(c->vs);
+    dfree(c->bias0); dfree(c->rig0);
+    free_working(c);
+    delete c;
+}
+
+extern "C" int lqrhip_carver_attach(LqrHipCarver *root, LqrHipCarver *aux)
+{
+    if (root->w0 != aux->w0 || root->h0 != aux->h0) return LQRHIP_EARG;
+    dfree(aux->vs);
+    aux->vs = root->vs;
+    aux->root = root;
+    root->aux.push_back(aux);
+    if (root->batch) root->batch->dirty = true;
+    return 0;
+}
+
+extern "C" int lqrhip_carver_activate(LqrHipCarver *c)
+{
+    c->active = 1;      // working planes are allocated lazily by lqrhip_wk_init
+    return 0;
+}
+
+// (re)allocate the working planes for a w x h carved frame
+static int ensure_working(LqrHipCarver *c, int w, int h)
+{
+    int stride = ((w + 16) + 63) & ~63;
+    bool need_bias = c->bias0 != nullptr, need_rig = c->rig0 != nullptr;
+    if (c->pix && c->stride == stride && c->wk_h == h && (!!c->bias == need_bias) && (!!c->rig == need_rig)) return 0;
+    free_working(c);
+    size_t n = (size_t) stride * (h + 1) + 1024;
+    int rc;
+    if ((rc = dmalloc(&c->pix, n)) || (rc = dmalloc(&c->en, n)) || (rc = dmalloc(&c->m, n)) || (rc = dmalloc(&c->least, n)) ||
+        (rc = dmalloc(&c->seam_x, (size_t) h + 8)) || (rc = dmalloc(&c->flags, FLAG_COUNT)))
+        return rc;
+    if (need_bias && (rc = dmalloc(&c->bias, n))) return rc;
+    if (need_rig && (rc = dmalloc(&c->rig, n))) return rc;
+    HIPCK(hipMemset(c->least, 0, n));
+    HIPCK(hipMemset(c->m, 0, n * sizeof(float)));
+    HIPCK(hipMemset(c->en, 0, n * sizeof(float)));
+    HIPCK(hipMemset(c->pix, 0, n * sizeof(uint32_t)));
+    HIPCK(hipMemset(c->flags, 0, FLAG_COUNT * sizeof(int32_t)));
+    c->stride = stride; c->wk_h = h;
+    if (c->batch) c->batch->dirty = true;
+    return 0;
+}
+
+static int ensure_log(LqrHipCarver *c, int n_seams, int h)
+{
+    if (c->seam_log && c->log_cap >= n_seams && c->log_h == h) return 0;
+    dfree(c->seam_log);
+    int rc = dmalloc(&c->seam_log, (size_t) n_seams * h);
+    if (rc) return rc;
+    c->log_cap = n_seams; c->log_h = h;
+    if (c->batch) c->batch->dirty = true;
+    return 0;
+}
+
+extern "C" int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int channels, int width, int height, int x_off,
+                               int y_off, int transposed, int is_rigmask, int bias_factor)
+{
+    int rc = batch_sync_of(c);
+    if (rc) return rc;
+    size_t n = (size_t) c->w0 * c->h0;
+    float **plane = is_rigmask ? &c->rig0 : &c->bias0;
+    if (!*plane) {
+        if ((rc = dmalloc(plane, n))) return rc;
+        HIPCK(hipMemset(*plane, 0, n * sizeof(float)));
+        if (c->batch) c->batch->dirty = true;
+    }
+    int wt = transposed ? c->h0 : c->w0, ht = transposed ? c->w0 : c->h0;
+    int x0 = x_off < 0 ? x_off : 0, y0 = y_off < 0 ? y_off : 0;
+    int x1 = x_off > 0 ? x_off : 0, y1 = y_off > 0 ? y_off : 0;
+    int x2 = wt < width + x_off ? wt : width + x_off, y2 = ht < height + y_off ? ht : height + y_off;
+    int nx = x2 - x1, ny = y2 - y1;
+    if (nx <= 0 || ny <= 0) return 0;
+    uint8_t *dmask = nullptr;
+    size_t mbytes = (size_t) width * height * channels;
+    if ((rc = dmalloc(&dmask, mbytes))) return rc;
+    HIPCK(hipMemcpy(dmask, mask, mbytes, hipMemcpyHostToDevice));
+    dim3 grid((nx + 255) / 256, ny);
+    hipLaunchKernelGGL(k_mask_add, grid, dim3(256), 0, g_stream0, *plane, c->w0, dmask, channels, width, x0, y0, x1, y1, nx, ny,
+                       transposed, is_rigmask, bias_factor);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(g_stream0));
+    dfree(dmask);
+    return 0;
+}
+
+// ---- batch -----------------------------------------------------------------
+extern "C" LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n)
+{
+    if (lqrhip_init() < 0 || n <= 0) return nullptr;
+    LqrHipBatch *b = new LqrHipBatch();
+    for (int i = 0; i < n; i++) {
+        b->cs.push_back(carvers[i]);
+        carvers[i]->batch = b;
+    }
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **) &b->d_desc, sizeof(DevCarver) * n) != hipSuccess) {
+        g_err = "batch_create failed";
+        delete b;
+        return nullptr;
+    }
+    return b;
+}
+
+extern "C" void lqrhip_batch_destroy(LqrHipBatch *b)
+{
+    if (!b) return;
+    if (b->stream) { (void) hipStreamSynchronize(b->stream); (void) hipStreamDestroy(b->stream); }
+    for (auto *c : b->cs) if (c->batch == b) c->batch = nullptr;
+    if (b->d_desc) (void) hipFree(b->d_desc);
+    delete b;
+}
+
+extern "C" int lqrhip_batch_sync(LqrHipBatch *b)
+{
+    HIPCK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+extern "C" void *lqrhip_batch_stream(LqrHipBatch *b) { return (void *) b->stream; }
+
+static DevCarver make_desc(const LqrHipCarver *c)
+{
+    DevCarver d;
+    d.rgb0 = c->rgb0; d.vs = c->vs; d.bias0 = c->bias0; d.rig0 = c->rig0;
+    d.pix = c->pix; d.en = c->en; d.m = c->m; d.least = c->least; d.bias = c->bias; d.rig = c->rig;
+    d.seam_x = c->seam_x; d.seam_log = c->seam_log; d.flags = c->flags;
+    return d;
+}
+
+static int batch_upload(LqrHipBatch *b)
+{
+    if (!b->dirty) return 0;
+    std::vector<DevCarver> h;
+    for (auto *c : b->cs) h.push_back(make_desc(c));
+    HIPCK(hipStreamSynchronize(b->stream));
+    HIPCK(hipMemcpy(b->d_desc, h.data(), sizeof(DevCarver) * h.size(), hipMemcpyHostToDevice));
+    b->dirty = false;
+    return 0;
+}
+
+static DpK make_dpk(const LqrHipDpParams *p, int ch)
+{
+    DpK k;
+    k.delta = p->delta_x; k.use_rig = p->use_rigidity;
+    memcpy(k.rigmap, p->rigidity_map, sizeof k.rigmap);
+    k.nrg = p->nrg_func; k.radius = p->nrg_radius; k.w_start = p->w_start; k.ch = ch;
+    return k;
+}
+
+struct ProfScope {
+    ProfRec *rec = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t s;
+    ProfScope(const char *name, hipStream_t stream, double bytes) : s(stream)
+    {
+        if (!g_prof) return;
+        rec = &g_profrec[name];
+        rec->bytes += bytes;
+        (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
+        (void) hipEventRecord(e0, s);
+    }
+    ~ProfScope()
+    {
+        if (!rec) return;
+        (void) hipEventRecord(e1, s);
+        rec->ev.emplace_back(e0, e1);
+    }
+};
+
+extern "C" void lqrhip_prof_enable(int on) { g_prof = on != 0; }
+extern "C" void lqrhip_prof_reset(void)
+{
+    for (auto &kv : g_profrec) for (auto &e : kv.second.ev) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
+    g_profrec.clear();
+}
+extern "C" int lqrhip_prof_get(const char *kernel, double *ms_total, long long *launches, double *bytes_total)
+{
+    auto it = g_profrec.find(kernel);
+    *ms_total = 0; *launches = 0; *bytes_total = 0;
+    if (it == g_profrec.end()) return 0;
+    (void) hipDeviceSynchronize();
+    for (auto &e : it->second.ev) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) *ms_total += ms;
+    }
+    *launches = (long long) it->second.ev.size();
+    *bytes_total = it->second.bytes;
+    return 0;
+}
+
+extern "C" int lqrhip_wk_init(LqrHipBatch *b)
+{
+    LqrHipCarver *c0 = b->cs[0];
+    int w = c0->w0, h = c0->h0, rc;
+    for (auto *c : b->cs) {
+        if (c->w0 != w || c->h0 != h || c->ch != c0->ch) return LQRHIP_EARG;
+        if ((rc = ensure_working(c, w, h))) return rc;
+    }
+    if ((rc = batch_upload(b))) return rc;
+    dim3 grid((c0->stride + 255) / 256, h, (unsigned) b->cs.size());
+    hipLaunchKernelGGL(k_wk_init, grid, dim3(256), 0, b->stream, b->d_desc, w, h, c0->stride, c0->ch);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lqrhip_emap_build(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h)
+{
+    int rc;
+    if ((rc = batch_upload(b))) return rc;
+    LqrHipCarver *c0 = b->cs[0];
+    dim3 grid((w + 255) / 256, h, (unsigned) b->cs.size());
+    DpK k = make_dpk(p, c0->ch);
+#define LAUNCH_EMAP(N) hipLaunchKernelGGL((k_emap_full<N>), grid, dim3(256), 0, b->stream, b->d_desc, k, w, h, c0->stride)
+    NRG_DISPATCH(p->nrg_func, LAUNCH_EMAP)
+#undef LAUNCH_EMAP
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+template <bool UPDATE>
+static int launch_dp(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
+{
+    LqrHipCarver *c0 = b->cs[0];
+    int pxt = (w + DP_THREADS - 1) / DP_THREADS;
+    size_t lds = (size_t) 2 * ((w + 3) & ~3) * sizeof(float);
+    dim3 grid((unsigned) b->cs.size()), block(DP_THREADS);
+#define LAUNCH_DP(P)                                                                                                  \
+    do {                                                                                                              \
+        if (lds > 64 * 1024)                                                                                          \
+            HIPCK(hipFuncSetAttribute((const void *) k_dp_sweep<P, UPDATE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int) lds));                                                                    \
+        hipLaunchKernelGGL((k_dp_sweep<P, UPDATE>), grid, block, lds, b->stream, b->d_desc, k, w, h, c0->stride, lr); \
+    } while (0)
+    if (pxt <= 1) LAUNCH_DP(1);
+    else if (pxt <= 2) LAUNCH_DP(2);
+    else if (pxt <= 4) LAUNCH_DP(4);
+    else if (pxt <= 8) LAUNCH_DP(8);
+    else if (pxt <= 16) LAUNCH_DP(16);
+    else { g_err = "image wider than 16384 px is not supported"; return LQRHIP_EARG; }
+#undef LAUNCH_DP
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lqrhip_mmap_build(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int leftright)
+{
+    int rc;
+    if ((rc = batch_upload(b))) return rc;
+    if (p->delta_x > LQRHIP_MAX_DELTA) return LQRHIP_EARG;
+    ProfScope ps("dp_sweep", b->stream, 9.0 * w * h * b->cs.size());
+    return launch_dp<false>(b, make_dpk(p, b->cs[0]->ch), w, h, leftright);
+}
+
+static int g_use_band = -1;
+
+extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
+                                int full_rebuild, int leftright_next)
+{
+    int rc;
+    LqrHipCarver *c0 = b->cs[0];
+    if (g_use_band < 0) {
+        const char *e = getenv("LQRHIP_NO_BAND");
+        g_use_band = (e && atoi(e)) ? 0 : 1;
+    }
+    for (auto *c : b->cs)
+        if (log_index >= c->log_cap) return LQRHIP_EARG;
+    if ((rc = batch_upload(b))) return rc;
+    const unsigned n = (unsigned) b->cs.size();
+    DpK k = make_dpk(p, c0->ch);
+    const int stride = c0->stride;
+    {
+        ProfScope ps("vpath", b->stream, 0);
+        hipLaunchKernelGGL(k_vpath, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, p->delta_x,
+                           log_index);
+    }
+    const int wnew = w - 1;
+    const int move_dp = (wnew > 1 && !full_rebuild) ? 1 : 0;
+    {
+        // algorithmic bytes of one carve launch: read + write of one 4-byte
+        // plane over the half of each row right of the seam = 8 B * w*h/2 per image
+        ProfScope ps("carve", b->stream, 4.0 * (double) w * h * n);
+        hipLaunchKernelGGL(k_carve, dim3((h + 3) / 4, n), dim3(256), 0, b->stream, b->d_desc, w, h, stride, p->delta_x, move_dp);
+    }
+    if (wnew > 1) {
+        {
+            ProfScope ps("emap_update", b->stream, 0);
+#define LAUNCH_EUPD(N) hipLaunchKernelGGL((k_emap_update<N>), dim3((h + 63) / 64, n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride)
+            NRG_DISPATCH(p->nrg_func, LAUNCH_EUPD)
+#undef LAUNCH_EUPD
+        }
+        if (full_rebuild) {
+            ProfScope ps("dp_sweep", b->stream, 9.0 * wnew * h * n);
+            if ((rc = launch_dp<false>(b, k, wnew, h, leftright_next))) return rc;
+        } else {
+            if (g_use_band) {
+                ProfScope ps("band_update", b->stream, 0);
+                hipLaunchKernelGGL(k_band_update, dim3(n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, leftright_next);
+            } else {
+                for (auto *c : b->cs) HIPCK(hipMemsetAsync(c->flags, 0, sizeof(int32_t), b->stream));
+            }
+            ProfScope ps("dp_update", b->stream, 0);
+            if ((rc = launch_dp<true>(b, k, wnew, h, leftright_next))) return rc;
+        }
+    }
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lqrhip_seam_log_reserve(LqrHipBatch *b, int n_seams, int h)
+{
+    int rc;
+    for (auto *c : b->cs) if ((rc = ensure_log(c, n_seams, h))) return rc;
+    return 0;
+}
+
+extern "C" int lqrhip_vs_commit(LqrHipBatch *b, int w0, int h0, int wc0, int n_seams, int first_level, int finish)
+{
+    int rc;
+    if ((rc = batch_upload(b))) return rc;
+    size_t lds = ((size_t) n_seams + wc0) * sizeof(int);
+    if (lds > 150 * 1024) { g_err = "vs_commit: session too large for LDS"; return LQRHIP_EARG; }
+    if (lds > 64 * 1024)
+        HIPCK(hipFuncSetAttribute((const void *) k_vs_commit, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    hipLaunchKernelGGL(k_vs_commit, dim3(h0, (unsigned) b->cs.size()), dim3(256), lds, b->stream, b->d_desc, w0, h0, wc0, n_seams,
+                       first_level, finish);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+// inflate one carver (root or aux) reading `vs_old`; new vs only for roots
+static int inflate_one(LqrHipCarver *c, const int32_t *vs_old, int32_t *nvs, int w0, int h0, int w1, int l, int max_level,
+                       hipStream_t s)
+{
+    uint8_t *nrgb = nullptr;
+    float *nbias = nullptr, *nrig = nullptr;
+    int rc;
+    size_t n1 = (size_t) w1 * h0;
+    if ((rc = dmalloc(&nrgb, n1 * c->ch))) return rc;
+    if (c->bias0 && (rc = dmalloc(&nbias, n1))) return rc;
+    if (c->rig0 && (rc = dmalloc(&nrig, n1))) return rc;
+    hipLaunchKernelGGL(k_inflate, dim3(h0), dim3(256), 0, s, c->rgb0, vs_old, c->bias0, c->rig0, nrgb, nvs, nbias, nrig, w0, w1,
+                       c->ch, l, max_level);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(s));
+    dfree(c->rgb0); c->rgb0 = nrgb;
+    if (nbias) { dfree(c->bias0); c->bias0 = nbias; }
+    if (nrig) { dfree(c->rig0); c->rig0 = nrig; }
+    c->w0 = w1;
+    return 0;
+}
+
+extern "C" int lqrhip_inflate(LqrHipBatch *b, int w0, int h0, int l, int max_level)
+{
+    int rc;
+    const int w1 = w0 + l - max_level + 1;
+    HIPCK(hipStreamSynchronize(b->stream));
+    for (auto *c : b->cs) {
+        int32_t *nvs = nullptr;
+        if ((rc = dmalloc(&nvs, (size_t) w1 * h0))) return rc;
+        for (auto *a : c->aux)
+            if ((rc = inflate_one(a, c->vs, nullptr, w0, h0, w1, l, max_level, b->stream))) return rc;
+        if ((rc = inflate_one(c, c->vs, nvs, w0, h0, w1, l, max_level, b->stream))) return rc;
+        dfree(c->vs);
+        c->vs = nvs;
+        for (auto *a : c->aux) a->vs = nvs;
+    }
+    b->dirty = true;
+    return 0;
+}
+
+static int flatten_one(LqrHipCarver *c, const int32_t *vs_old, int w0, int h0, int w, int level, hipStream_t s)
+{
+    uint8_t *nrgb = nullptr;
+    float *nbias = nullptr, *nrig = nullptr;
+    int rc;
+    size_t n1 = (size_t) w * h0;
+    if ((rc = dmalloc(&nrgb, n1 * c->ch))) return rc;
+    if (c->bias0 && (rc = dmalloc(&nbias, n1))) return rc;
+    if (c->rig0 && (rc = dmalloc(&nrig, n1))) return rc;
+    hipLaunchKernelGGL(k_compact, dim3(h0), dim3(256), 0, s, c->rgb0, vs_old, c->bias0, c->rig0, nrgb, nbias, nrig,
+                       (int32_t *) nullptr, w0, w, c->ch, level, 0);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(s));
+    dfree(c->rgb0); c->rgb0 = nrgb;
+    if (nbias) { dfree(c->bias0); c->bias0 = nbias; }
+    if (nrig) { dfree(c->rig0); c->rig0 = nrig; }
+    c->w0 = w;
+    return 0;
+}
+
+extern "C" int lqrhip_flatten(LqrHipBatch *b, int w0, int h0, int w, int level)
+{
+    int rc;
+    HIPCK(hipStreamSynchronize(b->stream));
+    for (auto *c : b->cs) {
+        for (auto *a : c->aux)
+            if ((rc = flatten_one(a, c->vs, w0, h0, w, level, b->stream))) return rc;
+        if ((rc = flatten_one(c, c->vs, w0, h0, w, level, b->stream))) return rc;
+        dfree(c->vs);
+        if ((rc = dmalloc(&c->vs, (size_t) w * h0))) return rc;
+        HIPCK(hipMemset(c->vs, 0, (size_t) w * h0 * sizeof(int32_t)));
+        for (auto *a : c->aux) a->vs = c->vs;
+    }
+    b->dirty = true;
+    return 0;
+}
+
+static int transpose_one(LqrHipCarver *c, int w, int h, hipStream_t s)
+{
+    uint8_t *nrgb = nullptr;
+    float *nbias = nullptr, *nrig = nullptr;
+    int rc;
+    size_t n = (size_t) w * h;
+    if ((rc = dmalloc(&nrgb, n * c->ch))) return rc;
+    if (c->bias0 && (rc = dmalloc(&nbias, n))) return rc;
+    if (c->rig0 && (rc = dmalloc(&nrig, n))) return rc;
+    hipLaunchKernelGGL(k_transpose, dim3((w + 31) / 32, (h + 31) / 32), dim3(32, 8), 0, s, c->rgb0, c->bias0, c->rig0, nrgb, nbias,
+                       nrig, w, h, c->ch);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(s));
+    dfree(c->rgb0); c->rgb0 = nrgb;
+    if (nbias) { dfree(c->bias0); c->bias0 = nbias; }
+    if (nrig) { dfree(c->rig0); c->rig0 = nrig; }
+    c->w0 = h; c->h0 = w;
+    return 0;
+}
+
+extern "C" int lqrhip_transpose(LqrHipBatch *b, int w, int h)
+{
+    int rc;
+    HIPCK(hipStreamSynchronize(b->stream));
+    for (auto *c : b->cs) {
+        for (auto *a : c->aux)
+            if ((rc = transpose_one(a, w, h, b->stream))) return rc;
+        if ((rc = transpose_one(c, w, h, b->stream))) return rc;
+        HIPCK(hipMemset(c->vs, 0, (size_t) w * h * sizeof(int32_t)));   // flat carver: all zero already
+    }
+    b->dirty = true;
+    return 0;
+}
+
+// ---- read-back ---------------------------------------------------------------
+extern "C" int lqrhip_read_visible(LqrHipCarver *c, int w0, int h0, int w, int level, unsigned char *out)
+{
+    int rc = batch_sync_of(c);
+    if (rc) return rc;
+    uint8_t *d = nullptr;
+    size_t n = (size_t) w * h0 * c->ch;
+    if ((rc = dmalloc(&d, n))) return rc;
+    hipLaunchKernelGGL(k_compact, dim3(h0), dim3(256), 0, g_stream0, c->rgb0, c->vs, (const float *) nullptr, (const float *) nullptr,
+                       d, (float *) nullptr, (float *) nullptr, (int32_t *) nullptr, w0, w, c->ch, level, 0);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(g_stream0));
+    HIPCK(hipMemcpy(out, d, n, hipMemcpyDeviceToHost));
+    dfree(d);
+    return 0;
+}
+
+extern "C" int lqrhip_read_vmap(LqrHipCarver *c, int w0, int h0, int w, int level, int depth, int *out)
+{
+    int rc = batch_sync_of(c);
+    if (rc) return rc;
+    int32_t *d = nullptr;
+    size_t n = (size_t) w * h0;
+    if ((rc = dmalloc(&d, n))) return rc;
+    hipLaunchKernelGGL(k_compact, dim3(h0), dim3(256), 0, g_stream0, (const uint8_t *) nullptr, c->vs, (const float *) nullptr,
+                       (const float *) nullptr, (uint8_t *) nullptr, (float *) nullptr, (float *) nullptr, d, w0, w, c->ch, level,
+                       depth);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(g_stream0));
+    HIPCK(hipMemcpy(out, d, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    dfree(d);
+    return 0;
+}
+
+extern "C" int lqrhip_read_working(LqrHipCarver *c, int w, int h, float *en, float *m, int *least_dx)
+{
+    int rc = batch_sync_of(c);
+    if (rc) return rc;
+    if (!c->pix) return LQRHIP_EARG;
+    size_t n = (size_t) c->stride * h;
+    std::vector<float> t(n);
+    std::vector<int8_t> tl(n);
+    if (en) {
+        HIPCK(hipMemcpy(t.data(), c->en, n * sizeof(float), hipMemcpyDeviceToHost));
+        for (int y = 0; y < h; y++) memcpy(en + (size_t) y * w, t.data() + (size_t) y * c->stride, (size_t) w * sizeof(float));
+    }
+    if (m) {
+        HIPCK(hipMemcpy(t.data(), c->m, n * sizeof(float), hipMemcpyDeviceToHost));
+        for (int y = 0; y < h; y++) memcpy(m + (size_t) y * w, t.data() + (size_t) y * c->stride, (size_t) w * sizeof(float));
+    }
+    if (least_dx) {
+        HIPCK(hipMemcpy(tl.data(), c->least, n, hipMemcpyDeviceToHost));
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) least_dx[(size_t) y * w + x] = y == 0 ? 0 : (int) tl[(size_t) y * c->stride + x];
+    }
+    return 0;
+}

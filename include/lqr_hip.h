@@ -1,0 +1,120 @@
+/*
+ * lqr_hip.h -- thin C-ABI shim between the C host side of the engine
+ * (gimp-lqr-plugin_amd/host/lqr_carver.c, which implements include/lqr.h) and
+ * the hand-written gfx950 kernels (gimp-lqr-plugin_amd/csrc/lqr_hip.hip).
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  Each entry point names
+ * the liblqr engine stage it replaces and the
+ * reference call site that reaches that stage.
+ *
+ * Everything is batch-native: a LqrHipBatch is n carvers of identical geometry
+ * and configuration that advance in lock-step, one grid.y (or grid.z) slice per
+ * image.  A single carver is a batch of one.  All work of a batch is enqueued
+ * on the batch's HIP stream; only lqrhip_batch_sync and the read-back calls
+ * block.  Every function returns 0 on success, LQRHIP_ENOMEM on device OOM and
+ * another negative value on any other HIP error; none of them aborts.
+ */
+#ifndef LQR_HIP_H
+#define LQR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LQRHIP_OK 0
+#define LQRHIP_ENOMEM (-2)
+#define LQRHIP_EHIP (-1)
+#define LQRHIP_EARG (-3)
+#define LQRHIP_MAX_DELTA 16
+
+typedef struct LqrHipCarver LqrHipCarver;   /* device-resident planes of one carver */
+typedef struct LqrHipBatch LqrHipBatch;     /* n carvers advancing in lock-step     */
+
+/* DP parameters that stay fixed while a visibility map is being built */
+typedef struct LqrHipDpParams {
+    int delta_x;                                  /* lqr_carver_init, render.c:224 */
+    int use_rigidity;                             /* rigidity != 0 */
+    float rigidity_map[2 * LQRHIP_MAX_DELTA + 1]; /* [dx + delta_x], host-computed (powf) */
+    int nrg_func;                                 /* LqrEnergyFuncBuiltinType, render.c:234 */
+    int nrg_radius;                               /* 1 for gradients, 0 for LQR_EF_NULL */
+    int w_start;                                  /* bias is divided by this (E4) */
+} LqrHipDpParams;
+
+/* -- device / lifetime ----------------------------------------------------- */
+/* Selects the HIP device (LOCAL_RANK, else 0) on first use.  Returns the
+ * device ordinal or a negative error when no gfx950 device is usable. */
+int lqrhip_init(void);
+const char *lqrhip_last_error(void);
+
+/* E1 lqr_carver_new (render.c:222,894): upload the interleaved u8 image as the
+ * base layout.  The host buffer is not retained. */
+LqrHipCarver *lqrhip_carver_create(const unsigned char *rgb, int w, int h, int channels);
+void lqrhip_carver_destroy(LqrHipCarver *c);
+/* attached carver (render.c:897): shares the root's visibility map */
+int lqrhip_carver_attach(LqrHipCarver *root, LqrHipCarver *aux);
+/* E1 lqr_carver_init (render.c:224): allocate the working planes
+ * (packed pixels, en, m, back-pointers, seam buffers) for a w x h frame. */
+int lqrhip_carver_activate(LqrHipCarver *c);
+
+/* E2 lqr_carver_bias_add_rgb_area / lqr_carver_rigmask_add_rgb_area
+ * (io_functions.c:94-95,125-126).  The carver must be flat.  `transposed`
+ * says whether the carver frame is the transpose of image orientation. */
+int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int channels, int width, int height,
+                    int x_off, int y_off, int transposed, int is_rigmask, int bias_factor);
+
+/* -- batch ------------------------------------------------------------------ */
+LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n);
+void lqrhip_batch_destroy(LqrHipBatch *b);
+int lqrhip_batch_sync(LqrHipBatch *b);
+void *lqrhip_batch_stream(LqrHipBatch *b);      /* hipStream_t, for event timing in bench.py */
+
+/* base layout -> working planes, identity map (carver must be flat):
+ * what liblqr's raw[y][x] = y*w+x initialisation means for compacted planes */
+int lqrhip_wk_init(LqrHipBatch *b);
+/* E3+E4 lqr_carver_build_emap: full energy map of the w x h carved frame */
+int lqrhip_emap_build(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h);
+/* E5 lqr_carver_build_mmap: full cumulative-min DP, tie rule by `leftright` */
+int lqrhip_mmap_build(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int leftright);
+/* One seam of lqr_carver_build_vsmap (reached from lqr_carver_resize,
+ * render.c:318,328,529), on a frame that is w wide on entry:
+ *   E7 build_vpath (argmin + backtrack) -> seam `log_index` of the session log,
+ *   E8 carve (all working planes shift left of the seam, w -> w-1),
+ *   E6 update_emap, then either E9 update_mmap (full_rebuild = 0) or E5
+ *   build_mmap with the given (already toggled) leftright (full_rebuild = 1).
+ * If w-1 == 1 only E7/E8 run (liblqr's finish_vsmap case). */
+int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index,
+                     int leftright_pick, int full_rebuild, int leftright_next);
+/* reserve the session seam log (n_seams x h ints per carver) before the first seam_step */
+int lqrhip_seam_log_reserve(LqrHipBatch *b, int n_seams, int h);
+/* E8 update_vsmap for a whole session at once: turn the session's seam log
+ * (n_seams seams, carved frame wc0 wide at session start) into visibility
+ * levels first_level, first_level+1, ... in the base layout; `finish` applies
+ * liblqr's finish_vsmap (last column gets level w0). */
+int lqrhip_vs_commit(LqrHipBatch *b, int w0, int h0, int wc0, int n_seams, int first_level, int finish);
+/* E14 lqr_carver_inflate(l) on roots and their attached carvers */
+int lqrhip_inflate(LqrHipBatch *b, int w0, int h0, int l, int max_level);
+/* E11 lqr_carver_flatten (render.c:325,636): keep pixels visible at `level` */
+int lqrhip_flatten(LqrHipBatch *b, int w0, int h0, int w, int level);
+/* E11 lqr_carver_transpose: base planes of a flat carver, w x h -> h x w */
+int lqrhip_transpose(LqrHipBatch *b, int w, int h);
+
+/* -- read-back (blocking) --------------------------------------------------- */
+/* E12 scan_line source: the pixels visible at `level`, packed w x h x channels
+ * in CARVER orientation (io_functions.c:155-164 then serves rows of it). */
+int lqrhip_read_visible(LqrHipCarver *c, int w0, int h0, int w, int level, unsigned char *out);
+/* E12 lqr_vmap_dump (render.c:725): vs of the pixels visible at `level`
+ * minus `depth` (0 stays 0), w x h in carver orientation */
+int lqrhip_read_vmap(LqrHipCarver *c, int w0, int h0, int w, int level, int depth, int *out);
+/* test hooks behind lqrx_carver_get_energy / lqrx_carver_debug_maps */
+int lqrhip_read_working(LqrHipCarver *c, int w, int h, float *en, float *m, int *least_dx);
+
+/* kernel-time accounting for bench.py: accumulated HIP-event time (ms) and
+ * launch count of the carve kernel (the roofline kernel) since the last reset */
+void lqrhip_prof_enable(int on);
+void lqrhip_prof_reset(void);
+int lqrhip_prof_get(const char *kernel, double *ms_total, long long *launches, double *bytes_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LQR_HIP_H */

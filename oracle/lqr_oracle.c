@@ -1,0 +1,1164 @@
+/*
+ * lqr_oracle.c -- CPU restatement of the liblqr-1 seam-carving engine.
+ *
+ * *** TEST INFRASTRUCTURE ONLY ***  This file is the parity oracle for the
+ * MI355X engine.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  The product (liblqr-hip.so) never links,
+ * loads or calls anything in oracle/.
+ *
+ * *** PARITY UNPINNED ***  The arithmetic restated here lives in the third
+ * party library liblqr-1 (pkg-config module lqr-1 >= 0.4.0, reference
+ * configure.ac:67-70; 0.4.1 is what windows_installer_files/lqr-pack4win/
+ * winpack.sh:8 bundles).  Its source is NOT in the reference tree, is not
+ * installed in the build container and cannot be fetched (no network); the
+ * reference has no tests, golden vectors or fixtures for this path
+ * (SURVEY.md section 4, 8(c)).  This file restates liblqr 0.4.x's published
+ * algorithm from its documented behaviour and is anchored on the reference's
+ * call sites only:
+ *   src/render.c:220-248 (construction/configuration order), :318,:328,:529
+ *   (resize), :325,:636 (flatten), :725 (vmap dump), :547-551 (getters);
+ *   src/io_functions.c:94-95,125-126 (mask areas), :155-164 (scan_line /
+ *   scan_by_row), :216-219 (vmap accessors), :312 (vmap list foreach).
+ * and on the prose semantics in help/en/index.wiki:48,83,85,130-133.
+ * "bit-exact vs liblqr" in this repository therefore means "bit-exact vs this
+ * restatement".  The exported ABI is identical to liblqr-1's, so a genuine
+ * liblqr-1.so.0 can be loaded by tests/lqr_ctypes.py as a second oracle
+ * wherever one exists.
+ *
+ * Where this restatement deliberately departs from SURVEY.md Appendix A (itself
+ * flagged "unverified recollection"), DESIGN.md section "Spec deltas" lists the
+ * delta and why:  (1) side-switch "frequency" = number of switches per
+ * rescale operation (interval schedule), not "every 2nd seam";  (2) every
+ * build of the visibility map ends with the inflate step that makes the
+ * multi-size image symmetric (shrink AND enlarge), which is what makes
+ * get_depth = w0 - w_start meaningful;  (3) transpose rescales the rigidity
+ * table instead of recomputing it.
+ *
+ * Data model (liblqr's): every per-pixel plane is indexed by a pixel id in
+ * the base layout (h0 rows of w0); `raw[y][x]` maps carved-frame coordinates
+ * to ids and is the only thing that moves when a seam is carved.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <stdio.h>
+
+#include "oracle_rename.h"
+#include "../include/lqr.h"
+
+#define MAXI(a, b) ((a) > (b) ? (a) : (b))
+#define MINI(a, b) ((a) < (b) ? (a) : (b))
+#define UPDATE_TOLERANCE (1e-5f)
+
+struct _LqrProgress {
+    gfloat update_step;
+    LqrProgressFuncInit init;
+    LqrProgressFuncUpdate update;
+    LqrProgressFuncEnd end;
+    gchar init_width_message[LQR_PROGRESS_MAX_MESSAGE_LENGTH];
+    gchar end_width_message[LQR_PROGRESS_MAX_MESSAGE_LENGTH];
+    gchar init_height_message[LQR_PROGRESS_MAX_MESSAGE_LENGTH];
+    gchar end_height_message[LQR_PROGRESS_MAX_MESSAGE_LENGTH];
+};
+
+struct _LqrVMap {
+    gint *buffer;
+    gint width, height, depth, orientation;
+};
+
+struct _LqrVMapList {
+    LqrVMap *current;
+    LqrVMapList *next;
+};
+
+struct _LqrCarverList {
+    LqrCarver *current;
+    LqrCarverList *next;
+};
+
+typedef struct {
+    int x, y;       /* coordinates among visible pixels */
+    int now;        /* pixel id in the base layout */
+    int eoc;        /* end of canvas */
+} Cursor;
+
+struct _LqrCarver {
+    int w_start, h_start;   /* reference size (carver frame) */
+    int w, h;               /* current size */
+    int w0, h0;             /* base-layout size */
+    int level, max_level;
+    int channels, alpha_channel, n_colour;
+    int transposed;
+    int active, nrg_active;
+    LqrCarver *root;
+    LqrCarverList *attached;
+
+    float rigidity;
+    float *rigidity_map_base;   /* 2*delta_x+1 entries */
+    float *rigidity_map;        /* = base + delta_x */
+    float *rigidity_mask;
+    int delta_x;
+
+    guchar *rgb;
+    int *vs;
+    float *en, *bias, *m;
+    int *least;
+    int *raw_store;
+    int **raw;
+    int *vpath, *vpath_x, *nrg_xmin, *nrg_xmax;
+
+    int nrg_builtin;    /* LqrEnergyFuncBuiltinType */
+    int nrg_radius;
+    int nrg_uptodate;
+
+    int leftright, lr_switch_frequency;
+    float enl_step;
+    int resize_order;
+    int dump_vmaps;
+    LqrVMapList *flushed_vs;
+
+    LqrProgress *progress;
+    int session_update_step, session_rescale_total, session_rescale_current;
+
+    Cursor c;
+    guchar *ro_buffer;
+
+    /* debug snapshot of the DP state taken just before inflate wipes it */
+    float *dbg_en, *dbg_m;
+    int *dbg_least, dbg_w, dbg_h;
+};
+
+static int g_debug_snapshot = 0;
+void lqrx_set_debug(gint on) { g_debug_snapshot = on; }
+
+/* ---- instrumentation (oracle only; used to size the engine's band kernel) -- */
+static long long g_stats[8];    /* 0:update rows 1:band px 2:max band 3:rows band>62 4:full builds 5:updates 6:rows band>254 */
+void olqr_oracle_get_stats(long long *out) { memcpy(out, g_stats, sizeof g_stats); }
+void olqr_oracle_reset_stats(void) { memset(g_stats, 0, sizeof g_stats); }
+
+/* ======================= progress ======================================== */
+LqrProgress *lqr_progress_new(void)
+{
+    LqrProgress *p = (LqrProgress *) calloc(1, sizeof *p);
+    if (!p) return NULL;
+    p->update_step = 0.02f;
+    strcpy(p->init_width_message, "Resizing width...");
+    strcpy(p->init_height_message, "Resizing height...");
+    strcpy(p->end_width_message, "done");
+    strcpy(p->end_height_message, "done");
+    return p;
+}
+LqrRetVal lqr_progress_set_init(LqrProgress *p, LqrProgressFuncInit f) { p->init = f; return LQR_OK; }
+LqrRetVal lqr_progress_set_update(LqrProgress *p, LqrProgressFuncUpdate f) { p->update = f; return LQR_OK; }
+LqrRetVal lqr_progress_set_end(LqrProgress *p, LqrProgressFuncEnd f) { p->end = f; return LQR_OK; }
+LqrRetVal lqr_progress_set_update_step(LqrProgress *p, gfloat s) { p->update_step = s; return LQR_OK; }
+static LqrRetVal set_msg(gchar *dst, const gchar *src)
+{
+    if (!src) return LQR_ERROR;
+    strncpy(dst, src, LQR_PROGRESS_MAX_MESSAGE_LENGTH - 1);
+    dst[LQR_PROGRESS_MAX_MESSAGE_LENGTH - 1] = 0;
+    return LQR_OK;
+}
+LqrRetVal lqr_progress_set_init_width_message(LqrProgress *p, const gchar *m) { return set_msg(p->init_width_message, m); }
+LqrRetVal lqr_progress_set_init_height_message(LqrProgress *p, const gchar *m) { return set_msg(p->init_height_message, m); }
+LqrRetVal lqr_progress_set_end_width_message(LqrProgress *p, const gchar *m) { return set_msg(p->end_width_message, m); }
+LqrRetVal lqr_progress_set_end_height_message(LqrProgress *p, const gchar *m) { return set_msg(p->end_height_message, m); }
+
+static void progress_init(LqrProgress *p, const gchar *msg) { if (p && p->init) p->init(msg); }
+static void progress_update(LqrProgress *p, double f) { if (p && p->update) p->update(f); }
+static void progress_end(LqrProgress *p, const gchar *msg) { if (p && p->end) p->end(msg); }
+
+/* ======================= cursor ========================================== */
+static int invisible(const LqrCarver *r, int id) { return r->vs[id] != 0 && r->vs[id] < r->level; }
+
+static void cursor_reset(LqrCarver *r)
+{
+    r->c.eoc = 0; r->c.x = 0; r->c.y = 0; r->c.now = 0;
+    while (invisible(r, r->c.now)) r->c.now++;
+}
+static void cursor_next(LqrCarver *r)
+{
+    if (r->c.eoc) return;
+    if (r->c.x == r->w - 1) {
+        if (r->c.y == r->h - 1) { r->c.eoc = 1; return; }
+        r->c.x = 0; r->c.y++;
+    } else {
+        r->c.x++;
+    }
+    r->c.now++;
+    while (invisible(r, r->c.now)) r->c.now++;
+}
+static void cursor_prev(LqrCarver *r)
+{
+    if (r->c.x == 0) {
+        if (r->c.y == 0) return;
+        r->c.x = r->w - 1; r->c.y--;
+    } else {
+        r->c.x--;
+    }
+    r->c.now--;
+    while (invisible(r, r->c.now)) r->c.now--;
+}
+
+/* ======================= lists =========================================== */
+static LqrCarverList *carver_list_append(LqrCarverList *list, LqrCarver *r)
+{
+    LqrCarverList *n = (LqrCarverList *) calloc(1, sizeof *n), *p = list;
+    if (!n) return NULL;
+    n->current = r;
+    if (!list) return n;
+    while (p->next) p = p->next;
+    p->next = n;
+    return list;
+}
+LqrCarverList *lqr_carver_list_start(LqrCarver *r) { return r->attached; }
+LqrCarver *lqr_carver_list_current(LqrCarverList *l) { return l->current; }
+LqrCarverList *lqr_carver_list_next(LqrCarverList *l) { return l->next; }
+
+LqrVMapList *lqr_vmap_list_start(LqrCarver *r) { return r->flushed_vs; }
+LqrVMap *lqr_vmap_list_current(LqrVMapList *l) { return l->current; }
+LqrVMapList *lqr_vmap_list_next(LqrVMapList *l) { return l->next; }
+LqrRetVal lqr_vmap_list_foreach(LqrVMapList *list, LqrVMapFunc func, gpointer data)
+{
+    for (; list; list = list->next) LQR_CATCH(func(list->current, data));
+    return LQR_OK;
+}
+gint *lqr_vmap_get_data(LqrVMap *v) { return v->buffer; }
+gint lqr_vmap_get_width(LqrVMap *v) { return v->width; }
+gint lqr_vmap_get_height(LqrVMap *v) { return v->height; }
+gint lqr_vmap_get_depth(LqrVMap *v) { return v->depth; }
+gint lqr_vmap_get_orientation(LqrVMap *v) { return v->orientation; }
+void lqr_vmap_destroy(LqrVMap *v) { if (v) { free(v->buffer); free(v); } }
+
+/* ======================= construction ==================================== */
+static void set_width(LqrCarver *r, int w1)
+{
+    r->w = w1;
+    r->level = r->w0 - w1 + 1;
+}
+
+LqrCarver *lqr_carver_new(guchar *buffer, gint width, gint height, gint channels)
+{
+    LqrCarver *r;
+    if (!buffer || width < 1 || height < 1 || channels < 1 || channels > 4) return NULL;
+    r = (LqrCarver *) calloc(1, sizeof *r);
+    if (!r) return NULL;
+    r->level = r->max_level = 1;
+    r->delta_x = 1;
+    r->w = r->w0 = r->w_start = width;
+    r->h = r->h0 = r->h_start = height;
+    r->channels = channels;
+    r->alpha_channel = (channels == 2 || channels == 4) ? channels - 1 : -1;
+    r->n_colour = channels - (r->alpha_channel >= 0 ? 1 : 0);
+    r->nrg_builtin = LQR_EF_GRAD_XABS;
+    r->nrg_radius = 1;
+    r->enl_step = 2.0f;
+    r->resize_order = LQR_RES_ORDER_HOR;
+    r->rgb = buffer;
+    r->vs = (int *) calloc((size_t) width * height, sizeof(int));
+    r->ro_buffer = (guchar *) calloc((size_t) width * channels, 1);
+    r->progress = lqr_progress_new();
+    if (!r->vs || !r->ro_buffer || !r->progress) { free(r->vs); free(r->ro_buffer); free(r->progress); free(r); return NULL; }
+    cursor_reset(r);
+    return r;
+}
+
+static LqrRetVal init_energy_related(LqrCarver *r)
+{
+    int x, y;
+    if (r->nrg_active) return LQR_OK;
+    r->en = (float *) calloc((size_t) r->w * r->h, sizeof(float));
+    r->raw_store = (int *) malloc((size_t) r->w_start * r->h_start * sizeof(int));
+    r->raw = (int **) malloc((size_t) r->h_start * sizeof(int *));
+    if (!r->en || !r->raw_store || !r->raw) return LQR_NOMEM;
+    for (y = 0; y < r->h; y++) {
+        r->raw[y] = r->raw_store + (size_t) y * r->w_start;
+        for (x = 0; x < r->w_start; x++) r->raw[y][x] = y * r->w_start + x;
+    }
+    r->nrg_active = 1;
+    return LQR_OK;
+}
+
+LqrRetVal lqr_carver_init(LqrCarver *r, gint delta_x, gfloat rigidity)
+{
+    int x;
+    if (r->active || delta_x < 0) return LQR_ERROR;
+    LQR_CATCH(init_energy_related(r));
+    r->m = (float *) malloc((size_t) r->w * r->h * sizeof(float));
+    r->least = (int *) malloc((size_t) r->w * r->h * sizeof(int));
+    r->vpath = (int *) malloc((size_t) r->h * sizeof(int));
+    r->vpath_x = (int *) malloc((size_t) r->h * sizeof(int));
+    r->nrg_xmin = (int *) malloc((size_t) r->h * sizeof(int));
+    r->nrg_xmax = (int *) malloc((size_t) r->h * sizeof(int));
+    r->rigidity_map_base = (float *) calloc((size_t) 2 * delta_x + 1, sizeof(float));
+    if (!r->m || !r->least || !r->vpath || !r->vpath_x || !r->nrg_xmin || !r->nrg_xmax || !r->rigidity_map_base)
+        return LQR_NOMEM;
+    r->delta_x = delta_x;
+    r->rigidity = rigidity;
+    r->rigidity_map = r->rigidity_map_base + delta_x;
+    /* rigidity bias ~ |dx|^1.5 summed along the seam, help/en/index.wiki:83 */
+    for (x = -delta_x; x <= delta_x; x++)
+        r->rigidity_map[x] = r->rigidity * powf(fabsf((float) x), 1.5f) / r->h;
+    r->active = 1;
+    return LQR_OK;
+}
+
+static void carver_free_one(LqrCarver *r)
+{
+    LqrVMapList *v, *vn;
+    free(r->rgb);
+    if (!r->root) free(r->vs);
+    free(r->en); free(r->bias); free(r->m); free(r->least);
+    free(r->raw_store); free(r->raw);
+    free(r->vpath); free(r->vpath_x); free(r->nrg_xmin); free(r->nrg_xmax);
+    free(r->rigidity_map_base); free(r->rigidity_mask);
+    free(r->ro_buffer); free(r->progress);
+    free(r->dbg_en); free(r->dbg_m); free(r->dbg_least);
+    for (v = r->flushed_vs; v; v = vn) { vn = v->next; lqr_vmap_destroy(v->current); free(v); }
+    free(r);
+}
+
+void lqr_carver_destroy(LqrCarver *r)
+{
+    LqrCarverList *l, *ln;
+    if (!r) return;
+    for (l = r->attached; l; l = ln) { ln = l->next; lqr_carver_destroy(l->current); free(l); }
+    carver_free_one(r);
+}
+
+LqrRetVal lqr_carver_attach(LqrCarver *r, LqrCarver *aux)
+{
+    LqrCarverList *nl;
+    if (r->w0 != aux->w0 || r->h0 != aux->h0) return LQR_ERROR;
+    nl = carver_list_append(r->attached, aux);
+    if (!nl) return LQR_NOMEM;
+    r->attached = nl;
+    free(aux->vs);
+    aux->vs = r->vs;
+    aux->root = r;
+    return LQR_OK;
+}
+
+/* ======================= configuration =================================== */
+LqrRetVal lqr_carver_set_energy_function_builtin(LqrCarver *r, LqrEnergyFuncBuiltinType ef)
+{
+    if ((int) ef < LQR_EF_GRAD_NORM || (int) ef > LQR_EF_NULL) return LQR_ERROR;
+    r->nrg_builtin = (int) ef;
+    r->nrg_radius = (ef == LQR_EF_NULL) ? 0 : 1;
+    r->nrg_uptodate = 0;
+    return LQR_OK;
+}
+void lqr_carver_set_resize_order(LqrCarver *r, LqrResizeOrder o) { r->resize_order = (int) o; }
+void lqr_carver_set_progress(LqrCarver *r, LqrProgress *p) { free(r->progress); r->progress = p; }
+void lqr_carver_set_side_switch_frequency(LqrCarver *r, guint f) { r->lr_switch_frequency = (int) f; }
+LqrRetVal lqr_carver_set_enl_step(LqrCarver *r, gfloat s)
+{
+    if (!(s > 1 && s <= 2)) return LQR_ERROR;
+    r->enl_step = s;
+    return LQR_OK;
+}
+gfloat lqr_carver_get_enl_step(LqrCarver *r) { return r->enl_step; }
+void lqr_carver_set_dump_vmaps(LqrCarver *r) { r->dump_vmaps = 1; }
+
+/* ======================= getters ========================================= */
+gint lqr_carver_get_width(LqrCarver *r) { return r->transposed ? r->h : r->w; }
+gint lqr_carver_get_height(LqrCarver *r) { return r->transposed ? r->w : r->h; }
+gint lqr_carver_get_channels(LqrCarver *r) { return r->channels; }
+gint lqr_carver_get_ref_width(LqrCarver *r) { return r->transposed ? r->h_start : r->w_start; }
+gint lqr_carver_get_ref_height(LqrCarver *r) { return r->transposed ? r->w_start : r->h_start; }
+gint lqr_carver_get_orientation(LqrCarver *r) { return r->transposed ? 1 : 0; }
+gint lqr_carver_get_depth(LqrCarver *r) { return r->w0 - r->w_start; }
+gint lqrx_carver_frame_width(LqrCarver *r) { return r->w; }
+gint lqrx_carver_frame_height(LqrCarver *r) { return r->h; }
+
+/* ======================= flatten / transpose ============================= */
+static LqrRetVal flatten_one(LqrCarver *r)
+{
+    int x, y, k, z0;
+    guchar *new_rgb;
+    float *new_bias = NULL, *new_rig = NULL;
+
+    free(r->en); free(r->m); free(r->least);
+    r->en = NULL; r->m = NULL; r->least = NULL;
+    r->nrg_uptodate = 0;
+
+    new_rgb = (guchar *) malloc((size_t) r->w * r->h * r->channels);
+    if (!new_rgb) return LQR_NOMEM;
+    if (r->active) {
+        if (r->bias && !(new_bias = (float *) malloc((size_t) r->w * r->h * sizeof(float)))) return LQR_NOMEM;
+        if (r->rigidity_mask && !(new_rig = (float *) malloc((size_t) r->w * r->h * sizeof(float)))) return LQR_NOMEM;
+        r->m = (float *) malloc((size_t) r->w * r->h * sizeof(float));
+        r->least = (int *) malloc((size_t) r->w * r->h * sizeof(int));
+        if (!r->m || !r->least) return LQR_NOMEM;
+    }
+    if (r->nrg_active) {
+        r->en = (float *) calloc((size_t) r->w * r->h, sizeof(float));
+        if (!r->en) return LQR_NOMEM;
+    }
+
+    cursor_reset(r);
+    for (y = 0; y < r->h; y++) {
+        for (x = 0; x < r->w; x++) {
+            z0 = y * r->w + x;
+            for (k = 0; k < r->channels; k++) new_rgb[z0 * r->channels + k] = r->rgb[r->c.now * r->channels + k];
+            if (new_bias) new_bias[z0] = r->bias[r->c.now];
+            if (new_rig) new_rig[z0] = r->rigidity_mask[r->c.now];
+            cursor_next(r);
+        }
+    }
+    if (r->raw) {      /* identity map again, re-allocated for the new width */
+        free(r->raw_store); free(r->raw);
+        r->raw_store = (int *) malloc((size_t) r->w * r->h * sizeof(int));
+        r->raw = (int **) malloc((size_t) r->h * sizeof(int *));
+        if (!r->raw_store || !r->raw) return LQR_NOMEM;
+        for (y = 0; y < r->h; y++) {
+            r->raw[y] = r->raw_store + (size_t) y * r->w;
+            for (x = 0; x < r->w; x++) r->raw[y][x] = y * r->w + x;
+        }
+    }
+
+    free(r->rgb); r->rgb = new_rgb;
+    if (new_bias) { free(r->bias); r->bias = new_bias; }
+    if (new_rig) { free(r->rigidity_mask); r->rigidity_mask = new_rig; }
+
+    if (!r->root) {
+        LqrCarverList *l;
+        free(r->vs);
+        r->vs = (int *) calloc((size_t) r->w * r->h, sizeof(int));
+        if (!r->vs) return LQR_NOMEM;
+        for (l = r->attached; l; l = l->next) l->current->vs = r->vs;
+    }
+
+    r->w0 = r->w; r->h0 = r->h;
+    r->w_start = r->w; r->h_start = r->h;
+    r->level = 1; r->max_level = 1;
+    return LQR_OK;
+}
+
+LqrRetVal lqr_carver_flatten(LqrCarver *r)
+{
+    LqrCarverList *l;
+    /* attached carvers first: they still need the root's old visibility map */
+    for (l = r->attached; l; l = l->next) LQR_CATCH(lqr_carver_flatten(l->current));
+    LQR_CATCH(flatten_one(r));
+    cursor_reset(r);
+    for (l = r->attached; l; l = l->next) cursor_reset(l->current);
+    return LQR_OK;
+}
+
+static LqrRetVal transpose_carver(LqrCarver *r)
+{
+    int x, y, k, z0, z1, d;
+    guchar *new_rgb;
+    float *new_bias = NULL, *new_rig = NULL;
+    LqrCarverList *l;
+
+    if (r->level > 1) LQR_CATCH(lqr_carver_flatten(r));
+    for (l = r->attached; l; l = l->next) LQR_CATCH(transpose_carver(l->current));
+
+    free(r->en); free(r->m); free(r->least); free(r->ro_buffer);
+    r->en = NULL; r->m = NULL; r->least = NULL; r->ro_buffer = NULL;
+
+    new_rgb = (guchar *) malloc((size_t) r->w0 * r->h0 * r->channels);
+    if (!new_rgb) return LQR_NOMEM;
+    if (r->active) {
+        if (r->bias && !(new_bias = (float *) malloc((size_t) r->w0 * r->h0 * sizeof(float)))) return LQR_NOMEM;
+        if (r->rigidity_mask && !(new_rig = (float *) malloc((size_t) r->w0 * r->h0 * sizeof(float)))) return LQR_NOMEM;
+    }
+    for (x = 0; x < r->w; x++) {
+        for (y = 0; y < r->h; y++) {
+            z0 = y * r->w0 + x;
+            z1 = x * r->h0 + y;
+            for (k = 0; k < r->channels; k++) new_rgb[z1 * r->channels + k] = r->rgb[z0 * r->channels + k];
+            if (new_bias) new_bias[z1] = r->bias[z0];
+            if (new_rig) new_rig[z1] = r->rigidity_mask[z0];
+        }
+    }
+    free(r->rgb); r->rgb = new_rgb;
+    if (new_bias) { free(r->bias); r->bias = new_bias; }
+    if (new_rig) { free(r->rigidity_mask); r->rigidity_mask = new_rig; }
+
+    if (!r->root) {
+        free(r->vs);
+        r->vs = (int *) calloc((size_t) r->w0 * r->h0, sizeof(int));
+        if (!r->vs) return LQR_NOMEM;
+        for (l = r->attached; l; l = l->next) l->current->vs = r->vs;
+    }
+
+    d = r->w0; r->w0 = r->h0; r->h0 = d;
+    r->w = r->w0; r->h = r->h0;
+    r->w_start = r->w0; r->h_start = r->h0;
+    r->level = 1; r->max_level = 1;
+
+    if (r->nrg_active) {
+        free(r->raw_store); free(r->raw); free(r->nrg_xmin); free(r->nrg_xmax);
+        r->en = (float *) calloc((size_t) r->w0 * r->h0, sizeof(float));
+        r->raw_store = (int *) malloc((size_t) r->w0 * r->h0 * sizeof(int));
+        r->raw = (int **) malloc((size_t) r->h0 * sizeof(int *));
+        r->nrg_xmin = (int *) malloc((size_t) r->h * sizeof(int));
+        r->nrg_xmax = (int *) malloc((size_t) r->h * sizeof(int));
+        if (!r->en || !r->raw_store || !r->raw || !r->nrg_xmin || !r->nrg_xmax) return LQR_NOMEM;
+        for (y = 0; y < r->h0; y++) {
+            r->raw[y] = r->raw_store + (size_t) y * r->w0;
+            for (x = 0; x < r->w0; x++) r->raw[y][x] = y * r->w0 + x;
+        }
+        r->nrg_uptodate = 0;
+    }
+    if (r->active) {
+        free(r->vpath); free(r->vpath_x);
+        r->m = (float *) malloc((size_t) r->w0 * r->h0 * sizeof(float));
+        r->least = (int *) malloc((size_t) r->w0 * r->h0 * sizeof(int));
+        r->vpath = (int *) malloc((size_t) r->h * sizeof(int));
+        r->vpath_x = (int *) malloc((size_t) r->h * sizeof(int));
+        if (!r->m || !r->least || !r->vpath || !r->vpath_x) return LQR_NOMEM;
+        /* the rigidity table is rescaled (not recomputed) for the new height */
+        for (x = -r->delta_x; x <= r->delta_x; x++)
+            r->rigidity_map[x] = r->rigidity_map[x] * r->w0 / r->h0;
+    }
+    r->ro_buffer = (guchar *) calloc((size_t) r->w0 * r->channels, 1);
+    if (!r->ro_buffer) return LQR_NOMEM;
+    r->transposed = r->transposed ? 0 : 1;
+    cursor_reset(r);
+    return LQR_OK;
+}
+
+/* ======================= masks (E2) ====================================== */
+static LqrRetVal mask_prepare(LqrCarver *r)
+{
+    if (!r->active) return LQR_ERROR;
+    if (r->w != r->w0 || r->w_start != r->w0 || r->h != r->h0 || r->h_start != r->h0)
+        LQR_CATCH(lqr_carver_flatten(r));
+    return LQR_OK;
+}
+
+/* mask value = mean(colour channels) x alpha (help/en/index.wiki:48) */
+static double mask_value(const guchar *px, int channels, int *sum_out)
+{
+    int has_alpha = (channels == 2 || channels >= 4);
+    int cc = channels - (has_alpha ? 1 : 0), k, sum = 0;
+    double v;
+    for (k = 0; k < cc; k++) sum += px[k];
+    *sum_out = sum;
+    v = (double) sum / (255 * cc);
+    if (has_alpha) v *= (double) px[channels - 1] / 255;
+    return v;
+}
+
+LqrRetVal lqr_carver_bias_add_rgb_area(LqrCarver *r, guchar *rgb, gint bias_factor, gint channels,
+                                       gint width, gint height, gint x_off, gint y_off)
+{
+    int x, y, x0, y0, x1, y1, x2, y2, wt, ht, sum, xc, yc;
+    int has_alpha = (channels == 2 || channels >= 4);
+    int cc = channels - (has_alpha ? 1 : 0);
+    LQR_CATCH(mask_prepare(r));
+    if (bias_factor == 0) return LQR_OK;
+    if (!r->bias) {
+        r->bias = (float *) calloc((size_t) r->w0 * r->h0, sizeof(float));
+        if (!r->bias) return LQR_NOMEM;
+    }
+    wt = r->transposed ? r->h : r->w;
+    ht = r->transposed ? r->w : r->h;
+    x0 = MINI(0, x_off); y0 = MINI(0, y_off);
+    x1 = MAXI(0, x_off); y1 = MAXI(0, y_off);
+    x2 = MINI(wt, width + x_off); y2 = MINI(ht, height + y_off);
+    for (y = 0; y < y2 - y1; y++) {
+        for (x = 0; x < x2 - x1; x++) {
+            const guchar *px = rgb + ((size_t) (y - y0) * width + (x - x0)) * channels;
+            double bias;
+            (void) mask_value(px, channels, &sum);
+            bias = (double) bias_factor * sum / (2 * 255 * cc);
+            if (has_alpha) bias *= (double) px[channels - 1] / 255;
+            xc = r->transposed ? y + y1 : x + x1;
+            yc = r->transposed ? x + x1 : y + y1;
+            r->bias[(size_t) yc * r->w0 + xc] += (float) bias;
+        }
+    }
+    r->nrg_uptodate = 0;
+    return LQR_OK;
+}
+
+LqrRetVal lqr_carver_rigmask_add_rgb_area(LqrCarver *r, guchar *rgb, gint channels,
+                                          gint width, gint height, gint x_off, gint y_off)
+{
+    int x, y, x0, y0, x1, y1, x2, y2, wt, ht, sum, xc, yc;
+    LQR_CATCH(mask_prepare(r));
+    if (!r->rigidity_mask) {
+        r->rigidity_mask = (float *) calloc((size_t) r->w0 * r->h0, sizeof(float));
+        if (!r->rigidity_mask) return LQR_NOMEM;
+    }
+    wt = r->transposed ? r->h : r->w;
+    ht = r->transposed ? r->w : r->h;
+    x0 = MINI(0, x_off); y0 = MINI(0, y_off);
+    x1 = MAXI(0, x_off); y1 = MAXI(0, y_off);
+    x2 = MINI(wt, width + x_off); y2 = MINI(ht, height + y_off);
+    for (y = 0; y < y2 - y1; y++) {
+        for (x = 0; x < x2 - x1; x++) {
+            const guchar *px = rgb + ((size_t) (y - y0) * width + (x - x0)) * channels;
+            double v = mask_value(px, channels, &sum);
+            xc = r->transposed ? y + y1 : x + x1;
+            yc = r->transposed ? x + x1 : y + y1;
+            r->rigidity_mask[(size_t) yc * r->w0 + xc] = (float) v;
+        }
+    }
+    return LQR_OK;
+}
+
+/* ======================= energy (E3, E4, E6) ============================= */
+/* brightness in double: mean of colour channels / 255 (or Rec.709 luma),
+ * times alpha/255 */
+static double read_bright(const LqrCarver *r, int x, int y, int luma)
+{
+    const guchar *px = r->rgb + (size_t) r->raw[y][x] * r->channels;
+    double b;
+    if (r->n_colour == 1) {
+        b = (double) px[0] / 255;
+    } else {
+        double red = (double) px[0] / 255, green = (double) px[1] / 255, blue = (double) px[2] / 255;
+        b = luma ? 0.2126 * red + 0.7152 * green + 0.0722 * blue : (red + green + blue) / 3;
+    }
+    if (r->alpha_channel >= 0) b *= (double) px[r->alpha_channel] / 255;
+    return b;
+}
+
+/* gradient from the four nearest neighbours (help/en/index.wiki:85),
+ * one-sided at the borders of the CURRENT frame */
+static float grad_energy(const LqrCarver *r, int x, int y)
+{
+    int ef = r->nrg_builtin, luma = (ef >= LQR_EF_LUMA_GRAD_NORM && ef <= LQR_EF_LUMA_GRAD_XABS);
+    double gx, gy;
+    if (ef == LQR_EF_NULL) return 0;
+    if (r->h == 1) gy = 0;
+    else if (y == 0) gy = read_bright(r, x, 1, luma) - read_bright(r, x, 0, luma);
+    else if (y < r->h - 1) gy = (read_bright(r, x, y + 1, luma) - read_bright(r, x, y - 1, luma)) / 2;
+    else gy = read_bright(r, x, y, luma) - read_bright(r, x, y - 1, luma);
+    if (r->w == 1) gx = 0;
+    else if (x == 0) gx = read_bright(r, 1, y, luma) - read_bright(r, 0, y, luma);
+    else if (x < r->w - 1) gx = (read_bright(r, x + 1, y, luma) - read_bright(r, x - 1, y, luma)) / 2;
+    else gx = read_bright(r, x, y, luma) - read_bright(r, x - 1, y, luma);
+    switch (ef) {
+        case LQR_EF_GRAD_NORM: case LQR_EF_LUMA_GRAD_NORM: return (float) sqrt(gx * gx + gy * gy);
+        case LQR_EF_GRAD_SUMABS: case LQR_EF_LUMA_GRAD_SUMABS: return (float) ((fabs(gx) + fabs(gy)) / 2);
+        default: return (float) fabs(gx);
+    }
+}
+
+static void compute_e(LqrCarver *r, int x, int y)
+{
+    int data = r->raw[y][x];
+    float b_add = 0;
+    if (r->bias) b_add = r->bias[data] / r->w_start;
+    r->en[data] = grad_energy(r, x, y) + b_add;
+}
+
+static LqrRetVal build_emap(LqrCarver *r)
+{
+    int x, y;
+    if (r->nrg_uptodate) return LQR_OK;
+    for (y = 0; y < r->h; y++)
+        for (x = 0; x < r->w; x++) compute_e(r, x, y);
+    r->nrg_uptodate = 1;
+    return LQR_OK;
+}
+
+static LqrRetVal update_emap(LqrCarver *r)
+{
+    int x, y, y1, y1_min, y1_max;
+    if (r->nrg_uptodate) return LQR_OK;
+    for (y = 0; y < r->h; y++) {
+        x = r->vpath_x[y];              /* the seam has already been carved */
+        r->nrg_xmin[y] = x;
+        r->nrg_xmax[y] = x - 1;
+    }
+    for (y = 0; y < r->h; y++) {
+        x = r->vpath_x[y];
+        y1_min = MAXI(y - r->nrg_radius, 0);
+        y1_max = MINI(y + r->nrg_radius, r->h - 1);
+        for (y1 = y1_min; y1 <= y1_max; y1++) {
+            r->nrg_xmin[y1] = MINI(r->nrg_xmin[y1], x - r->nrg_radius);
+            r->nrg_xmin[y1] = MAXI(0, r->nrg_xmin[y1]);
+            r->nrg_xmax[y1] = MAXI(r->nrg_xmax[y1], x + r->nrg_radius - 1);
+            r->nrg_xmax[y1] = MINI(r->w - 1, r->nrg_xmax[y1]);
+        }
+    }
+    for (y = 0; y < r->h; y++)
+        for (x = r->nrg_xmin[y]; x <= r->nrg_xmax[y]; x++) compute_e(r, x, y);
+    r->nrg_uptodate = 1;
+    return LQR_OK;
+}
+
+/* ======================= cumulative-min DP (E5, E9) ====================== */
+/* best predecessor of carved-frame pixel (x,y): scan dx ascending, first is the
+ * incumbent, replace on strict < (or on == when leftright == 1) */
+static float best_parent(const LqrCarver *r, int x, int y, int data, int *least_out)
+{
+    int x1_min = MAXI(-x, -r->delta_x), x1_max = MINI(r->w - 1 - x, r->delta_x), x1;
+    int data_down = r->raw[y - 1][x + x1_min], least = data_down;
+    float m, m1;
+    if (r->rigidity) {
+        float r_fact = r->rigidity_mask ? r->rigidity_mask[data] : 1;
+        m = r->m[data_down] + r_fact * r->rigidity_map[x1_min];
+        for (x1 = x1_min + 1; x1 <= x1_max; x1++) {
+            data_down = r->raw[y - 1][x + x1];
+            m1 = r->m[data_down] + r_fact * r->rigidity_map[x1];
+            if (m1 < m || (m1 == m && r->leftright == 1)) { m = m1; least = data_down; }
+        }
+    } else {
+        m = r->m[data_down];
+        for (x1 = x1_min + 1; x1 <= x1_max; x1++) {
+            data_down = r->raw[y - 1][x + x1];
+            m1 = r->m[data_down];
+            if (m1 < m || (m1 == m && r->leftright == 1)) { m = m1; least = data_down; }
+        }
+    }
+    *least_out = least;
+    return m;
+}
+
+static LqrRetVal build_mmap(LqrCarver *r)
+{
+    int x, y, data, least;
+    g_stats[4]++;
+    for (x = 0; x < r->w; x++) { data = r->raw[0][x]; r->m[data] = r->en[data]; }
+    for (y = 1; y < r->h; y++) {
+        for (x = 0; x < r->w; x++) {
+            float m;
+            data = r->raw[y][x];
+            m = best_parent(r, x, y, data, &least);
+            r->least[data] = least;
+            r->m[data] = r->en[data] + m;
+        }
+    }
+    return LQR_OK;
+}
+
+static LqrRetVal update_mmap(LqrCarver *r)
+{
+    int x, y, x_min, x_max, data, least, stop, x_stop;
+    g_stats[5]++;
+    x_min = MAXI(r->nrg_xmin[0], 0);
+    x_max = MINI(r->nrg_xmax[0], r->w - 1);
+    for (x = x_min; x <= x_max; x++) { data = r->raw[0][x]; r->m[data] = r->en[data]; }
+    for (y = 1; y < r->h; y++) {
+        /* include the changed-energy interval, then widen by delta_x */
+        x_min = MINI(x_min, r->nrg_xmin[y]);
+        x_max = MAXI(x_max, r->nrg_xmax[y]);
+        x_min = MAXI(x_min - r->delta_x, 0);
+        x_max = MINI(x_max + r->delta_x, r->w - 1);
+        {
+            long long bw = (long long) x_max - x_min + 1;
+            if (bw < 0) bw = 0;
+            g_stats[0]++; g_stats[1] += bw;
+            if (bw > g_stats[2]) g_stats[2] = bw;
+            if (bw > 62) g_stats[3]++;
+            if (bw > 254) g_stats[6]++;
+        }
+        stop = 0; x_stop = 0;
+        for (x = x_min; x <= x_max; x++) {
+            float m, new_m;
+            data = r->raw[y][x];
+            m = best_parent(r, x, y, data, &least);
+            new_m = r->en[data] + m;
+            /* shrink the band where nothing (relevant) changed: the stale
+             * value is KEPT when the change is below tolerance */
+            if (r->least[data] == least) {
+                if (fabsf(r->m[data] - new_m) < UPDATE_TOLERANCE) {
+                    if (stop == 0) x_stop = x;
+                    stop = 1;
+                    new_m = r->m[data];
+                } else {
+                    stop = 0;
+                    r->m[data] = new_m;
+                }
+                if (x == x_min && stop) x_min++;
+            } else {
+                stop = 0;
+                r->m[data] = new_m;
+            }
+            r->least[data] = least;
+            if (x == x_max && stop) x_max = x_stop;
+        }
+    }
+    return LQR_OK;
+}
+
+/* ======================= seam (E7, E8) =================================== */
+static void build_vpath(LqrCarver *r)
+{
+    int x, y, last = -1, last_x = 0, x_min, x_max;
+    float m = (float) (1 << 29), m1;
+    y = r->h - 1;
+    for (x = 0; x < r->w; x++) {
+        m1 = r->m[r->raw[y][x]];
+        if (m1 < m || (m1 == m && r->leftright == 1)) { last = r->raw[y][x]; last_x = x; m = m1; }
+    }
+    if (last < 0) { last = r->raw[y][0]; last_x = 0; }   /* liblqr: undefined; pinned to x=0 here */
+    for (y = r->h0 - 1; y >= 0; y--) {
+        r->vpath[y] = last;
+        r->vpath_x[y] = last_x;
+        if (y > 0) {
+            last = r->least[r->raw[y][last_x]];
+            x_min = MAXI(last_x - r->delta_x, 0);
+            x_max = MINI(last_x + r->delta_x, r->w - 1);
+            for (x = x_min; x <= x_max; x++)
+                if (r->raw[y - 1][x] == last) { last_x = x; break; }
+        }
+    }
+}
+
+static void update_vsmap(LqrCarver *r, int l)
+{
+    int y;
+    for (y = 0; y < r->h; y++) r->vs[r->vpath[y]] = l;
+}
+
+static void carve(LqrCarver *r)
+{
+    int x, y;
+    for (y = 0; y < r->h_start; y++)
+        for (x = r->vpath_x[y]; x < r->w; x++) r->raw[y][x] = r->raw[y][x + 1];
+    r->nrg_uptodate = 0;
+}
+
+static void finish_vsmap(LqrCarver *r)
+{
+    int y;
+    cursor_reset(r);
+    for (y = 1; y <= r->h; y++, cursor_next(r)) r->vs[r->c.now] = r->w0;
+    cursor_reset(r);
+}
+
+/* ======================= inflate (E14) =================================== */
+/* Rebuild the base layout so that every seam computed since the last inflate
+ * is present twice (original + interpolated copy): the multi-size image then
+ * covers w_start -/+ (depth-1). */
+static LqrRetVal inflate_carver(LqrCarver *r, int l)
+{
+    int w1, z0, vs, k, x, y, c_left, n;
+    guchar *new_rgb;
+    int *new_vs = NULL;
+    float *new_bias = NULL, *new_rig = NULL;
+    LqrCarverList *al;
+
+    for (al = r->attached; al; al = al->next) LQR_CATCH(inflate_carver(al->current, l));
+
+    set_width(r, r->w0);
+    w1 = r->w0 + l - r->max_level + 1;
+
+    new_rgb = (guchar *) calloc((size_t) w1 * r->h0 * r->channels, 1);
+    if (!new_rgb) return LQR_NOMEM;
+    if (!r->root && !(new_vs = (int *) calloc((size_t) w1 * r->h0, sizeof(int)))) return LQR_NOMEM;
+    if (r->active) {
+        if (r->bias && !(new_bias = (float *) calloc((size_t) w1 * r->h0, sizeof(float)))) return LQR_NOMEM;
+        if (r->rigidity_mask && !(new_rig = (float *) malloc((size_t) w1 * r->h0 * sizeof(float)))) return LQR_NOMEM;
+    }
+
+    cursor_reset(r);
+    x = 0; y = 0;
+    n = r->w0 * r->h0;
+    for (z0 = 0; z0 < w1 * r->h0 && n > 0; z0++, n--, cursor_next(r)) {
+        vs = r->vs[r->c.now];
+        if (vs != 0 && vs <= l + r->max_level - 1 && vs >= 2 * r->max_level - 1) {
+            /* a seam computed in this session: insert its interpolated twin
+             * (mean of the pixel and its left neighbour, integer floor) */
+            c_left = (r->c.x > 0) ? r->c.now - 1 : r->c.now;
+            for (k = 0; k < r->channels; k++)
+                new_rgb[z0 * r->channels + k] =
+                    (guchar) ((r->rgb[c_left * r->channels + k] + r->rgb[r->c.now * r->channels + k]) / 2);
+            if (new_bias) new_bias[z0] = (r->bias[c_left] + r->bias[r->c.now]) / 2;
+            if (new_rig) new_rig[z0] = (r->rigidity_mask[c_left] + r->rigidity_mask[r->c.now]) / 2;
+            if (new_vs) new_vs[z0] = l - vs + r->max_level;
+            z0++;
+        }
+        for (k = 0; k < r->channels; k++) new_rgb[z0 * r->channels + k] = r->rgb[r->c.now * r->channels + k];
+        if (new_bias) new_bias[z0] = r->bias[r->c.now];
+        if (new_rig) new_rig[z0] = r->rigidity_mask[r->c.now];
+        if (vs != 0) {
+            if (new_vs) new_vs[z0] = vs + l - r->max_level + 1;
+        } else if (r->raw) {
+            r->raw[y][x] = z0;
+            x++;
+            if (x >= r->w_start - l) { x = 0; y++; }
+        }
+    }
+
+    free(r->rgb); r->rgb = new_rgb;
+    free(r->en); free(r->m); free(r->least);
+    r->en = NULL; r->m = NULL; r->least = NULL;
+    r->nrg_uptodate = 0;
+    if (new_bias) { free(r->bias); r->bias = new_bias; }
+    if (new_rig) { free(r->rigidity_mask); r->rigidity_mask = new_rig; }
+    if (!r->root) {
+        free(r->vs);
+        r->vs = new_vs;
+        for (al = r->attached; al; al = al->next) al->current->vs = r->vs;
+    }
+    if (r->nrg_active) {
+        r->en = (float *) calloc((size_t) w1 * r->h0, sizeof(float));
+        if (!r->en) return LQR_NOMEM;
+    }
+    if (r->active) {
+        r->m = (float *) calloc((size_t) w1 * r->h0, sizeof(float));
+        r->least = (int *) malloc((size_t) w1 * r->h0 * sizeof(int));
+        if (!r->m || !r->least) return LQR_NOMEM;
+    }
+    r->level = l + 1;
+    r->max_level = l + 1;
+    r->w0 = w1;
+    r->w = r->w_start;
+    free(r->ro_buffer);
+    r->ro_buffer = (guchar *) calloc((size_t) r->w0 * r->channels, 1);
+    if (!r->ro_buffer) return LQR_NOMEM;
+    cursor_reset(r);
+    return LQR_OK;
+}
+
+/* ======================= per-seam loop (E10) ============================= */
+LqrRetVal lqrx_carver_debug_maps(LqrCarver *r, gfloat *en, gfloat *m, gint *least_dx);
+static void set_width_all(LqrCarver *r, int w1)
+{
+    LqrCarverList *l;
+    set_width(r, w1);
+    for (l = r->attached; l; l = l->next) set_width_all(l->current, w1);
+}
+
+static LqrRetVal build_vsmap(LqrCarver *r, int depth)
+{
+    int l, lr_switch_interval = 0;
+    LqrCarverList *al;
+    if (depth == 0) depth = r->w_start + 1;
+    /* "frequency" = number of side switches per rescale operation */
+    if (r->lr_switch_frequency)
+        lr_switch_interval = (depth - r->max_level - 1) / r->lr_switch_frequency + 1;
+
+    for (l = r->max_level; l < depth; l++) {
+        if ((l - r->max_level + r->session_rescale_current) % r->session_update_step == 0)
+            progress_update(r->progress, (double) (l - r->max_level + r->session_rescale_current) /
+                                         (double) r->session_rescale_total);
+        build_vpath(r);
+        update_vsmap(r, l + r->max_level - 1);
+        r->level++;
+        r->w--;
+        carve(r);
+        if (r->w > 1) {
+            LQR_CATCH(update_emap(r));
+            if (r->lr_switch_frequency && ((l - r->max_level + lr_switch_interval / 2) % lr_switch_interval) == 0) {
+                r->leftright ^= 1;
+                LQR_CATCH(build_mmap(r));
+            } else {
+                LQR_CATCH(update_mmap(r));
+            }
+        } else {
+            finish_vsmap(r);
+        }
+    }
+    if (g_debug_snapshot && r->w >= 1) {
+        free(r->dbg_en); free(r->dbg_m); free(r->dbg_least);
+        r->dbg_w = r->w; r->dbg_h = r->h;
+        r->dbg_en = (float *) malloc((size_t) r->w * r->h * sizeof(float));
+        r->dbg_m = (float *) malloc((size_t) r->w * r->h * sizeof(float));
+        r->dbg_least = (int *) malloc((size_t) r->w * r->h * sizeof(int));
+        if (!r->dbg_en || !r->dbg_m || !r->dbg_least) return LQR_NOMEM;
+        LQR_CATCH(lqrx_carver_debug_maps(r, r->dbg_en, r->dbg_m, r->dbg_least));
+    }
+    LQR_CATCH(inflate_carver(r, depth - 1));
+    set_width(r, r->w_start);
+    for (al = r->attached; al; al = al->next) set_width_all(al->current, r->w_start);
+    return LQR_OK;
+}
+
+static LqrRetVal build_maps(LqrCarver *r, int depth)
+{
+    if (depth > r->max_level) {
+        if (!r->active || r->root) return LQR_ERROR;
+        set_width(r, r->w_start - r->max_level + 1);    /* the carved frame */
+        LQR_CATCH(build_emap(r));
+        LQR_CATCH(build_mmap(r));
+        LQR_CATCH(build_vsmap(r, depth));
+    }
+    return LQR_OK;
+}
+
+/* ======================= vmaps =========================================== */
+LqrVMap *lqr_vmap_dump(LqrCarver *r)
+{
+    LqrVMap *v;
+    int w1 = r->w, w, h, x, y, z0, vs, depth;
+    int *buffer;
+    set_width(r, r->w_start);
+    w = lqr_carver_get_width(r);
+    h = lqr_carver_get_height(r);
+    depth = r->w0 - r->w_start;
+    buffer = (int *) malloc((size_t) w * h * sizeof(int));
+    v = (LqrVMap *) calloc(1, sizeof *v);
+    if (!buffer || !v) { free(buffer); free(v); return NULL; }
+    cursor_reset(r);
+    for (y = 0; y < r->h; y++) {
+        for (x = 0; x < r->w; x++) {
+            vs = r->vs[r->c.now];
+            z0 = r->transposed ? x * r->h + y : y * r->w + x;
+            buffer[z0] = vs == 0 ? 0 : vs - depth;
+            cursor_next(r);
+        }
+    }
+    set_width(r, w1);
+    cursor_reset(r);
+    v->buffer = buffer; v->width = w; v->height = h; v->depth = depth; v->orientation = r->transposed;
+    return v;
+}
+
+static LqrRetVal vmap_internal_dump(LqrCarver *r)
+{
+    LqrVMap *v = lqr_vmap_dump(r);
+    LqrVMapList *n = (LqrVMapList *) calloc(1, sizeof *n), *p;
+    if (!v || !n) return LQR_NOMEM;
+    n->current = v;
+    if (!r->flushed_vs) r->flushed_vs = n;
+    else { for (p = r->flushed_vs; p->next; p = p->next); p->next = n; }
+    return LQR_OK;
+}
+
+/* ======================= resize (E10) ==================================== */
+static void scan_reset_all(LqrCarver *r)
+{
+    LqrCarverList *l;
+    cursor_reset(r);
+    for (l = r->attached; l; l = l->next) scan_reset_all(l->current);
+}
+
+static LqrRetVal resize_dir(LqrCarver *r, int w1, int want_transposed)
+{
+    int delta, gamma, delta_max;
+    const gchar *init_msg = want_transposed ? r->progress->init_height_message : r->progress->init_width_message;
+    const gchar *end_msg = want_transposed ? r->progress->end_height_message : r->progress->end_width_message;
+
+    if (r->transposed == want_transposed) {
+        delta = w1 - r->w_start; gamma = w1 - r->w;
+        delta_max = (int) ((r->enl_step - 1) * r->w_start) - 1;
+    } else {
+        delta = w1 - r->h_start; gamma = w1 - r->h;
+        delta_max = (int) ((r->enl_step - 1) * r->h_start) - 1;
+    }
+    if (delta_max < 1) delta_max = 1;
+    if (delta < 0) { delta = -delta; delta_max = delta; }
+
+    r->session_rescale_total = gamma > 0 ? gamma : -gamma;
+    r->session_rescale_current = 0;
+    r->session_update_step = (int) MAXI(r->session_rescale_total * r->progress->update_step, 1);
+    if (r->session_rescale_total) progress_init(r->progress, init_msg);
+
+    while (gamma) {
+        int delta0 = MINI(delta, delta_max), new_w;
+        delta -= delta0;
+        if (r->transposed != want_transposed) LQR_CATCH(transpose_carver(r));
+        new_w = MINI(w1, r->w_start + delta_max);
+        gamma = w1 - new_w;
+        LQR_CATCH(build_maps(r, delta0 + 1));
+        set_width_all(r, new_w);
+        r->session_rescale_current = r->session_rescale_total - (gamma > 0 ? gamma : -gamma);
+        if (r->dump_vmaps) LQR_CATCH(vmap_internal_dump(r));
+        if (new_w < w1) {
+            LQR_CATCH(lqr_carver_flatten(r));
+            delta_max = (int) ((r->enl_step - 1) * r->w_start) - 1;
+            if (delta_max < 1) delta_max = 1;
+        }
+    }
+    if (r->session_rescale_total) progress_end(r->progress, end_msg);
+    return LQR_OK;
+}
+
+LqrRetVal lqr_carver_resize(LqrCarver *r, gint w1, gint h1)
+{
+    if (w1 < 1 || h1 < 1 || r->root) return LQR_ERROR;
+    if (r->resize_order == LQR_RES_ORDER_HOR) {
+        LQR_CATCH(resize_dir(r, w1, 0));
+        LQR_CATCH(resize_dir(r, h1, 1));
+    } else {
+        LQR_CATCH(resize_dir(r, h1, 1));
+        LQR_CATCH(resize_dir(r, w1, 0));
+    }
+    scan_reset_all(r);
+    return LQR_OK;
+}
+
+LqrRetVal lqrx_carver_resize_batch(LqrCarver **carvers, gint n, gint w1, gint h1)
+{
+    int i;
+    for (i = 0; i < n; i++) LQR_CATCH(lqr_carver_resize(carvers[i], w1, h1));
+    return LQR_OK;
+}
+
+/* ======================= readout (E12) =================================== */
+void lqr_carver_scan_reset(LqrCarver *r) { cursor_reset(r); }
+gboolean lqr_carver_scan_by_row(LqrCarver *r) { return r->transposed ? FALSE : TRUE; }
+
+gboolean lqr_carver_scan_line(LqrCarver *r, gint *n, guchar **rgb)
+{
+    int x, k;
+    if (r->c.eoc) { cursor_reset(r); return FALSE; }
+    *n = r->c.y;
+    while (r->c.x > 0) cursor_prev(r);
+    for (x = 0; x < r->w; x++) {
+        for (k = 0; k < r->channels; k++) r->ro_buffer[x * r->channels + k] = r->rgb[r->c.now * r->channels + k];
+        cursor_next(r);
+    }
+    *rgb = r->ro_buffer;
+    return TRUE;
+}
+
+LqrRetVal lqrx_carver_read_image(LqrCarver *r, guchar *out)
+{
+    int n, W = lqr_carver_get_width(r), H = lqr_carver_get_height(r), ch = r->channels, i;
+    guchar *line;
+    cursor_reset(r);
+    while (lqr_carver_scan_line(r, &n, &line)) {
+        if (lqr_carver_scan_by_row(r)) memcpy(out + (size_t) n * W * ch, line, (size_t) W * ch);
+        else for (i = 0; i < H; i++) memcpy(out + ((size_t) i * W + n) * ch, line + (size_t) i * ch, ch);
+    }
+    return LQR_OK;
+}
+
+/* ======================= test hooks ====================================== */
+LqrRetVal lqrx_carver_get_energy(LqrCarver *r, gfloat *buffer)
+{
+    int x, y;
+    if (r->root) return LQR_ERROR;
+    LQR_CATCH(init_energy_related(r));
+    if (r->w != r->w_start - r->max_level + 1) LQR_CATCH(lqr_carver_flatten(r));
+    LQR_CATCH(build_emap(r));
+    for (y = 0; y < r->h; y++)
+        for (x = 0; x < r->w; x++) buffer[(size_t) y * r->w + x] = r->en[r->raw[y][x]];
+    return LQR_OK;
+}
+
+gint lqrx_carver_debug_width(LqrCarver *r) { return r->dbg_w; }
+gint lqrx_carver_debug_height(LqrCarver *r) { return r->dbg_h; }
+LqrRetVal lqrx_carver_debug_snapshot(LqrCarver *r, gfloat *en, gfloat *m, gint *least_dx)
+{
+    size_t n = (size_t) r->dbg_w * r->dbg_h;
+    if (!r->dbg_m) return LQR_ERROR;
+    if (en) memcpy(en, r->dbg_en, n * sizeof(float));
+    if (m) memcpy(m, r->dbg_m, n * sizeof(float));
+    if (least_dx) memcpy(least_dx, r->dbg_least, n * sizeof(int));
+    return LQR_OK;
+}
+
+LqrRetVal lqrx_carver_debug_maps(LqrCarver *r, gfloat *en, gfloat *m, gint *least_dx)
+{
+    int x, y, x1;
+    if (!r->active || !r->m || !r->en || !r->least) return LQR_ERROR;
+    for (y = 0; y < r->h; y++) {
+        for (x = 0; x < r->w; x++) {
+            int data = r->raw[y][x];
+            size_t o = (size_t) y * r->w + x;
+            if (en) en[o] = r->en[data];
+            if (m) m[o] = r->m[data];
+            if (least_dx) {
+                least_dx[o] = 0;
+                if (y > 0)
+                    for (x1 = MAXI(x - r->delta_x, 0); x1 <= MINI(x + r->delta_x, r->w - 1); x1++)
+                        if (r->raw[y - 1][x1] == r->least[data]) { least_dx[o] = x1 - x; break; }
+            }
+        }
+    }
+    return LQR_OK;
+}

@@ -1,0 +1,91 @@
+"""Headless replay of the reference's render path on in-memory layers.
+
+run_case() issues, against any library exporting the LqrCarver ABI, the call
+sequence of render_init_carver (src/render.c:220-248) followed by
+render_noninteractive (src/render.c:318-376) and the read-out of
+write_carver_to_layer / write_all_vmaps (src/io_functions.c:134-182,292-314).
+The config keys are the engine-facing subset of PlugInVals
+(src/main_common.h:34-60) with the defaults of src/main.c:62-87.
+"""
+import numpy as np
+
+import lqr_ctypes as L
+
+DEFAULTS = dict(pres_coeff=1000, disc_coeff=1000, rigidity=0.0, delta_x=1, enl_step=150.0,
+                nrg_func=L.LQR_EF_GRAD_XABS, res_order=L.LQR_RES_ORDER_HOR, output_seams=False,
+                resize_aux_layers=False, scaleback=False, no_disc_on_enlarge=True,
+                switch_freq=2)
+
+
+def compute_ignore_disc_mask(v, ow, oh, nw, nh):
+    """src/render.c:794-821"""
+    if not v["no_disc_on_enlarge"]:
+        return False
+    if v["res_order"] == L.LQR_RES_ORDER_HOR:
+        return nw > ow or (nw == ow and nh > oh)
+    return nh > oh or (nh == oh and nw > ow)
+
+
+def init_carver(api, img, new_w, new_h, pres=None, disc=None, rigmask=None, progress=False, **kw):
+    v = dict(DEFAULTS); v.update(kw)
+    h, w = img.shape[:2]
+    rigidity = 3 * v["rigidity"] if rigmask is not None else v["rigidity"]      # render.c:781-792
+    c = L.Carver(api, img, delta_x=v["delta_x"], rigidity=rigidity)
+    if pres is not None and v["pres_coeff"]:
+        assert c.bias_add(pres, v["pres_coeff"]) == L.LQR_OK
+    if disc is not None and v["disc_coeff"] and not compute_ignore_disc_mask(v, w, h, new_w, new_h):
+        assert c.bias_add(disc, -v["disc_coeff"]) == L.LQR_OK
+    if rigmask is not None:
+        assert c.rigmask_add(rigmask) == L.LQR_OK
+    c.configure(nrg_func=v["nrg_func"], res_order=v["res_order"], switch_freq=v["switch_freq"],
+                enl_step=v["enl_step"] / 100.0, dump_vmaps=v["output_seams"], progress=progress)
+    if v["resize_aux_layers"]:
+        for m in (pres, disc, rigmask):
+            if m is not None:
+                c.attach(m)
+    return c, v
+
+
+def run_case(api, img, new_w, new_h, **kw):
+    """returns everything observable at the C ABI after render_noninteractive"""
+    c, v = init_carver(api, img, new_w, new_h, **kw)
+    h, w = img.shape[:2]
+    res = {}
+    res["ret"] = c.resize(new_w, new_h)
+    if v["scaleback"]:      # SCALEBACK_MODE_LQRBACK, render.c:320-329
+        assert c.flatten() == L.LQR_OK
+        res["ret2"] = c.resize(w, h)
+    if v["output_seams"]:
+        res["vmaps"] = c.dumped_vmaps()
+    res["getters"] = c.getters()
+    img_lines, nlines = c.read_scanlines()
+    res["image"] = img_lines
+    res["nlines"] = nlines
+    res["aux"] = [a.read_scanlines()[0] for a in c.aux]
+    res["vmap"] = c.vmap_dump()
+    res["events"] = list(c.events)
+    c.destroy()
+    return res
+
+
+def assert_same(a, b, what=""):
+    assert a["ret"] == b["ret"], what
+    assert a["getters"] == b["getters"], (what, a["getters"], b["getters"])
+    assert a["image"].shape == b["image"].shape, what
+    assert a["vmap"]["depth"] == b["vmap"]["depth"] and a["vmap"]["orientation"] == b["vmap"]["orientation"], what
+    if not np.array_equal(a["vmap"]["data"], b["vmap"]["data"]):
+        bad = np.argwhere(a["vmap"]["data"] != b["vmap"]["data"])
+        first_level = min(int(a["vmap"]["data"][tuple(bad[0])]), int(b["vmap"]["data"][tuple(bad[0])]))
+        raise AssertionError("%s: seam maps differ at %d px, first %s (levels %d vs %d)" % (
+            what, len(bad), bad[0], a["vmap"]["data"][tuple(bad[0])], b["vmap"]["data"][tuple(bad[0])]))
+    assert np.array_equal(a["image"], b["image"]), what + ": images differ"
+    assert a["nlines"] == b["nlines"], what
+    assert len(a["aux"]) == len(b["aux"])
+    for x, y in zip(a["aux"], b["aux"]):
+        assert np.array_equal(x, y), what + ": aux images differ"
+    if "vmaps" in a or "vmaps" in b:
+        assert len(a["vmaps"]) == len(b["vmaps"]), what
+        for x, y in zip(a["vmaps"], b["vmaps"]):
+            assert x["depth"] == y["depth"] and x["orientation"] == y["orientation"]
+            assert np.array_equal(x["data"], y["data"]), what + ": dumped vmaps differ"
+    assert a["events"] == b["events"], what + ": progress events differ"
