@@ -1372,6 +1372,23 @@ extern "C" int lqrhip_read_visible(LqrHipCarver *c, int w0, int h0, int w, int l
     return 0;
 }
 
+extern "C" int lqrhip_read_visible_device(LqrHipCarver *c, int w0, int h0, int w, int level, void *device_out)
+{
+    int rc = batch_sync_of(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_compact, dim3(h0), dim3(256), 0, g_stream0, c->rgb0, c->vs, (const float *) nullptr, (const float *) nullptr,
+                       (uint8_t *) device_out, (float *) nullptr, (float *) nullptr, (int32_t *) nullptr, w0, w, c->ch, level, 0);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(g_stream0));
+    return 0;
+}
+
+extern "C" int lqrhip_device_sync(void)
+{
+    HIPCK(hipDeviceSynchronize());
+    return 0;
+}
+
 extern "C" int lqrhip_read_vmap(LqrHipCarver *c, int w0, int h0, int w, int level, int depth, int *out)
 {
     int rc = batch_sync_of(c);

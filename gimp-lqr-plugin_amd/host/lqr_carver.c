@@ -682,6 +682,12 @@ LqrRetVal lqrx_carver_read_image(LqrCarver *r, guchar *out)
     return LQR_OK;
 }
 
+LqrRetVal lqrx_carver_read_image_device(LqrCarver *r, void *device_ptr)
+{
+    HIP_CATCH(lqrhip_read_visible_device(r->dev, r->w0, r->h0, r->w, r->level, device_ptr));
+    return LQR_OK;
+}
+
 /* ======================= test hooks ====================================== */
 LqrRetVal lqrx_carver_get_energy(LqrCarver *r, gfloat *buffer)
 {

@@ -195,6 +195,11 @@ LqrRetVal lqrx_carver_debug_snapshot(LqrCarver *r, gfloat *en, gfloat *m, gint *
  * get_width*get_height*channels bytes): the same bytes the scan_line loop of
  * io_functions.c:155-164 would assemble, in one call. */
 LqrRetVal lqrx_carver_read_image(LqrCarver *r, guchar *out);
+/* Same bytes as the scan lines, but written straight into a caller-provided
+ * DEVICE buffer (get_width*get_height*channels bytes in CARVER orientation, i.e.
+ * image orientation unless lqr_carver_get_orientation() is 1): lets a batch
+ * driver hand results to RCCL without a host round trip. */
+LqrRetVal lqrx_carver_read_image_device(LqrCarver *r, void *device_ptr);
 /* Carve n independent carvers (same geometry and configuration) in lock-step;
  * equivalent to calling lqr_carver_resize on each.  The engine runs them as one
  * batched launch sequence (the per-frame batch axis). */

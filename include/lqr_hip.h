@@ -102,6 +102,9 @@ int lqrhip_transpose(LqrHipBatch *b, int w, int h);
 /* E12 scan_line source: the pixels visible at `level`, packed w x h x channels
  * in CARVER orientation (io_functions.c:155-164 then serves rows of it). */
 int lqrhip_read_visible(LqrHipCarver *c, int w0, int h0, int w, int level, unsigned char *out);
+/* same, but into a caller-provided device buffer (no host round trip) */
+int lqrhip_read_visible_device(LqrHipCarver *c, int w0, int h0, int w, int level, void *device_out);
+int lqrhip_device_sync(void);
 /* E12 lqr_vmap_dump (render.c:725): vs of the pixels visible at `level`
  * minus `depth` (0 stays 0), w x h in carver orientation */
 int lqrhip_read_vmap(LqrHipCarver *c, int w0, int h0, int w, int level, int depth, int *out);

@@ -1117,6 +1117,16 @@ LqrRetVal lqrx_carver_read_image(LqrCarver *r, guchar *out)
     return LQR_OK;
 }
 
+/* the oracle has no device: the "device" pointer is plain host memory, carver orientation */
+LqrRetVal lqrx_carver_read_image_device(LqrCarver *r, void *device_ptr)
+{
+    int n;
+    guchar *line, *out = (guchar *) device_ptr;
+    cursor_reset(r);
+    while (lqr_carver_scan_line(r, &n, &line)) memcpy(out + (size_t) n * r->w * r->channels, line, (size_t) r->w * r->channels);
+    return LQR_OK;
+}
+
 /* ======================= test hooks ====================================== */
 LqrRetVal lqrx_carver_get_energy(LqrCarver *r, gfloat *buffer)
 {

@@ -1,0 +1,74 @@
+"""The C-ABI library loads (no GPU needed for dlopen) and exports every symbol the
+headers declare; no compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import lqr_ctypes as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header, pattern):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(pattern, text)))
+
+
+def test_headers_declare_the_reference_surface():
+    names = declared("lqr.h", r"\b(lqr_[a-z_0-9]+)\s*\(")
+    # the 39 functions gimp-lqr-plugin references
+    for need in ("lqr_carver_new", "lqr_carver_init", "lqr_carver_destroy", "lqr_carver_attach", "lqr_carver_resize",
+                 "lqr_carver_flatten", "lqr_carver_scan_line", "lqr_carver_scan_by_row", "lqr_carver_bias_add_rgb_area",
+                 "lqr_carver_rigmask_add_rgb_area", "lqr_carver_set_energy_function_builtin", "lqr_carver_set_resize_order",
+                 "lqr_carver_set_progress", "lqr_carver_set_side_switch_frequency", "lqr_carver_set_enl_step",
+                 "lqr_carver_get_enl_step", "lqr_carver_set_dump_vmaps", "lqr_carver_get_height", "lqr_carver_get_channels",
+                 "lqr_carver_get_ref_width", "lqr_carver_get_ref_height", "lqr_carver_get_orientation", "lqr_carver_get_depth",
+                 "lqr_carver_list_start", "lqr_carver_list_current", "lqr_carver_list_next", "lqr_vmap_dump",
+                 "lqr_vmap_get_data", "lqr_vmap_get_width", "lqr_vmap_get_height", "lqr_vmap_get_depth",
+                 "lqr_vmap_list_start", "lqr_vmap_list_foreach", "lqr_progress_new", "lqr_progress_set_init",
+                 "lqr_progress_set_update", "lqr_progress_set_end", "lqr_progress_set_init_width_message",
+                 "lqr_progress_set_init_height_message"):
+        assert need in names, need
+    assert set(L.SYMBOLS) == set(declared("lqr.h", r"\b(lqrx?_[a-z_0-9]+)\s*\("))
+
+
+def test_engine_library_exports_every_declared_symbol():
+    if not os.path.exists(L.ENGINE_LIB):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(L.ENGINE_LIB)
+    for name in declared("lqr.h", r"\b(lqrx?_[a-z_0-9]+)\s*\("):
+        assert hasattr(lib, name), "missing export " + name
+    for name in declared("lqr_hip.h", r"\b(lqrhip_[a-z_0-9]+)\s*\("):
+        assert hasattr(lib, name), "missing export " + name
+
+
+def test_engine_does_not_link_or_reference_the_oracle():
+    """the product path never routes through oracle/ (no CPU fallback)"""
+    out = os.popen("readelf -d '%s'" % L.ENGINE_LIB).read()
+    assert "oracle" not in out
+    syms = os.popen("nm -D '%s'" % L.ENGINE_LIB).read()
+    assert "olqr_" not in syms
+    for src in ("gimp-lqr-plugin_amd/host/lqr_carver.c", "gimp-lqr-plugin_amd/csrc/lqr_hip.hip", "gimp-lqr-plugin_amd/__init__.py"):
+        text = open(os.path.join(ROOT, src)).read()
+        assert "oracle/" not in text and "olqr_" not in text and "liblqr_oracle" not in text, src
+
+
+def test_oracle_exports_the_same_abi(oracle):
+    for name in L.SYMBOLS:
+        assert hasattr(oracle.lib, "o" + name)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """on a box without a HIP device lqr_carver_new must return NULL (and say why)"""
+    import numpy as np
+    lib = ctypes.CDLL(L.ENGINE_LIB)
+    lib.lqrhip_init.restype = ctypes.c_int
+    if lib.lqrhip_init() >= 0:
+        pytest.skip("a GPU is present")
+    eng = L.engine_api()
+    with pytest.raises(MemoryError):
+        L.Carver(eng, np.zeros((4, 4, 4), np.uint8))

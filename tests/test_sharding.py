@@ -1,0 +1,80 @@
+"""Multi-GPU path on CPU: world_size-2 gloo run of the sharding + gather logic that
+bench.py uses (image i -> rank i mod N, no data-path collective, one gather of the
+equal-sized outputs).  The carving backend here is the CPU oracle (tests only)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _pkg():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    return g._import_package()
+
+
+def test_shard_indices_partition():
+    pkg = _pkg()
+    for n, world in [(64, 8), (7, 2), (3, 4), (1, 1)]:
+        parts = [pkg.shard_indices(n, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(n))
+        assert all(i % world == r for r, p in enumerate(parts) for i in p)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, HERE)
+    import datasets as D
+    import lqr_ctypes as L
+    pkg = _pkg()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    api = L.oracle_api()
+    n_images, w, h, nw = 6, 40, 24, 32
+    mine = pkg.shard_indices(n_images, rank, world)
+    outs = torch.zeros((len(mine), h, nw, 4), dtype=torch.uint8)
+    for j, i in enumerate(mine):
+        c = L.Carver(api, D.photo_like(w, h, 100 + i)).configure()
+        assert c.resize(nw, h) == L.LQR_OK
+        outs[j] = torch.from_numpy(c.read_image())
+        c.destroy()
+    dist.barrier()
+    gathered = [torch.zeros_like(outs) for _ in range(world)] if rank == 0 else None
+    dist.gather(outs, gathered, dst=0)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)       # the max-over-ranks timing reduction
+    assert t.item() == world
+    if rank == 0:
+        full = np.zeros((n_images, h, nw, 4), np.uint8)
+        for r in range(world):
+            for j, i in enumerate(pkg.shard_indices(n_images, r, world)):
+                full[i] = gathered[r][j].numpy()
+        q.put(full)
+    dist.destroy_process_group()
+
+
+def test_two_rank_batch_equals_single_process():
+    import datasets as D
+    import lqr_ctypes as L
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    api = L.oracle_api()
+    for i in range(6):
+        c = L.Carver(api, D.photo_like(40, 24, 100 + i)).configure()
+        assert c.resize(32, 24) == L.LQR_OK
+        assert np.array_equal(c.read_image(), full[i])
+        c.destroy()
