@@ -97,7 +97,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
-    # the engine first: it pins the process to ROCm's HIP runtime and to device LOCAL_RANK
+    # torch first: its bundled HIP runtime (same soname) must be the one runtime of the process;
+    # the engine then binds to it and pins itself to device LOCAL_RANK
+    import numpy as np
+    import torch
     import lqr_ctypes as L
     eng = L.engine_api()
     lib = eng.lib
@@ -105,8 +108,6 @@ def main():
         lib.lqrhip_last_error.restype = C.c_char_p
         raise SystemExit("bench.py: no usable HIP device: %s" % lib.lqrhip_last_error().decode())
 
-    import numpy as np
-    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -59,6 +59,40 @@ struct DevCarver {
     int32_t *flags;
 };
 
+// Pointers fetched from a descriptor in memory are "generic" to the compiler, which then
+// emits flat_load/flat_store (slower issue, and every access also ties up lgkmcnt, which
+// defeats software prefetching).  Kernels therefore work on a view whose members are typed
+// as address-space-1 (global) pointers, so that they become global_load/global_store.
+#define GLOBAL_AS __attribute__((address_space(1)))
+typedef GLOBAL_AS uint8_t gu8;
+typedef GLOBAL_AS uint32_t gu32;
+typedef GLOBAL_AS int32_t gi32;
+typedef GLOBAL_AS int8_t gi8;
+typedef GLOBAL_AS float gf32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native vectors: usable through address-space pointers
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GCarver {
+    gu8 *rgb0;
+    gi32 *vs;
+    gf32 *bias0, *rig0;
+    gu32 *pix;
+    gf32 *en, *m;
+    gi8 *least;
+    gf32 *bias, *rig;
+    gi32 *seam_x, *seam_log, *flags;
+};
+
+__device__ __forceinline__ GCarver gview(const DevCarver &d)
+{
+    GCarver g;
+    g.rgb0 = (gu8 *) d.rgb0; g.vs = (gi32 *) d.vs; g.bias0 = (gf32 *) d.bias0; g.rig0 = (gf32 *) d.rig0;
+    g.pix = (gu32 *) d.pix; g.en = (gf32 *) d.en; g.m = (gf32 *) d.m; g.least = (gi8 *) d.least;
+    g.bias = (gf32 *) d.bias; g.rig = (gf32 *) d.rig;
+    g.seam_x = (gi32 *) d.seam_x; g.seam_log = (gi32 *) d.seam_log; g.flags = (gi32 *) d.flags;
+    return g;
+}
+
 struct DpK {
     int delta;
     int use_rig;
@@ -113,12 +147,12 @@ __device__ __forceinline__ double px_bright(uint32_t p, int ch, bool luma)
 // reproduces it), so every kernel that evaluates the energy is instantiated
 // once per energy function and the selector is resolved at launch.
 template <int NRG>
-__device__ __forceinline__ float grad_energy(const uint32_t *pix, int stride, int x, int y, int w, int h, int ch)
+__device__ __forceinline__ float grad_energy(const gu32 *pix, int stride, int x, int y, int w, int h, int ch)
 {
     if (NRG == 6) return 0.0f;
     constexpr bool luma = (NRG >= 3);
     constexpr int kind = NRG % 3;          // 0 norm, 1 sumabs, 2 xabs
-    const uint32_t *row = pix + (size_t) y * stride;
+    const gu32 *row = pix + (size_t) y * stride;
     double gx, gy = 0.0;
     if (kind != 2) {
         if (h == 1) gy = 0.0;
@@ -138,7 +172,7 @@ __device__ __forceinline__ float grad_energy(const uint32_t *pix, int stride, in
 }
 
 template <int NRG>
-__device__ __forceinline__ float energy_at(const DevCarver &c, const DpK &p, int stride, int x, int y, int w, int h)
+__device__ __forceinline__ float energy_at(const GCarver &c, const DpK &p, int stride, int x, int y, int w, int h)
 {
     float e = grad_energy<NRG>(c.pix, stride, x, y, w, h, p.ch);
     if (c.bias) e = __fadd_rn(e, __fdiv_rn(c.bias[(size_t) y * stride + x], (float) p.w_start));
@@ -162,14 +196,14 @@ __device__ __forceinline__ float energy_at(const DevCarver &c, const DpK &p, int
 // ---------------------------------------------------------------------------
 __global__ void k_wk_init(const DevCarver *cs, int w, int h, int stride, int ch)
 {
-    const DevCarver c = cs[blockIdx.z];
+    const GCarver c = gview(cs[blockIdx.z]);
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= stride) return;
     size_t o = (size_t) y * stride + x;
     uint32_t p = 0;
     float b = 0.0f, r = 0.0f;
     if (x < w) {
-        const uint8_t *s = c.rgb0 + ((size_t) y * w + x) * ch;
+        const gu8 *s = c.rgb0 + ((size_t) y * w + x) * ch;
         for (int k = 0; k < ch; k++) p |= (uint32_t) s[k] << (8 * k);
         if (c.bias0) b = c.bias0[(size_t) y * w + x];
         if (c.rig0) r = c.rig0[(size_t) y * w + x];
@@ -182,7 +216,7 @@ __global__ void k_wk_init(const DevCarver *cs, int w, int h, int stride, int ch)
 template <int NRG>
 __global__ void k_emap_full(const DevCarver *cs, DpK p, int w, int h, int stride)
 {
-    const DevCarver c = cs[blockIdx.z];
+    const GCarver c = gview(cs[blockIdx.z]);
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     c.en[(size_t) y * stride + x] = energy_at<NRG>(c, p, stride, x, y, w, h);
@@ -225,7 +259,7 @@ __global__ void k_mask_add(float *plane, int w0, const uint8_t *mask, int channe
 template <int PXT, bool UPDATE>
 __global__ __launch_bounds__(DP_THREADS) void k_dp_sweep(const DevCarver *cs, DpK p, int w, int h, int stride, int lr)
 {
-    const DevCarver c = cs[blockIdx.x];
+    const GCarver c = gview(cs[blockIdx.x]);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int wpad = (w + 3) & ~3;
     float *prev = sm, *cur = sm + wpad;
@@ -308,7 +342,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sweep(const DevCarver *cs, Dp
 __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, int w, int h, int stride, int lr, int delta,
                                                           int log_index)
 {
-    const DevCarver c = cs[blockIdx.x];
+    const GCarver c = gview(cs[blockIdx.x]);
     __shared__ float s_val[VPATH_THREADS];
     __shared__ int s_idx[VPATH_THREADS];
     __shared__ int s_x;
@@ -316,7 +350,7 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
     const int tid = threadIdx.x;
 
     // ---- argmin over the last row: leftmost (lr=0) / rightmost (lr=1) of equals
-    const float *mrow = c.m + (size_t) (h - 1) * stride;
+    const gf32 *mrow = c.m + (size_t) (h - 1) * stride;
     float bv = __int_as_float(0x7f800000);    // +inf
     int bi = -1;
     for (int x = tid; x < w; x += VPATH_THREADS) {
@@ -349,8 +383,8 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
     __syncthreads();
 
     // ---- backtrack
-    int32_t *seam = c.seam_x;
-    int32_t *logp = c.seam_log + (size_t) log_index * h;
+    gi32 *seam = c.seam_x;
+    gi32 *logp = c.seam_log + (size_t) log_index * h;
     const int R = delta > 0 ? max(1, 64 / delta) : 64;      // rows per chunk, R*delta <= 64
     const int half = (R > 64 ? 64 : R) * delta;
     const int rows_per_chunk = R > 64 ? 64 : R;
@@ -391,37 +425,37 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
 // The back-pointer plane is re-based on the fly: a stored dx stays valid unless
 // pixel and parent are on different sides of the seam.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void shift_row_u32(uint32_t *row, int v, int wnew, int lane)
+__device__ __forceinline__ void shift_row_u32(gu32 *row, int v, int wnew, int lane)
 {
     int base = v & ~3;
     // 4 chunks of 256 px in flight: all loads of a group are issued before its stores
     for (; base < wnew; base += 1024) {
-        uint4 a[4]; uint32_t nx[4];
+        u32x4 a[4]; uint32_t nx[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             int x = base + u * 256 + lane * 4;
-            if (x < wnew) { a[u] = *(const uint4 *) (row + x); nx[u] = row[x + 4]; }
+            if (x < wnew) { a[u] = *(const GLOBAL_AS u32x4 *) (row + x); nx[u] = row[x + 4]; }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             int x = base + u * 256 + lane * 4;
             if (x < wnew) {
-                uint4 o;
+                u32x4 o;
                 o.x = (x >= v) ? a[u].y : a[u].x;
                 o.y = (x + 1 >= v) ? a[u].z : a[u].y;
                 o.z = (x + 2 >= v) ? a[u].w : a[u].z;
                 o.w = (x + 3 >= v) ? nx[u] : a[u].w;
-                *(uint4 *) (row + x) = o;
+                *(GLOBAL_AS u32x4 *) (row + x) = o;
             }
         }
     }
 }
 
-__device__ __forceinline__ void shift_row_least(int8_t *row, int v, int vprev, int y, int delta, int wnew, int lane)
+__device__ __forceinline__ void shift_row_least(gi8 *row, int v, int vprev, int y, int delta, int wnew, int lane)
 {
     int start = (y > 0) ? min(v, vprev - delta) : v;
     if (start < 0) start = 0;
-    uint32_t *row32 = (uint32_t *) row;
+    gu32 *row32 = (gu32 *) row;
     for (int base = start & ~3; base < wnew; base += 256) {
         int x = base + lane * 4;
         if (x < wnew) {
@@ -448,7 +482,7 @@ __device__ __forceinline__ void shift_row_least(int8_t *row, int v, int vprev, i
 
 __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h, int stride, int delta, int move_dp)
 {
-    const DevCarver c = cs[blockIdx.y];
+    const GCarver c = gview(cs[blockIdx.y]);
     const int lane = threadIdx.x & 63;
     const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (y >= h) return;
@@ -456,18 +490,18 @@ __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h
     const int wnew = w - 1;
     size_t ro = (size_t) y * stride;
     shift_row_u32(c.pix + ro, v, wnew, lane);
-    shift_row_u32((uint32_t *) (c.en + ro), v, wnew, lane);
-    if (c.bias) shift_row_u32((uint32_t *) (c.bias + ro), v, wnew, lane);
-    if (c.rig) shift_row_u32((uint32_t *) (c.rig + ro), v, wnew, lane);
+    shift_row_u32((gu32 *) (c.en + ro), v, wnew, lane);
+    if (c.bias) shift_row_u32((gu32 *) (c.bias + ro), v, wnew, lane);
+    if (c.rig) shift_row_u32((gu32 *) (c.rig + ro), v, wnew, lane);
     if (move_dp) {
-        shift_row_u32((uint32_t *) (c.m + ro), v, wnew, lane);
+        shift_row_u32((gu32 *) (c.m + ro), v, wnew, lane);
         int vprev = y > 0 ? c.seam_x[y - 1] : 0;
         shift_row_least(c.least + ro, v, vprev, y, delta, wnew, lane);
     }
 }
 
 // changed-energy interval of row y after carving (liblqr update_emap), w = new width
-__device__ __forceinline__ void nrg_interval(const int32_t *seam, int y, int h, int w, int radius, int &xmin, int &xmax)
+__device__ __forceinline__ void nrg_interval(const gi32 *seam, int y, int h, int w, int radius, int &xmin, int &xmax)
 {
     int y1a = max(y - radius, 0), y1b = min(y + radius, h - 1);
     int lo = seam[y], hi = seam[y] - 1;
@@ -484,7 +518,7 @@ __device__ __forceinline__ void nrg_interval(const int32_t *seam, int y, int h, 
 template <int NRG>
 __global__ void k_emap_update(const DevCarver *cs, DpK p, int w, int h, int stride)
 {
-    const DevCarver c = cs[blockIdx.y];
+    const GCarver c = gview(cs[blockIdx.y]);
     int y = blockIdx.x * blockDim.x + threadIdx.x;
     if (y >= h) return;
     int xmin, xmax;
@@ -510,11 +544,11 @@ struct BandRow {
 
 __global__ __launch_bounds__(64) void k_band_update(const DevCarver *cs, DpK p, int w, int h, int stride, int lr)
 {
-    const DevCarver c = cs[blockIdx.x];
+    const GCarver c = gview(cs[blockIdx.x]);
     __shared__ __attribute__((aligned(16))) float prow[BAND_WIN + 2 * LQRHIP_MAX_DELTA + 8];
     const int lane = threadIdx.x;
     const int delta = p.delta;
-    const int32_t *seam = c.seam_x;
+    const gi32 *seam = c.seam_x;
     float *pr = prow + LQRHIP_MAX_DELTA + 4;      // pr[-delta .. BAND_WIN+delta) addressable
 
     int a, b;                                     // current band (liblqr's x_min, x_max)
@@ -549,11 +583,11 @@ __global__ __launch_bounds__(64) void k_band_update(const DevCarver *cs, DpK p, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         {
-            const float *mp = c.m + (size_t) (y - 1) * stride;
+            const gf32 *mp = c.m + (size_t) (y - 1) * stride;
             for (int i = lane; i < BAND_WIN + 2 * delta; i += 64) {
                 int x = B - delta + i;
                 float v = 0.0f;
-                if (x >= 0 && x < w) v = __hip_atomic_load((float *) (mp + x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (x >= 0 && x < w) v = __hip_atomic_load((gf32 *) (mp + x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pr[i - delta] = v;
             }
         }
@@ -563,13 +597,13 @@ __global__ __launch_bounds__(64) void k_band_update(const DevCarver *cs, DpK p, 
         auto load_row = [&](BandRow &r, int yy) {
             if (yy < h) {
                 size_t o = (size_t) yy * stride + x0;
-                float4 mv = *(const float4 *) (c.m + o);
-                float4 ev = *(const float4 *) (c.en + o);
+                f32x4 mv = *(const GLOBAL_AS f32x4 *) (c.m + o);
+                f32x4 ev = *(const GLOBAL_AS f32x4 *) (c.en + o);
                 r.mo[0] = mv.x; r.mo[1] = mv.y; r.mo[2] = mv.z; r.mo[3] = mv.w;
                 r.e[0] = ev.x; r.e[1] = ev.y; r.e[2] = ev.z; r.e[3] = ev.w;
-                r.lo = *(const uint32_t *) (c.least + o);
+                r.lo = *(const gu32 *) (c.least + o);
                 if (c.rig) {
-                    float4 rv = *(const float4 *) (c.rig + o);
+                    f32x4 rv = *(const GLOBAL_AS f32x4 *) (c.rig + o);
                     r.rf[0] = rv.x; r.rf[1] = rv.y; r.rf[2] = rv.z; r.rf[3] = rv.w;
                 }
             }
@@ -627,8 +661,8 @@ __global__ __launch_bounds__(64) void k_band_update(const DevCarver *cs, DpK p, 
                         {
                             size_t o = (size_t) y * stride + x0;
                             if (x0 < stride) {
-                                *(float4 *) (c.m + o) = make_float4(mc[0], mc[1], mc[2], mc[3]);
-                                *(uint32_t *) (c.least + o) = lnew;
+                                { f32x4 t4 = {mc[0], mc[1], mc[2], mc[3]}; *(GLOBAL_AS f32x4 *) (c.m + o) = t4; }
+                                *(gu32 *) (c.least + o) = lnew;
                             }
                         }
                         // halo of pr (parents outside the window never matter: see `fits`)
@@ -658,6 +692,220 @@ __global__ __launch_bounds__(64) void k_band_update(const DevCarver *cs, DpK p, 
 }
 
 // ---------------------------------------------------------------------------
+// E9 update_mmap, band form, delta_x == 1 fast path (the plug-in default).
+// One workgroup of NW waves per image.  The window is NW slots of 64*PXL px; wave
+// v owns slot v and lane L the PXL consecutive pixels x = B + 64*PXL*v + PXL*L.
+// The 3-neighbour window of the previous row lives in registers (inside a lane
+// directly, across lanes through DPP wave shifts, across waves through two LDS
+// words per wave), so the per-row dependency chain is VALU + one s_barrier; only
+// the waves whose slot the band reaches do any arithmetic.  Rows are prefetched
+// in batches of R rows into a register ping-pong (loads for the next batch are in
+// flight while this batch is processed), so the H-step chain does not stall on HBM.
+// The band shrink (leading / trailing run of "stop" pixels) is an LDS min/max.
+// Seam positions (for the changed-energy intervals) are staged in LDS once.
+// ---------------------------------------------------------------------------
+#define DPP_WAVE_SHL1 0x130
+#define DPP_WAVE_SHR1 0x138
+
+template <int PXL> struct PxVec;
+template <> struct PxVec<1> { typedef float F; typedef uint8_t L; };
+template <> struct PxVec<2> { typedef float F __attribute__((ext_vector_type(2))); typedef uint16_t L; };
+template <> struct PxVec<4> { typedef f32x4 F; typedef uint32_t L; };
+
+template <int PXL, int NW, int R, bool LR, bool RIG>
+__global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs, DpK p, int w, int h, int stride)
+{
+    typedef typename PxVec<PXL>::F FV;
+    typedef typename PxVec<PXL>::L LV;
+    typedef GLOBAL_AS FV GFV;
+    typedef GLOBAL_AS LV GLV;
+    const GCarver c = gview(cs[blockIdx.x]);
+    extern __shared__ int s_seam[];                   // [h]
+    __shared__ float s_edge[2][NW][2];                // [row parity][wave]{first px of lane 0, last px of lane 63}
+    __shared__ int s_first[3], s_last[3];             // [row % 3] first / last changed pixel of the row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float INF = __int_as_float(0x7f800000);
+    constexpr int SLOT = 64 * PXL, WIN = SLOT * NW;
+    const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
+    const int radius = p.radius;
+
+    for (int i = tid; i < h; i += 64 * NW) s_seam[i] = c.seam_x[i];
+    if (tid < 3) { s_first[tid] = 0x7fffffff; s_last[tid] = -1; }
+    __syncthreads();
+
+    // liblqr update_emap interval of row y (radius is 0 or 1)
+    auto interval = [&](int y, int &n0, int &n1) {
+        const int yy = min(y, h - 1);
+        const int v0 = s_seam[yy];
+        int lo = v0, hi = v0 - 1;
+        if (radius) {
+            const int vm = s_seam[max(yy - 1, 0)], vp = s_seam[min(yy + 1, h - 1)];
+            lo = min(min(v0, vm), vp) - 1;
+            hi = max(max(v0, vm), vp);
+        }
+        n0 = __builtin_amdgcn_readfirstlane(max(0, lo));
+        n1 = __builtin_amdgcn_readfirstlane(min(w - 1, hi));
+    };
+
+    int a, b;
+    {
+        int n0, n1;
+        interval(0, n0, n1);
+        a = max(n0, 0); b = min(n1, w - 1);
+        for (int x = a + tid; x <= b; x += 64 * NW) c.m[x] = c.en[x];      // row 0: m = en
+    }
+    if (h < 2) { if (tid == 0) c.flags[FLAG_OVF_ROW] = h; return; }
+
+    const unsigned dummy = (unsigned) h * stride + PXL * tid;      // scratch row for lanes outside the image
+    int y = 1, ovf = h;
+    int n0, n1;
+    interval(1, n0, n1);
+    while (y < h) {
+        // ---- (re)base the window on the band of row y (identical decision in every wave)
+        const int na = max(min(a, n0) - 1, 0), nb = min(max(b, n1) + 1, w - 1);
+        if (nb - na + 1 > WIN - 2 * 70) { ovf = y; break; }
+        int B = (((na + nb) >> 1) - WIN / 2) & ~3;
+        B = max(0, min(B, (w - WIN + 3) & ~3));
+        B = __builtin_amdgcn_readfirstlane(B);
+
+        const int x0 = B + SLOT * wave + PXL * lane;          // first pixel of this lane
+        const int sx0 = B + SLOT * wave;                      // first pixel of this wave's slot
+        const unsigned lo_off = (unsigned) min(x0, stride - PXL);
+        const bool in_img = x0 < w;
+
+        // previous row: rows < y were stored by this workgroup -> make them visible, then load
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        float mp[PXL];
+        {
+            gf32 *mrow = c.m + (size_t) (y - 1) * stride;
+#pragma unroll
+            for (int k = 0; k < PXL; k++)
+                mp[k] = (x0 + k < w) ? __hip_atomic_load(mrow + x0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
+            if (lane == 0) s_edge[(y - 1) & 1][wave][0] = mp[0];
+            if (lane == 63) s_edge[(y - 1) & 1][wave][1] = mp[PXL - 1];
+        }
+        __syncthreads();
+
+        FV q_mo[2][R], q_e[2][R];
+        LV q_lo[2][R];
+        auto issue = [&](int buf, int ybase) {           // one batch of R rows, unconditional
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const unsigned ro = (unsigned) min(ybase + r, h - 1) * (unsigned) stride + lo_off;
+                q_mo[buf][r] = *(const GFV *) (c.m + ro);
+                q_e[buf][r] = *(const GFV *) (c.en + ro);
+                q_lo[buf][r] = *(const GLV *) (c.least + ro);
+            }
+        };
+        issue(0, y);
+
+        bool rebase = false;
+        while (y < h && !rebase) {
+#pragma unroll
+            for (int buf = 0; buf < 2; buf++) {
+                if (y < h && !rebase) {
+                    issue(buf ^ 1, y + R);            // next batch in flight while this one is processed
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (y < h && !rebase) {
+                            const int ra = max(min(a, n0) - 1, 0), rb = min(max(b, n1) + 1, w - 1);
+                            const bool fits = (ra - 1 >= B || B == 0) && (rb + 1 < B + WIN || B + WIN >= w);
+                            if (!fits) {
+                                rebase = true;
+                            } else {
+                                interval(y + 1, n0, n1);        // for the next row: off the dependency chain
+                                const unsigned span = (unsigned) (rb - ra);
+                                const int par = (y - 1) & 1;
+                                float mo[PXL], e[PXL], mc[PXL];
+                                uint32_t lo4 = (uint32_t) q_lo[buf][r];
+                                if (PXL == 1) { mo[0] = ((const float *) &q_mo[buf][r])[0]; e[0] = ((const float *) &q_e[buf][r])[0]; }
+                                else {
+#pragma unroll
+                                    for (int k = 0; k < PXL; k++) { mo[k] = q_mo[buf][r][k]; e[k] = q_e[buf][r][k]; }
+                                }
+                                uint32_t lnew = lo4;
+#pragma unroll
+                                for (int k = 0; k < PXL; k++) mc[k] = (x0 + k < w) ? mo[k] : INF;
+                                if (sx0 <= rb + 1 && sx0 + SLOT - 1 >= ra - 1) {          // the band reaches this slot
+                                    // neighbours of the lane's first / last pixel come from the adjacent lane,
+                                    // or from the adjacent wave (LDS) for lanes 0 and 63
+                                    const float wl = (wave > 0) ? s_edge[par][wave > 0 ? wave - 1 : 0][1] : INF;
+                                    const float wr = (wave < NW - 1) ? s_edge[par][wave < NW - 1 ? wave + 1 : 0][0] : INF;
+                                    float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wl), __float_as_int(mp[PXL - 1]),
+                                                                                        DPP_WAVE_SHR1, 0xf, 0xf, false));
+                                    float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wr), __float_as_int(mp[0]),
+                                                                                         DPP_WAVE_SHL1, 0xf, 0xf, false));
+                                    left = (x0 == 0) ? INF : left;
+                                    uint32_t chg = 0;
+                                    lnew = 0;
+#pragma unroll
+                                    for (int k = 0; k < PXL; k++) {
+                                        float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
+                                        const float cc = mp[k];
+                                        float rr = (k == PXL - 1) ? right : mp[k < PXL - 1 ? k + 1 : 0];
+                                        if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
+                                        // ascending scan, strict < (LR=0) or <= (LR=1); missing neighbours are +inf
+                                        const float best = fminf(fminf(l, cc), rr);
+                                        int bdx;
+                                        if (LR) bdx = (rr <= fminf(l, cc)) ? 1 : ((cc <= l) ? 0 : -1);
+                                        else bdx = ((l <= cc) & (l <= rr)) ? -1 : ((cc <= rr) ? 0 : 1);
+                                        const float nm = __fadd_rn(e[k], best);
+                                        const int lo_k = (int) (int8_t) (lo4 >> (8 * k));
+                                        // (double) fabsf(d) < 1e-5  <=>  fabsf(d) <= 1e-5f (the largest float below 1e-5)
+                                        const bool stop = (lo_k == bdx) & (fabsf(__fsub_rn(mo[k], nm)) <= 1e-5f);
+                                        const bool inband = (unsigned) (x0 + k - ra) <= span;
+                                        const bool ch = inband & !stop;
+                                        mc[k] = ch ? nm : mc[k];
+                                        const int outl = inband ? bdx : lo_k;
+                                        lnew |= ((uint32_t) outl & 0xffu) << (8 * k);
+                                        chg |= ch ? (1u << k) : 0u;
+                                    }
+                                    const unsigned long long bal = __ballot(chg != 0);
+                                    if (bal) {
+                                        const int fl = __ffsll((long long) bal) - 1, ll = 63 - __clzll((long long) bal);
+                                        const uint32_t mf = (uint32_t) __builtin_amdgcn_readlane((int) chg, fl);
+                                        const uint32_t ml = (uint32_t) __builtin_amdgcn_readlane((int) chg, ll);
+                                        if (lane == 0) {
+                                            atomicMin(&s_first[y % 3], sx0 + PXL * fl + (__ffs((int) mf) - 1));
+                                            atomicMax(&s_last[y % 3], sx0 + PXL * ll + (31 - __clz((int) ml)));
+                                        }
+                                    }
+                                }
+                                if (lane == 0) s_edge[y & 1][wave][0] = mc[0];
+                                if (lane == 63) s_edge[y & 1][wave][1] = mc[PXL - 1];
+                                if (tid == 0) { s_first[(y + 1) % 3] = 0x7fffffff; s_last[(y + 1) % 3] = -1; }
+                                // unconditional stores; lanes outside the image hit a scratch row
+                                const unsigned so = in_img ? (unsigned) y * (unsigned) stride + (unsigned) x0 : dummy;
+                                FV t;
+                                if (PXL == 1) ((float *) &t)[0] = mc[0];
+                                else {
+#pragma unroll
+                                    for (int k = 0; k < PXL; k++) t[k] = mc[k];
+                                }
+                                *(GFV *) (c.m + so) = t;
+                                *(GLV *) (c.least + so) = (LV) lnew;
+#pragma unroll
+                                for (int k = 0; k < PXL; k++) mp[k] = mc[k];
+                                // one barrier per row: LDS only (outstanding global loads/stores keep flying)
+                                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                                const int first = s_first[y % 3], last = s_last[y % 3];
+                                // shrink the band: leading stops advance a, the trailing run of stops pulls b back
+                                a = __builtin_amdgcn_readfirstlane(first == 0x7fffffff ? rb + 1 : first);
+                                b = __builtin_amdgcn_readfirstlane(first == 0x7fffffff ? ra : ((last == rb) ? rb : last + 1));
+                                y++;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (tid == 0) c.flags[FLAG_OVF_ROW] = ovf;
+}
+
+// ---------------------------------------------------------------------------
 // visibility map: seam log -> levels in the base layout (E8 update_vsmap for a
 // whole session), inflate (E14), flatten / read-out compaction (E11, E12),
 // transpose (E11)
@@ -680,7 +928,7 @@ __device__ __forceinline__ int block_rank_256(bool flag, int *s_wave, int &total
 __global__ __launch_bounds__(256) void k_vs_commit(const DevCarver *cs, int w0, int h0, int wc0, int n_seams, int first_level,
                                                     int finish)
 {
-    const DevCarver c = cs[blockIdx.y];
+    const GCarver c = gview(cs[blockIdx.y]);
     extern __shared__ int smi[];
     int *xs = smi;                      // [n_seams]
     int *lvl = smi + n_seams;           // [wc0]
@@ -696,7 +944,7 @@ __global__ __launch_bounds__(256) void k_vs_commit(const DevCarver *cs, int w0, 
         lvl[pz] = first_level + k;
     }
     __syncthreads();
-    int32_t *vrow = c.vs + (size_t) y * w0;
+    gi32 *vrow = c.vs + (size_t) y * w0;
     int carry = 0;
     for (int base = 0; base < w0; base += 256) {
         int col = base + tid;
@@ -1175,8 +1423,8 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     int rc;
     LqrHipCarver *c0 = b->cs[0];
     if (g_use_band < 0) {
-        const char *e = getenv("LQRHIP_NO_BAND");
-        g_use_band = (e && atoi(e)) ? 0 : 1;
+        const char *e = getenv("LQRHIP_NO_BAND");       // debug switches: 1 = full-width updates only,
+        g_use_band = (e && atoi(e) == 1) ? 0 : (e && atoi(e) == 2) ? 2 : 1;   // 2 = generic band kernel only
     }
     for (auto *c : b->cs)
         if (log_index >= c->log_cap) return LQRHIP_EARG;
@@ -1210,7 +1458,16 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         } else {
             if (g_use_band) {
                 ProfScope ps("band_update", b->stream, 0);
-                hipLaunchKernelGGL(k_band_update, dim3(n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, leftright_next);
+                bool has_rigmask = false;
+                for (auto *c : b->cs) has_rigmask |= (c->rig != nullptr);
+                if (p->delta_x == 1 && !has_rigmask && g_use_band == 1 && (size_t) h * sizeof(int) <= 60 * 1024) {
+#define LAUNCH_BAND(LRV, RIGV) hipLaunchKernelGGL((k_band_update_mw<2, 8, 8, LRV, RIGV>), dim3(n), dim3(512), (size_t) h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride)
+                    if (leftright_next) { if (p->use_rigidity) LAUNCH_BAND(true, true); else LAUNCH_BAND(true, false); }
+                    else { if (p->use_rigidity) LAUNCH_BAND(false, true); else LAUNCH_BAND(false, false); }
+#undef LAUNCH_BAND
+                } else {
+                    hipLaunchKernelGGL(k_band_update, dim3(n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, leftright_next);
+                }
             } else {
                 for (auto *c : b->cs) HIPCK(hipMemsetAsync(c->flags, 0, sizeof(int32_t), b->stream));
             }

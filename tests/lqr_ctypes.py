@@ -15,6 +15,11 @@ import os
 
 import numpy as np
 
+try:        # if torch is going to be used in this process, its bundled HIP runtime must load first
+    import torch  # noqa: F401
+except Exception:      # the engine does not need torch
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ENGINE_LIB = os.path.join(ROOT, "gimp-lqr-plugin_amd", "liblqr-hip.so")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "liblqr_oracle.so")
