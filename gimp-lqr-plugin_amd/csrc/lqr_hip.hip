@@ -335,18 +335,22 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sweep(const DevCarver *cs, Dp
 
 // ---------------------------------------------------------------------------
 // E7 build_vpath: argmin of the last row of m with liblqr's tie rule, then the
-// backtrack through the back-pointer plane.  One workgroup per image.  The
-// backtrack stages a (2*R*delta+1) x R window of back-pointers in LDS per
-// chunk of R rows so that the H-step pointer chase never waits on HBM.
+// backtrack through the back-pointer plane.  One workgroup per image finds the
+// argmin; wave 0 then walks the H-step pointer chase entirely in registers:
+// rows are taken in chunks of R (R*delta <= 62); lane L holds, for each row of the
+// chunk, the 4 back-pointer bytes of columns xa+4L..xa+4L+3 of a 256-column window
+// (one coalesced 256-byte load per row), and a chase step is v_readlane + a few
+// scalar ops -- no memory or LDS on the dependency chain.  The next chunk starts
+// within +-R*delta of this chunk's start column, so its (256-wide) window can be
+// loaded into a second register set before this chunk's chase has finished.
 // ---------------------------------------------------------------------------
+#define VP_ROWS 62
 __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, int w, int h, int stride, int lr, int delta,
                                                           int log_index)
 {
     const GCarver c = gview(cs[blockIdx.x]);
     __shared__ float s_val[VPATH_THREADS];
     __shared__ int s_idx[VPATH_THREADS];
-    __shared__ int s_x;
-    __shared__ int8_t tile[64 * 132];
     const int tid = threadIdx.x;
 
     // ---- argmin over the last row: leftmost (lr=0) / rightmost (lr=1) of equals
@@ -373,49 +377,62 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
         }
         __syncthreads();
     }
-    if (tid == 0) {
+    if (tid >= 64) return;                       // the chase is one wave
+    int x;
+    {
         // liblqr starts from m = 2^29: a candidate must beat it (or tie it when lr == 1)
         const float lim = 536870912.0f;
         float v = s_val[0]; int i = s_idx[0];
         bool ok = (i >= 0) && (v < lim || (v == lim && lr));
-        s_x = ok ? i : 0;
+        x = __builtin_amdgcn_readfirstlane(ok ? i : 0);
     }
-    __syncthreads();
 
     // ---- backtrack
+    const int lane = tid;
     gi32 *seam = c.seam_x;
     gi32 *logp = c.seam_log + (size_t) log_index * h;
-    const int R = delta > 0 ? max(1, 64 / delta) : 64;      // rows per chunk, R*delta <= 64
-    const int half = (R > 64 ? 64 : R) * delta;
-    const int rows_per_chunk = R > 64 ? 64 : R;
-    const int tw = 2 * half + 1;                              // <= 129
+    const int R = delta > 0 ? min(VP_ROWS, max(1, VP_ROWS / delta)) : VP_ROWS;   // rows per chunk, R*delta <= 62
+    uint32_t regs[2][VP_ROWS];
+    // window of the chunk whose top row is y_top, for a start column within +-R*delta of cx
+    auto window_base = [&](int cx) { return (cx - 126) & ~3; };
+    auto load_chunk = [&](int b, int y_top, int xa) {
+        const int xl = xa + 4 * lane;
+        const bool ok = (xl >= 0) && (xl + 3 < stride);
+#pragma unroll
+        for (int r = 0; r < VP_ROWS; r++) {
+            const int y = max(y_top - r, 0);
+            regs[b][r] = ok ? *(const gu32 *) (c.least + (size_t) y * stride + xl) : 0u;
+        }
+    };
     int y_top = h - 1;
+    int xa_cur = window_base(x);
+    if (y_top >= 1) load_chunk(0, y_top, xa_cur);
     while (y_top >= 1) {
-        const int x0 = s_x;
-        const int nrows = min(rows_per_chunk, y_top);         // rows y_top .. y_top-nrows+1 (all >= 1)
-        for (int i = tid; i < nrows * tw; i += VPATH_THREADS) {
-            int r = i / tw, col = i - r * tw;
-            int x = x0 - half + col, y = y_top - r;
-            int8_t d = 0;
-            if (x >= 0 && x < w) d = c.least[(size_t) y * stride + x];
-            tile[r * 132 + col] = d;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int x = x0;
-            for (int r = 0; r < nrows; r++) {
-                int y = y_top - r;
-                seam[y] = x; logp[y] = x;
-                int d = tile[r * 132 + (x - x0 + half)];
-                if (d == LEAST_INVALID) d = 0;
-                x += d;
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            if (y_top >= 1) {
+                const int nrows = min(R, y_top);
+                const int xa_next = window_base(x);
+                if (y_top - nrows >= 1) load_chunk(b ^ 1, y_top - nrows, xa_next);     // in flight during the chase
+                int path = 0;
+#pragma unroll
+                for (int r = 0; r < VP_ROWS; r++) {
+                    if (r < nrows) {
+                        path = (lane == r) ? x : path;                                    // lane r <- column at row y_top - r
+                        const int o = x - xa_cur;
+                        const uint32_t dw = (uint32_t) __builtin_amdgcn_readlane((int) regs[b][r], o >> 2);
+                        int d = (int) (int8_t) (dw >> (8 * (o & 3)));
+                        d = (d == LEAST_INVALID) ? 0 : d;
+                        x += d;
+                    }
+                }
+                if (lane < nrows) { seam[y_top - lane] = path; logp[y_top - lane] = path; }
+                xa_cur = xa_next;
+                y_top -= nrows;
             }
-            s_x = x;
         }
-        __syncthreads();
-        y_top -= nrows;
     }
-    if (tid == 0) { seam[0] = s_x; logp[0] = s_x; }
+    if (lane == 0) { seam[0] = x; logp[0] = x; }
 }
 
 // ---------------------------------------------------------------------------
@@ -693,24 +710,42 @@ __global__ __launch_bounds__(64) void k_band_update(const DevCarver *cs, DpK p, 
 
 // ---------------------------------------------------------------------------
 // E9 update_mmap, band form, delta_x == 1 fast path (the plug-in default).
-// One workgroup of NW waves per image.  The window is NW slots of 64*PXL px; wave
-// v owns slot v and lane L the PXL consecutive pixels x = B + 64*PXL*v + PXL*L.
-// The 3-neighbour window of the previous row lives in registers (inside a lane
-// directly, across lanes through DPP wave shifts, across waves through two LDS
-// words per wave), so the per-row dependency chain is VALU + one s_barrier; only
-// the waves whose slot the band reaches do any arithmetic.  Rows are prefetched
-// in batches of R rows into a register ping-pong (loads for the next batch are in
-// flight while this batch is processed), so the H-step chain does not stall on HBM.
-// The band shrink (leading / trailing run of "stop" pixels) is an LDS min/max.
-// Seam positions (for the changed-energy intervals) are staged in LDS once.
+//
+// liblqr walks a band [x_min, x_max] down the image and applies, to every pixel
+// of the band, "recompute (best parent, m); keep the stale m if the parent is
+// the same and |dm| < 1e-5".  Applied to a pixel whose inputs did not change the
+// rule is a no-op, so any superset of the pixels with changed inputs leaves the
+// same memory contents.  This kernel therefore needs no global
+// band bookkeeping: a 64*PXL-pixel slot is recomputed on row y iff something
+// in it (or the pixel beside it) changed on row y-1, or the carve touched it
+// (changed energy / re-based parents next to the seam).
+//
+// One workgroup of NW waves per image; wave v owns slot v of a window of NW
+// slots and lane L the PXL consecutive pixels x = B + 64*PXL*v + PXL*L.  The
+// 3-neighbour window of the previous row lives in registers (inside a lane
+// directly, across lanes by DPP wave shifts, across waves through one 16-byte LDS
+// record per wave), so a row costs the active waves ~100 instructions and all
+// waves one s_barrier.  Rows are prefetched in batches of R rows into a register
+// ping-pong (the next batch is in flight while this one is processed).  The window
+// follows the seam: it is re-centred at batch boundaries when the dirty slots or
+// the seam come within one slot of its ends; if the dirty region is wider than
+// the window the kernel records the row in flags[FLAG_OVF_ROW] and the full-width
+// sweep (k_dp_sweep<UPDATE>) finishes from there with identical results.
 // ---------------------------------------------------------------------------
 #define DPP_WAVE_SHL1 0x130
 #define DPP_WAVE_SHR1 0x138
 
 template <int PXL> struct PxVec;
-template <> struct PxVec<1> { typedef float F; typedef uint8_t L; };
+template <> struct PxVec<1> { typedef float F __attribute__((ext_vector_type(1))); typedef uint8_t L; };
 template <> struct PxVec<2> { typedef float F __attribute__((ext_vector_type(2))); typedef uint16_t L; };
 template <> struct PxVec<4> { typedef f32x4 F; typedef uint32_t L; };
+
+struct BandEdge {          // what a wave publishes about the row it just finished
+    float first_val;       // m of its first pixel (lane 0)
+    float last_val;        // m of its last pixel (lane 63)
+    int flags;             // bit0: first pixel changed, bit1: last pixel changed, bit2: anything changed
+    int pad;
+};
 
 template <int PXL, int NW, int R, bool LR, bool RIG>
 __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs, DpK p, int w, int h, int stride)
@@ -720,72 +755,84 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
     typedef GLOBAL_AS FV GFV;
     typedef GLOBAL_AS LV GLV;
     const GCarver c = gview(cs[blockIdx.x]);
-    extern __shared__ int s_seam[];                   // [h]
-    __shared__ float s_edge[2][NW][2];                // [row parity][wave]{first px of lane 0, last px of lane 63}
-    __shared__ int s_first[3], s_last[3];             // [row % 3] first / last changed pixel of the row
+    extern __shared__ int s_touch[];                  // [h] packed (t0 | t1 << 16): pixels the carve touched on row y
+    __shared__ __attribute__((aligned(16))) BandEdge s_edge[2][NW + 2];     // [row parity][wave + 1], sentinels at both ends
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float INF = __int_as_float(0x7f800000);
     constexpr int SLOT = 64 * PXL, WIN = SLOT * NW;
     const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
-    const int radius = p.radius;
 
-    for (int i = tid; i < h; i += 64 * NW) s_seam[i] = c.seam_x[i];
-    if (tid < 3) { s_first[tid] = 0x7fffffff; s_last[tid] = -1; }
-    __syncthreads();
-
-    // liblqr update_emap interval of row y (radius is 0 or 1)
-    auto interval = [&](int y, int &n0, int &n1) {
-        const int yy = min(y, h - 1);
-        const int v0 = s_seam[yy];
-        int lo = v0, hi = v0 - 1;
-        if (radius) {
-            const int vm = s_seam[max(yy - 1, 0)], vp = s_seam[min(yy + 1, h - 1)];
-            lo = min(min(v0, vm), vp) - 1;
-            hi = max(max(v0, vm), vp);
-        }
-        n0 = __builtin_amdgcn_readfirstlane(max(0, lo));
-        n1 = __builtin_amdgcn_readfirstlane(min(w - 1, hi));
-    };
-
-    int a, b;
-    {
-        int n0, n1;
-        interval(0, n0, n1);
-        a = max(n0, 0); b = min(n1, w - 1);
-        for (int x = a + tid; x <= b; x += 64 * NW) c.m[x] = c.en[x];      // row 0: m = en
+    // pixels of row y whose inputs the carve changed: energy (liblqr's update_emap interval)
+    // and parent sets next to the seam; a superset is fine
+    for (int y = tid; y < h; y += 64 * NW) {
+        const int v0 = c.seam_x[y], vm = c.seam_x[max(y - 1, 0)], vp = c.seam_x[min(y + 1, h - 1)];
+        const int t0 = max(min(min(v0, vm), vp) - 2, 0), t1 = min(max(max(v0, vm), vp) + 1, w - 1);
+        s_touch[y] = t0 | (t1 << 16);
     }
+    if (tid < 2 * (NW + 2)) {
+        BandEdge e; e.first_val = INF; e.last_val = INF; e.flags = 0; e.pad = 0;
+        s_edge[tid / (NW + 2)][tid % (NW + 2)] = e;
+    }
+    {   // row 0: m = en on liblqr's interval
+        const int v0 = c.seam_x[0], vp = c.seam_x[min(1, h - 1)];
+        int lo = v0, hi = v0 - 1;
+        if (p.radius) { lo = min(v0, vp) - 1; hi = max(v0, vp); }
+        const int a = max(lo, 0), b = min(hi, w - 1);
+        for (int x = a + tid; x <= b; x += 64 * NW) c.m[x] = c.en[x];
+    }
+    __syncthreads();
     if (h < 2) { if (tid == 0) c.flags[FLAG_OVF_ROW] = h; return; }
 
     const unsigned dummy = (unsigned) h * stride + PXL * tid;      // scratch row for lanes outside the image
     int y = 1, ovf = h;
-    int n0, n1;
-    interval(1, n0, n1);
+    int dirty_lo = -1, dirty_hi = -1;      // dirty slots of the last finished row, window-relative (-1: none)
+    int B = 0;
+    bool have_window = false;
     while (y < h) {
-        // ---- (re)base the window on the band of row y (identical decision in every wave)
-        const int na = max(min(a, n0) - 1, 0), nb = min(max(b, n1) + 1, w - 1);
-        if (nb - na + 1 > WIN - 2 * 70) { ovf = y; break; }
-        int B = (((na + nb) >> 1) - WIN / 2) & ~3;
-        B = max(0, min(B, (w - WIN + 3) & ~3));
-        B = __builtin_amdgcn_readfirstlane(B);
-
+        // ---- (re)base the window (identical decision in every wave)
+        {
+            const int t = s_touch[y];
+            int lo = t & 0xffff, hi = t >> 16;                       // absolute pixel range that must be inside
+            if (have_window && dirty_lo >= 0) { lo = min(lo, B + SLOT * dirty_lo - 1); hi = max(hi, B + SLOT * (dirty_hi + 1)); }
+            lo = max(lo, 0); hi = min(hi, w - 1);
+            if (hi - lo + 1 > WIN - 2 * SLOT - 2 * (R + 2) && hi - lo + 1 < w) { ovf = y; break; }
+            int nb = (((lo + hi) >> 1) - WIN / 2) & ~3;
+            nb = max(0, min(nb, (w - WIN + 3) & ~3));
+            B = __builtin_amdgcn_readfirstlane(nb);
+            have_window = true;
+        }
         const int x0 = B + SLOT * wave + PXL * lane;          // first pixel of this lane
         const int sx0 = B + SLOT * wave;                      // first pixel of this wave's slot
         const unsigned lo_off = (unsigned) min(x0, stride - PXL);
         const bool in_img = x0 < w;
+        // pixels this lane may recompute: inside the image, and not the first / last pixel of a
+        // window that does not end at the image border (their outer neighbour is not in the window;
+        // the window is re-centred long before a change can reach them)
+        uint32_t okmask = 0;
+#pragma unroll
+        for (int k = 0; k < PXL; k++) {
+            const int x = x0 + k;
+            const bool ok = (x < w) && !(B > 0 && x == B) && !(B + WIN < w && x == B + WIN - 1);
+            okmask |= ok ? (1u << k) : 0u;
+        }
 
         // previous row: rows < y were stored by this workgroup -> make them visible, then load
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         float mp[PXL];
+        int par = 0;
         {
             gf32 *mrow = c.m + (size_t) (y - 1) * stride;
 #pragma unroll
             for (int k = 0; k < PXL; k++)
                 mp[k] = (x0 + k < w) ? __hip_atomic_load(mrow + x0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
-            if (lane == 0) s_edge[(y - 1) & 1][wave][0] = mp[0];
-            if (lane == 63) s_edge[(y - 1) & 1][wave][1] = mp[PXL - 1];
+            // after a re-base every slot is recomputed once (cheap, and trivially a superset); bit 2
+            // (really dirty) stays clear so that the window check below sees only real changes
+            if (lane == 0) { s_edge[par][wave + 1].first_val = mp[0]; s_edge[par][wave + 1].flags = 3; }
+            if (lane == 63) s_edge[par][wave + 1].last_val = mp[PXL - 1];
         }
+        int own_dirty = 1;
         __syncthreads();
 
         FV q_mo[2][R], q_e[2][R];
@@ -806,40 +853,46 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
 #pragma unroll
             for (int buf = 0; buf < 2; buf++) {
                 if (y < h && !rebase) {
-                    issue(buf ^ 1, y + R);            // next batch in flight while this one is processed
+                    // ---- batch boundary: does the window still hold the next R rows?
+                    {
+                        const BandEdge ef = s_edge[par][1], el = s_edge[par][NW];
+                        const int t = s_touch[y];
+                        const int t0 = (t & 0xffff) - (R + 2), t1 = (t >> 16) + (R + 2);
+                        const bool left_ok = (B == 0) || (!(ef.flags & 4) && t0 >= B + SLOT);
+                        const bool right_ok = (B + WIN >= w) || (!(el.flags & 4) && t1 < B + WIN - SLOT);
+                        rebase = !(left_ok && right_ok);
+                    }
+                    if (rebase) {
+                        // dirty slot range of the last finished row, for the re-centring
+                        int lo = -1, hi = -1;
+                        for (int v = 0; v < NW; v++)
+                            if (s_edge[par][v + 1].flags & 4) { if (lo < 0) lo = v; hi = v; }
+                        dirty_lo = __builtin_amdgcn_readfirstlane(lo);
+                        dirty_hi = __builtin_amdgcn_readfirstlane(hi);
+                    } else {
+                        issue(buf ^ 1, y + R);            // next batch in flight while this one is processed
 #pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        if (y < h && !rebase) {
-                            const int ra = max(min(a, n0) - 1, 0), rb = min(max(b, n1) + 1, w - 1);
-                            const bool fits = (ra - 1 >= B || B == 0) && (rb + 1 < B + WIN || B + WIN >= w);
-                            if (!fits) {
-                                rebase = true;
-                            } else {
-                                interval(y + 1, n0, n1);        // for the next row: off the dependency chain
-                                const unsigned span = (unsigned) (rb - ra);
-                                const int par = (y - 1) & 1;
+                        for (int r = 0; r < R; r++) {
+                            if (y < h) {
+                                // what the neighbours published about row y-1
+                                const BandEdge eL = s_edge[par][wave], eR = s_edge[par][wave + 2];
+                                const int t = s_touch[y];
+                                const bool touch = ((t & 0xffff) <= sx0 + SLOT - 1) && ((t >> 16) >= sx0);
+                                const bool active = own_dirty || (eL.flags & 2) || (eR.flags & 1) || touch;
                                 float mo[PXL], e[PXL], mc[PXL];
-                                uint32_t lo4 = (uint32_t) q_lo[buf][r];
-                                if (PXL == 1) { mo[0] = ((const float *) &q_mo[buf][r])[0]; e[0] = ((const float *) &q_e[buf][r])[0]; }
-                                else {
+                                const uint32_t lo4 = (uint32_t) q_lo[buf][r];
 #pragma unroll
-                                    for (int k = 0; k < PXL; k++) { mo[k] = q_mo[buf][r][k]; e[k] = q_e[buf][r][k]; }
-                                }
-                                uint32_t lnew = lo4;
+                                for (int k = 0; k < PXL; k++) { mo[k] = q_mo[buf][r][k]; e[k] = q_e[buf][r][k]; }
 #pragma unroll
                                 for (int k = 0; k < PXL; k++) mc[k] = (x0 + k < w) ? mo[k] : INF;
-                                if (sx0 <= rb + 1 && sx0 + SLOT - 1 >= ra - 1) {          // the band reaches this slot
-                                    // neighbours of the lane's first / last pixel come from the adjacent lane,
-                                    // or from the adjacent wave (LDS) for lanes 0 and 63
-                                    const float wl = (wave > 0) ? s_edge[par][wave > 0 ? wave - 1 : 0][1] : INF;
-                                    const float wr = (wave < NW - 1) ? s_edge[par][wave < NW - 1 ? wave + 1 : 0][0] : INF;
-                                    float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wl), __float_as_int(mp[PXL - 1]),
+                                int flags = 0;
+                                if (active) {
+                                    float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(eL.last_val), __float_as_int(mp[PXL - 1]),
                                                                                         DPP_WAVE_SHR1, 0xf, 0xf, false));
-                                    float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wr), __float_as_int(mp[0]),
+                                    float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(eR.first_val), __float_as_int(mp[0]),
                                                                                          DPP_WAVE_SHL1, 0xf, 0xf, false));
                                     left = (x0 == 0) ? INF : left;
-                                    uint32_t chg = 0;
-                                    lnew = 0;
+                                    uint32_t chg = 0, lnew = 0;
 #pragma unroll
                                     for (int k = 0; k < PXL; k++) {
                                         float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
@@ -855,45 +908,31 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
                                         const int lo_k = (int) (int8_t) (lo4 >> (8 * k));
                                         // (double) fabsf(d) < 1e-5  <=>  fabsf(d) <= 1e-5f (the largest float below 1e-5)
                                         const bool stop = (lo_k == bdx) & (fabsf(__fsub_rn(mo[k], nm)) <= 1e-5f);
-                                        const bool inband = (unsigned) (x0 + k - ra) <= span;
-                                        const bool ch = inband & !stop;
+                                        const bool ok = (okmask >> k) & 1;
+                                        const bool ch = ok & !stop;
                                         mc[k] = ch ? nm : mc[k];
-                                        const int outl = inband ? bdx : lo_k;
-                                        lnew |= ((uint32_t) outl & 0xffu) << (8 * k);
+                                        lnew |= ((uint32_t) (ok ? bdx : lo_k) & 0xffu) << (8 * k);
                                         chg |= ch ? (1u << k) : 0u;
                                     }
                                     const unsigned long long bal = __ballot(chg != 0);
-                                    if (bal) {
-                                        const int fl = __ffsll((long long) bal) - 1, ll = 63 - __clzll((long long) bal);
-                                        const uint32_t mf = (uint32_t) __builtin_amdgcn_readlane((int) chg, fl);
-                                        const uint32_t ml = (uint32_t) __builtin_amdgcn_readlane((int) chg, ll);
-                                        if (lane == 0) {
-                                            atomicMin(&s_first[y % 3], sx0 + PXL * fl + (__ffs((int) mf) - 1));
-                                            atomicMax(&s_last[y % 3], sx0 + PXL * ll + (31 - __clz((int) ml)));
-                                        }
-                                    }
-                                }
-                                if (lane == 0) s_edge[y & 1][wave][0] = mc[0];
-                                if (lane == 63) s_edge[y & 1][wave][1] = mc[PXL - 1];
-                                if (tid == 0) { s_first[(y + 1) % 3] = 0x7fffffff; s_last[(y + 1) % 3] = -1; }
-                                // unconditional stores; lanes outside the image hit a scratch row
-                                const unsigned so = in_img ? (unsigned) y * (unsigned) stride + (unsigned) x0 : dummy;
-                                FV t;
-                                if (PXL == 1) ((float *) &t)[0] = mc[0];
-                                else {
+                                    const int c0 = __builtin_amdgcn_readlane((int) chg, 0), c63 = __builtin_amdgcn_readlane((int) chg, 63);
+                                    flags = (c0 & 1) | (((c63 >> (PXL - 1)) & 1) << 1) | (bal ? 4 : 0);
+                                    // lanes outside the image write to a scratch row
+                                    const unsigned so = in_img ? (unsigned) y * (unsigned) stride + (unsigned) x0 : dummy;
+                                    FV tv;
 #pragma unroll
-                                    for (int k = 0; k < PXL; k++) t[k] = mc[k];
+                                    for (int k = 0; k < PXL; k++) tv[k] = mc[k];
+                                    *(GFV *) (c.m + so) = tv;
+                                    *(GLV *) (c.least + so) = (LV) lnew;
                                 }
-                                *(GFV *) (c.m + so) = t;
-                                *(GLV *) (c.least + so) = (LV) lnew;
+                                own_dirty = flags & 4;
+                                par ^= 1;
+                                if (lane == 0) { s_edge[par][wave + 1].first_val = mc[0]; s_edge[par][wave + 1].flags = flags; }
+                                if (lane == 63) s_edge[par][wave + 1].last_val = mc[PXL - 1];
 #pragma unroll
                                 for (int k = 0; k < PXL; k++) mp[k] = mc[k];
                                 // one barrier per row: LDS only (outstanding global loads/stores keep flying)
                                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                                const int first = s_first[y % 3], last = s_last[y % 3];
-                                // shrink the band: leading stops advance a, the trailing run of stops pulls b back
-                                a = __builtin_amdgcn_readfirstlane(first == 0x7fffffff ? rb + 1 : first);
-                                b = __builtin_amdgcn_readfirstlane(first == 0x7fffffff ? ra : ((last == rb) ? rb : last + 1));
                                 y++;
                             }
                         }
@@ -1416,6 +1455,7 @@ extern "C" int lqrhip_mmap_build(LqrHipBatch *b, const LqrHipDpParams *p, int w,
 }
 
 static int g_use_band = -1;
+static int g_band_variant = 0;
 
 extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
                                 int full_rebuild, int leftright_next)
@@ -1425,6 +1465,8 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     if (g_use_band < 0) {
         const char *e = getenv("LQRHIP_NO_BAND");       // debug switches: 1 = full-width updates only,
         g_use_band = (e && atoi(e) == 1) ? 0 : (e && atoi(e) == 2) ? 2 : 1;   // 2 = generic band kernel only
+        const char *v = getenv("LQRHIP_BAND_VARIANT");  // tuning experiments
+        g_band_variant = v ? atoi(v) : 0;
     }
     for (auto *c : b->cs)
         if (log_index >= c->log_cap) return LQRHIP_EARG;
@@ -1461,9 +1503,20 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
                 bool has_rigmask = false;
                 for (auto *c : b->cs) has_rigmask |= (c->rig != nullptr);
                 if (p->delta_x == 1 && !has_rigmask && g_use_band == 1 && (size_t) h * sizeof(int) <= 60 * 1024) {
-#define LAUNCH_BAND(LRV, RIGV) hipLaunchKernelGGL((k_band_update_mw<2, 8, 8, LRV, RIGV>), dim3(n), dim3(512), (size_t) h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride)
+#define LAUNCH_BAND_V(PX, NWV, RV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_mw<PX, NWV, RV, LRV, RIGV>), dim3(n), dim3(64 * NWV), (size_t) h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride)
+#define LAUNCH_BAND(LRV, RIGV)                                                          \
+    do {                                                                                \
+        if (g_band_variant == 1) LAUNCH_BAND_V(4, 4, 8, LRV, RIGV);                     \
+        else if (g_band_variant == 2) LAUNCH_BAND_V(1, 16, 8, LRV, RIGV);               \
+        else if (g_band_variant == 3) LAUNCH_BAND_V(4, 2, 8, LRV, RIGV);                \
+        else if (g_band_variant == 4) LAUNCH_BAND_V(2, 4, 8, LRV, RIGV);                \
+        else if (g_band_variant == 5) LAUNCH_BAND_V(2, 16, 8, LRV, RIGV);               \
+        else if (g_band_variant == 6) LAUNCH_BAND_V(4, 8, 8, LRV, RIGV);                \
+        else LAUNCH_BAND_V(2, 8, 8, LRV, RIGV);                                         \
+    } while (0)
                     if (leftright_next) { if (p->use_rigidity) LAUNCH_BAND(true, true); else LAUNCH_BAND(true, false); }
                     else { if (p->use_rigidity) LAUNCH_BAND(false, true); else LAUNCH_BAND(false, false); }
+#undef LAUNCH_BAND_V
 #undef LAUNCH_BAND
                 } else {
                     hipLaunchKernelGGL(k_band_update, dim3(n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, leftright_next);

@@ -778,6 +778,18 @@ static LqrRetVal update_mmap(LqrCarver *r)
             if (x == x_max && stop) x_max = x_stop;
         }
     }
+    if (g_debug_snapshot) {
+        /* consistency probe (debug only): every back-pointer must name a pixel that is still
+         * within delta_x of its child in the carved frame; g_stats[7] counts violations */
+        int x1, ok;
+        for (y = 1; y < r->h; y++)
+            for (x = 0; x < r->w; x++) {
+                ok = 0;
+                for (x1 = MAXI(x - r->delta_x, 0); x1 <= MINI(x + r->delta_x, r->w - 1); x1++)
+                    if (r->raw[y - 1][x1] == r->least[r->raw[y][x]]) ok = 1;
+                if (!ok) g_stats[7]++;
+            }
+    }
     return LQR_OK;
 }
 
