@@ -6,10 +6,10 @@
 One "step" = one pass of the hot path (lqr_carver_resize: energy -> DP -> seam
 pick/backtrack -> carve) over one batch of synthetic
 images that are already resident in HBM.  Default workload = config 4 of
-BASELINE.json sharded per GPU ("batch of 64 independent 4K RGBA images, 200
-seams each, sharded over 8 GPUs"): every rank carves its own 8 images of
-3840x2160 RGBA by 200 vertical seams, as one lock-step batch; no data-path
-collective (images are independent), weak scaling.  --workload single4k runs
+BASELINE.json ("batch of 64 independent 4K RGBA images, 200 seams each"): every
+rank carves its own batch of 64 images of 3840x2160 RGBA by 200 vertical seams as
+one lock-step batch (--images-per-gpu 8 gives the literal 64/8 shard); images are
+independent, so there is no data-path collective and scaling is weak.  --workload single4k runs
 config 3 (one 4K image, 500 vertical + 500 horizontal seams) instead.
 
 value = Mseams*px/s over ALL ranks = sum over phases (n_seams * W * H) * images
@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="batch4k", choices=["batch4k", "single4k", "fhd", "8k"])
-    ap.add_argument("--images-per-gpu", type=int, default=8)
+    ap.add_argument("--images-per-gpu", type=int, default=64)
     ap.add_argument("--seams", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")

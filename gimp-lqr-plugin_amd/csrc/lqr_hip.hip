@@ -1215,12 +1215,6 @@ extern "C" int lqrhip_carver_attach(LqrHipCarver *root, LqrHipCarver *aux)
     return 0;
 }
 
-extern "C" int lqrhip_carver_activate(LqrHipCarver *c)
-{
-    c->active = 1;      // working planes are allocated lazily by lqrhip_wk_init
-    return 0;
-}
-
 // (re)allocate the working planes for a w x h carved frame
 static int ensure_working(LqrHipCarver *c, int w, int h)
 {
@@ -1254,6 +1248,14 @@ static int ensure_log(LqrHipCarver *c, int n_seams, int h)
     c->log_cap = n_seams; c->log_h = h;
     if (c->batch) c->batch->dirty = true;
     return 0;
+}
+
+extern "C" int lqrhip_carver_activate(LqrHipCarver *c)
+{
+    c->active = 1;
+    // E1 lqr_carver_init allocates the DP maps: do the same here, so that the first resize does
+    // not pay for hipMalloc (re-done lazily by lqrhip_wk_init if the geometry changes)
+    return ensure_working(c, c->w0, c->h0);
 }
 
 extern "C" int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int channels, int width, int height, int x_off,

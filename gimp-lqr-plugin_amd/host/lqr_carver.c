@@ -89,10 +89,14 @@ struct _LqrCarver {
     int *dbg_least, dbg_w, dbg_h;
 };
 
+#define MAX_SUB 8
 typedef struct {
     LqrCarver **r;
     int n;
-    LqrHipBatch *b;
+    /* the group's carvers are split over nb device batches (one HIP stream each): the per-image
+     * dependency chains of one sub-batch overlap with the bandwidth-bound carve of another */
+    LqrHipBatch *b[MAX_SUB];
+    int nb;
 } Group;
 
 static int g_debug_snapshot = 0;
@@ -279,35 +283,66 @@ static void set_width_tree(LqrCarver *r, int w1)
     for (l = r->attached; l; l = l->next) set_width_tree(l->current, w1);
 }
 
+static int sub_batches_for(int n)
+{
+    /* measured on MI355X (64 x 4K): 1 stream 157-175k, 2 streams 177k, 4 streams 130k Mseams*px/s --
+     * the chain kernels slow down under the carve's HBM load as much as the overlap gains, so the
+     * default is one batch; LQRHIP_SUBBATCHES overrides */
+    const char *e = getenv("LQRHIP_SUBBATCHES");
+    int nb = e ? atoi(e) : 1;
+    if (nb < 1) nb = 1;
+    if (nb > MAX_SUB) nb = MAX_SUB;
+    if (nb > n) nb = n;
+    return nb;
+}
+
 static LqrRetVal group_open(Group *g, LqrCarver **rs, int n)
 {
-    g->r = rs; g->n = n; g->b = NULL;
+    int i, k;
+    g->r = rs; g->n = n; g->nb = 0;
+    for (k = 0; k < MAX_SUB; k++) g->b[k] = NULL;
     if (n == 1) {
         if (!rs[0]->own_batch) {
             LqrHipCarver *d = rs[0]->dev;
             rs[0]->own_batch = lqrhip_batch_create(&d, 1);
             if (!rs[0]->own_batch) return LQR_NOMEM;
         }
-        g->b = rs[0]->own_batch;
+        g->b[0] = rs[0]->own_batch;
+        g->nb = 1;
     } else {
         LqrHipCarver **ds = (LqrHipCarver **) malloc((size_t) n * sizeof *ds);
-        int i;
+        int nb = sub_batches_for(n);
         if (!ds) return LQR_NOMEM;
         for (i = 0; i < n; i++) {
             if (rs[i]->own_batch) { lqrhip_batch_destroy(rs[i]->own_batch); rs[i]->own_batch = NULL; }
             ds[i] = rs[i]->dev;
         }
-        g->b = lqrhip_batch_create(ds, n);
+        for (k = 0; k < nb; k++) {
+            int lo = (int) ((long long) n * k / nb), hi = (int) ((long long) n * (k + 1) / nb);
+            g->b[k] = lqrhip_batch_create(ds + lo, hi - lo);
+            if (!g->b[k]) { free(ds); return LQR_NOMEM; }
+            g->nb = k + 1;
+        }
         free(ds);
-        if (!g->b) return LQR_NOMEM;
     }
     return LQR_OK;
 }
 static void group_close(Group *g)
 {
-    if (g->n > 1 && g->b) lqrhip_batch_destroy(g->b);
-    g->b = NULL;
+    int k;
+    if (g->n > 1)
+        for (k = 0; k < g->nb; k++) lqrhip_batch_destroy(g->b[k]);
+    g->nb = 0;
 }
+/* the same device call on every sub-batch */
+#define HIP_ALL(g, call)                                                   \
+    do {                                                                   \
+        int k__;                                                           \
+        for (k__ = 0; k__ < (g)->nb; k__++) {                              \
+            LqrHipBatch *B = (g)->b[k__];                                  \
+            HIP_CATCH(call);                                               \
+        }                                                                  \
+    } while (0)
 
 #define FOR_TREE(g, i, r, body)                                   \
     for (i = 0; i < (g)->n; i++) {                                \
@@ -338,7 +373,7 @@ static LqrRetVal group_flatten(Group *g)
     int i;
     /* a carver that is already flat (nothing hidden, nothing inserted) is its own flattening */
     if (!(r0->w == r0->w0 && r0->level == 1 && r0->max_level == 1 && r0->w_start == r0->w0))
-        HIP_CATCH(lqrhip_flatten(g->b, r0->w0, r0->h0, r0->w, r0->level));
+        HIP_ALL(g, lqrhip_flatten(B, r0->w0, r0->h0, r0->w, r0->level));
     else if (r0->wk_valid)
         return LQR_OK;
     FOR_TREE(g, i, r, {
@@ -355,7 +390,7 @@ static LqrRetVal group_transpose(Group *g)
     LqrCarver *r0 = g->r[0];
     int i, x, d;
     if (r0->level > 1 || r0->max_level > 1 || r0->w0 != r0->w) LQR_CATCH(group_flatten(g));
-    HIP_CATCH(lqrhip_transpose(g->b, r0->w0, r0->h0));
+    HIP_ALL(g, lqrhip_transpose(B, r0->w0, r0->h0));
     FOR_TREE(g, i, r, {
         d = r->w0; r->w0 = r->h0; r->h0 = d;
         r->w = r->w0; r->h = r->h0;
@@ -436,14 +471,14 @@ static LqrRetVal group_build_vsmap(Group *g, int depth)
     /* "frequency" = number of side switches per rescale operation */
     if (r0->lr_switch_frequency) lr_switch_interval = (depth - r0->max_level - 1) / r0->lr_switch_frequency + 1;
     dp_params(r0, &p);
-    HIP_CATCH(lqrhip_seam_log_reserve(g->b, n_seams, r0->h));
+    HIP_ALL(g, lqrhip_seam_log_reserve(B, n_seams, r0->h));
 
     for (l = r0->max_level; l < depth; l++) {
         int full = 0, lr_pick = r0->leftright, w_before = r0->w;
         if ((l - r0->max_level + r0->session_rescale_current) % r0->session_update_step == 0 && r0->progress &&
             r0->progress->update) {
             /* report completed work, not enqueued work */
-            HIP_CATCH(lqrhip_batch_sync(g->b));
+            HIP_ALL(g, lqrhip_batch_sync(B));
             r0->progress->update((gdouble) (l - r0->max_level + r0->session_rescale_current) /
                                  (gdouble) r0->session_rescale_total);
         }
@@ -455,16 +490,16 @@ static LqrRetVal group_build_vsmap(Group *g, int depth)
         } else {
             finish = 1;
         }
-        HIP_CATCH(lqrhip_seam_step(g->b, &p, w_before, r0->h, l - r0->max_level, lr_pick, full, r0->leftright));
+        HIP_ALL(g, lqrhip_seam_step(B, &p, w_before, r0->h, l - r0->max_level, lr_pick, full, r0->leftright));
         for (i = 0; i < g->n; i++) { g->r[i]->level++; g->r[i]->w--; }
     }
 
     if (g_debug_snapshot)
         for (i = 0; i < g->n; i++) LQR_CATCH(take_debug_snapshot(g->r[i]));
 
-    HIP_CATCH(lqrhip_vs_commit(g->b, r0->w0, r0->h0, wc0, n_seams, first_level, finish));
+    HIP_ALL(g, lqrhip_vs_commit(B, r0->w0, r0->h0, wc0, n_seams, first_level, finish));
     /* inflate (E14): every seam of this session is doubled in the base layout */
-    HIP_CATCH(lqrhip_inflate(g->b, r0->w0, r0->h0, depth - 1, r0->max_level));
+    HIP_ALL(g, lqrhip_inflate(B, r0->w0, r0->h0, depth - 1, r0->max_level));
     w1 = r0->w0 + (depth - 1) - r0->max_level + 1;
     FOR_TREE(g, i, r, {
         r->level = depth; r->max_level = depth;
@@ -484,12 +519,12 @@ static LqrRetVal group_build_maps(Group *g, int depth)
     for (i = 0; i < g->n; i++) set_width_one(g->r[i], g->r[i]->w_start - g->r[i]->max_level + 1);    /* the carved frame */
     if (!r0->wk_valid) {
         if (r0->max_level != 1 || r0->w0 != r0->w_start) return LQR_ERROR;     /* working planes lost on a non-flat carver */
-        HIP_CATCH(lqrhip_wk_init(g->b));
+        HIP_ALL(g, lqrhip_wk_init(B));
         for (i = 0; i < g->n; i++) g->r[i]->wk_valid = 1;
     }
     dp_params(r0, &p);
-    HIP_CATCH(lqrhip_emap_build(g->b, &p, r0->w, r0->h));
-    HIP_CATCH(lqrhip_mmap_build(g->b, &p, r0->w, r0->h, r0->leftright));
+    HIP_ALL(g, lqrhip_emap_build(B, &p, r0->w, r0->h));
+    HIP_ALL(g, lqrhip_mmap_build(B, &p, r0->w, r0->h, r0->leftright));
     return group_build_vsmap(g, depth);
 }
 
@@ -580,7 +615,7 @@ static LqrRetVal group_resize_dir(Group *g, int w1, int want_transposed)
         }
     }
     if (r->session_rescale_total && r->progress->end) {
-        HIP_CATCH(lqrhip_batch_sync(g->b));
+        HIP_ALL(g, lqrhip_batch_sync(B));
         r->progress->end(end_msg);
     }
     return LQR_OK;
@@ -615,7 +650,7 @@ static LqrRetVal group_resize(LqrCarver **rs, int n, int w1, int h1)
     } else {
         if ((ret = group_resize_dir(&g, h1, 1)) == LQR_OK) ret = group_resize_dir(&g, w1, 0);
     }
-    if (ret == LQR_OK) ret = hip_ret(lqrhip_batch_sync(g.b));
+    if (ret == LQR_OK) { int k; for (k = 0; k < g.nb && ret == LQR_OK; k++) ret = hip_ret(lqrhip_batch_sync(g.b[k])); }
     FOR_TREE(&g, i, r, { r->ro_valid = 0; r->ro_line = 0; });
     group_close(&g);
     return ret;
@@ -699,11 +734,11 @@ LqrRetVal lqrx_carver_get_energy(LqrCarver *r, gfloat *buffer)
     if (r->w != r->w_start - r->max_level + 1) ret = group_flatten(&g);
     if (ret == LQR_OK && !r->wk_valid) {
         if (r->max_level != 1 || r->w0 != r->w_start) ret = LQR_ERROR;
-        else if ((ret = hip_ret(lqrhip_wk_init(g.b))) == LQR_OK) r->wk_valid = 1;
+        else if ((ret = hip_ret(lqrhip_wk_init(g.b[0]))) == LQR_OK) r->wk_valid = 1;
     }
     if (ret == LQR_OK) {
         dp_params(r, &p);
-        ret = hip_ret(lqrhip_emap_build(g.b, &p, r->w, r->h));
+        ret = hip_ret(lqrhip_emap_build(g.b[0], &p, r->w, r->h));
     }
     if (ret == LQR_OK) ret = hip_ret(lqrhip_read_working(r->dev, r->w, r->h, buffer, NULL, NULL));
     group_close(&g);
