@@ -146,29 +146,34 @@ __device__ __forceinline__ double px_bright(uint32_t p, int ch, bool luma)
 // function (it returned an un-normalised channel value; scripts/dbg/t_energy2.hip
 // reproduces it), so every kernel that evaluates the energy is instantiated
 // once per energy function and the selector is resolved at launch.
-template <int NRG>
-__device__ __forceinline__ float grad_energy(const gu32 *pix, int stride, int x, int y, int w, int h, int ch)
+template <int NRG, class BF>
+__device__ __forceinline__ float grad_energy_f(BF B, int x, int y, int w, int h)
 {
     if (NRG == 6) return 0.0f;
-    constexpr bool luma = (NRG >= 3);
     constexpr int kind = NRG % 3;          // 0 norm, 1 sumabs, 2 xabs
-    const gu32 *row = pix + (size_t) y * stride;
     double gx, gy = 0.0;
     if (kind != 2) {
         if (h == 1) gy = 0.0;
-        else if (y == 0) gy = __dsub_rn(px_bright(row[stride + x], ch, luma), px_bright(row[x], ch, luma));
-        else if (y < h - 1) gy = __dmul_rn(__dsub_rn(px_bright(row[stride + x], ch, luma), px_bright(row[x - stride], ch, luma)), 0.5);
-        else gy = __dsub_rn(px_bright(row[x], ch, luma), px_bright(row[x - stride], ch, luma));
+        else if (y == 0) gy = __dsub_rn(B(x, 1), B(x, 0));
+        else if (y < h - 1) gy = __dmul_rn(__dsub_rn(B(x, y + 1), B(x, y - 1)), 0.5);
+        else gy = __dsub_rn(B(x, y), B(x, y - 1));
     }
     if (w == 1) gx = 0.0;
-    else if (x == 0) gx = __dsub_rn(px_bright(row[1], ch, luma), px_bright(row[0], ch, luma));
-    else if (x < w - 1) gx = __dmul_rn(__dsub_rn(px_bright(row[x + 1], ch, luma), px_bright(row[x - 1], ch, luma)), 0.5);
-    else gx = __dsub_rn(px_bright(row[x], ch, luma), px_bright(row[x - 1], ch, luma));
+    else if (x == 0) gx = __dsub_rn(B(1, y), B(0, y));
+    else if (x < w - 1) gx = __dmul_rn(__dsub_rn(B(x + 1, y), B(x - 1, y)), 0.5);
+    else gx = __dsub_rn(B(x, y), B(x - 1, y));
     double g;
     if (kind == 0) g = __dsqrt_rn(__dadd_rn(__dmul_rn(gx, gx), __dmul_rn(gy, gy)));
     else if (kind == 1) g = __dmul_rn(__dadd_rn(fabs(gx), fabs(gy)), 0.5);
     else g = fabs(gx);
     return __double2float_rn(g);
+}
+
+template <int NRG>
+__device__ __forceinline__ float grad_energy(const gu32 *pix, int stride, int x, int y, int w, int h, int ch)
+{
+    constexpr bool luma = (NRG >= 3);
+    return grad_energy_f<NRG>([&](int xx, int yy) { return px_bright(pix[(size_t) yy * stride + xx], ch, luma); }, x, y, w, h);
 }
 
 template <int NRG>
@@ -506,9 +511,9 @@ __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h
     const int v = c.seam_x[y];
     const int wnew = w - 1;
     size_t ro = (size_t) y * stride;
-    shift_row_u32(c.pix + ro, v, wnew, lane);
+    // pix and bias are NOT moved: they stay in the frame of `frozen epoch` and the energy
+    // update maps current coordinates back through the seam log (k_emap_update)
     shift_row_u32((gu32 *) (c.en + ro), v, wnew, lane);
-    if (c.bias) shift_row_u32((gu32 *) (c.bias + ro), v, wnew, lane);
     if (c.rig) shift_row_u32((gu32 *) (c.rig + ro), v, wnew, lane);
     if (move_dp) {
         shift_row_u32((gu32 *) (c.m + ro), v, wnew, lane);
@@ -531,16 +536,107 @@ __device__ __forceinline__ void nrg_interval(const gi32 *seam, int y, int h, int
     xmax = min(w - 1, hi);
 }
 
-// E6 update_emap: recompute en next to the carved seam (w = new width)
+// exclusive scan of 0/1 flags over a 256-thread block; returns rank, total via reference
+__device__ __forceinline__ int block_rank_256(bool flag, int *s_wave, int &total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long bal = __ballot(flag);
+    int r = __popcll(bal & ((1ull << lane) - 1ull));
+    __syncthreads();                 // protect s_wave reuse
+    if (lane == 0) s_wave[wv] = __popcll(bal);
+    __syncthreads();
+    int off = 0;
+    total = 0;
+    for (int i = 0; i < 4; i++) { int t = s_wave[i]; if (i < wv) off += t; total += t; }
+    return r + off;
+}
+
+// E6 update_emap: recompute en next to the carved seam (w = new width).
+// The packed-pixel (and bias) planes are frozen in the frame they had at seam `epoch`
+// of the session; current coordinates are mapped back by undoing seams k..epoch of the
+// row (p += (log[j] <= p)), which costs O(k - epoch) per pixel for ~10 pixels per row and
+// saves moving 4 (8 with bias) of the 13 bytes per pixel that a carve would otherwise move.
+#define EU_NT 12            // brightness samples per row tile
+#define EU_ROWS 62          // rows per block (+2 halo rows)
 template <int NRG>
-__global__ void k_emap_update(const DevCarver *cs, DpK p, int w, int h, int stride)
+__global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, int w, int h, int stride, int k, int epoch)
 {
     const GCarver c = gview(cs[blockIdx.y]);
-    int y = blockIdx.x * blockDim.x + threadIdx.x;
-    if (y >= h) return;
-    int xmin, xmax;
-    nrg_interval(c.seam_x, y, h, w, p.radius, xmin, xmax);
-    for (int x = xmin; x <= xmax; x++) c.en[(size_t) y * stride + x] = energy_at<NRG>(c, p, stride, x, y, w, h);
+    __shared__ double bt[64][EU_NT];
+    __shared__ float bb[64][EU_NT];
+    __shared__ int slo[64];
+    const int tid = threadIdx.x;
+    const int y = blockIdx.x * EU_ROWS + tid - 1;
+    const bool row_ok = (y >= 0 && y < h);
+    constexpr bool luma = (NRG >= 3);
+    int xmin = 0, xmax = -1, lo = 0;
+    if (row_ok) {
+        nrg_interval(c.seam_x, y, h, w, p.radius, xmin, xmax);
+        // samples of this row that rows y-1, y, y+1 will ask for
+        int l = xmin - 1, r = xmax + 1;
+        if (y > 0) { int a, b; nrg_interval(c.seam_x, y - 1, h, w, p.radius, a, b); if (b >= a) { l = min(l, a); r = max(r, b); } }
+        if (y < h - 1) { int a, b; nrg_interval(c.seam_x, y + 1, h, w, p.radius, a, b); if (b >= a) { l = min(l, a); r = max(r, b); } }
+        lo = max(l, 0);
+        int pos[EU_NT];
+#pragma unroll
+        for (int i = 0; i < EU_NT; i++) pos[i] = lo + i;
+        const gi32 *lg = c.seam_log + y;
+        for (int j = k; j >= epoch; j--) {
+            const int v = lg[(size_t) j * h];
+#pragma unroll
+            for (int i = 0; i < EU_NT; i++) pos[i] += (v <= pos[i]) ? 1 : 0;
+        }
+        const int wf = w + (k - epoch) + 1;           // width of the frozen frame
+#pragma unroll
+        for (int i = 0; i < EU_NT; i++) {
+            const bool ok = (lo + i <= min(r, w - 1)) && pos[i] < wf;
+            const size_t o = (size_t) y * stride + (ok ? pos[i] : 0);
+            bt[tid][i] = ok ? px_bright(c.pix[o], p.ch, luma) : 0.0;
+            bb[tid][i] = (ok && c.bias) ? c.bias[o] : 0.0f;
+        }
+    }
+    slo[tid] = lo;
+    __syncthreads();
+    if (!row_ok || tid == 0 || tid == 63) return;
+    for (int x = xmin; x <= xmax; x++) {
+        float e = grad_energy_f<NRG>([&](int xx, int yy) { const int t = tid + (yy - y); return bt[t][xx - slo[t]]; }, x, y, w, h);
+        if (c.bias) e = __fadd_rn(e, __fdiv_rn(bb[tid][x - lo], (float) p.w_start));
+        c.en[(size_t) y * stride + x] = e;
+    }
+}
+
+// bring the frozen planes (pix, bias) forward: remove seams [from, to) of the session log from
+// every row; w_from = width of the frame the planes are in.  One block per row, in place.
+__global__ __launch_bounds__(256) void k_frozen_catchup(const DevCarver *cs, int from, int to, int w_from, int h, int stride)
+{
+    const GCarver c = gview(cs[blockIdx.y]);
+    extern __shared__ int smc[];
+    int *xs = smc;                                  // [to - from]
+    uint8_t *rem = (uint8_t *) (smc + (to - from));  // [w_from]
+    __shared__ int s_wave[4];
+    const int y = blockIdx.x, tid = threadIdx.x, n = to - from;
+    for (int i = tid; i < n; i += 256) xs[i] = c.seam_log[(size_t) (from + i) * h + y];
+    for (int i = tid; i < w_from; i += 256) rem[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        int pz = xs[i];
+        for (int j = i - 1; j >= 0; j--) if (xs[j] <= pz) pz++;
+        rem[pz] = 1;
+    }
+    __syncthreads();
+    gu32 *prow = c.pix + (size_t) y * stride;
+    gf32 *brow = c.bias ? c.bias + (size_t) y * stride : (gf32 *) nullptr;
+    int carry = 0;
+    for (int base = 0; base < w_from; base += 256) {
+        const int col = base + tid;
+        const bool keep = (col < w_from) && !rem[col];
+        const uint32_t v = (col < w_from) ? prow[col] : 0u;
+        const float bv = (brow && col < w_from) ? brow[col] : 0.0f;
+        int total;
+        const int rank = carry + block_rank_256(keep, s_wave, total);     // barriers inside: all reads of the chunk are done
+        if (keep) { prow[rank] = v; if (brow) brow[rank] = bv; }
+        carry += total;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -949,21 +1045,6 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
 // whole session), inflate (E14), flatten / read-out compaction (E11, E12),
 // transpose (E11)
 // ---------------------------------------------------------------------------
-// exclusive scan of 0/1 flags over a 256-thread block; returns rank, total via reference
-__device__ __forceinline__ int block_rank_256(bool flag, int *s_wave, int &total)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    unsigned long long bal = __ballot(flag);
-    int r = __popcll(bal & ((1ull << lane) - 1ull));
-    __syncthreads();                 // protect s_wave reuse
-    if (lane == 0) s_wave[wv] = __popcll(bal);
-    __syncthreads();
-    int off = 0;
-    total = 0;
-    for (int i = 0; i < 4; i++) { int t = s_wave[i]; if (i < wv) off += t; total += t; }
-    return r + off;
-}
-
 __global__ __launch_bounds__(256) void k_vs_commit(const DevCarver *cs, int w0, int h0, int wc0, int n_seams, int first_level,
                                                     int finish)
 {
@@ -1109,6 +1190,7 @@ struct LqrHipCarver {
     int8_t *least = nullptr;
     int32_t *seam_x = nullptr, *seam_log = nullptr, *flags = nullptr;
     int log_cap = 0, log_h = 0;
+    int frozen_epoch = 0;           // pix / bias are in the frame before seam `frozen_epoch` of the session
     LqrHipCarver *root = nullptr;
     std::vector<LqrHipCarver *> aux;
     LqrHipBatch *batch = nullptr;
@@ -1402,6 +1484,7 @@ extern "C" int lqrhip_wk_init(LqrHipBatch *b)
         if ((rc = ensure_working(c, w, h))) return rc;
     }
     if ((rc = batch_upload(b))) return rc;
+    for (auto *c : b->cs) c->frozen_epoch = 0;
     dim3 grid((c0->stride + 255) / 256, h, (unsigned) b->cs.size());
     hipLaunchKernelGGL(k_wk_init, grid, dim3(256), 0, b->stream, b->d_desc, w, h, c0->stride, c0->ch);
     HIPCK(hipGetLastError());
@@ -1456,6 +1539,23 @@ extern "C" int lqrhip_mmap_build(LqrHipBatch *b, const LqrHipDpParams *p, int w,
     return launch_dp<false>(b, make_dpk(p, b->cs[0]->ch), w, h, leftright);
 }
 
+#define FROZEN_LAG_MAX 128      // seams the frozen planes may lag behind before they are compacted
+
+// remove seams [epoch, to) from the frozen planes of every carver of the batch
+static int frozen_catchup(LqrHipBatch *b, int to, int w_at_to, int h)
+{
+    LqrHipCarver *c0 = b->cs[0];
+    const int from = c0->frozen_epoch;
+    if (to <= from) return 0;
+    const int w_from = w_at_to + (to - from);
+    size_t lds = (size_t) (to - from) * sizeof(int) + (size_t) w_from + 16;
+    hipLaunchKernelGGL(k_frozen_catchup, dim3(h, (unsigned) b->cs.size()), dim3(256), lds, b->stream, b->d_desc, from, to, w_from, h,
+                       c0->stride);
+    HIPCK(hipGetLastError());
+    for (auto *c : b->cs) c->frozen_epoch = to;
+    return 0;
+}
+
 static int g_use_band = -1;
 static int g_band_variant = 0;
 
@@ -1492,7 +1592,11 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     if (wnew > 1) {
         {
             ProfScope ps("emap_update", b->stream, 0);
-#define LAUNCH_EUPD(N) hipLaunchKernelGGL((k_emap_update<N>), dim3((h + 63) / 64, n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride)
+            if (log_index + 1 - c0->frozen_epoch > FROZEN_LAG_MAX) {
+                if ((rc = frozen_catchup(b, log_index + 1, wnew, h))) return rc;
+            }
+            const int epoch = c0->frozen_epoch;
+#define LAUNCH_EUPD(N) hipLaunchKernelGGL((k_emap_update<N>), dim3((h + EU_ROWS - 1) / EU_ROWS, n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, log_index, epoch)
             NRG_DISPATCH(p->nrg_func, LAUNCH_EUPD)
 #undef LAUNCH_EUPD
         }
@@ -1552,6 +1656,9 @@ extern "C" int lqrhip_vs_commit(LqrHipBatch *b, int w0, int h0, int wc0, int n_s
     hipLaunchKernelGGL(k_vs_commit, dim3(h0, (unsigned) b->cs.size()), dim3(256), lds, b->stream, b->d_desc, w0, h0, wc0, n_seams,
                        first_level, finish);
     HIPCK(hipGetLastError());
+    // the session is over: bring the frozen planes to the carved frame, the log restarts at 0
+    if ((rc = frozen_catchup(b, n_seams, wc0 - n_seams, h0))) return rc;
+    for (auto *c : b->cs) c->frozen_epoch = 0;
     return 0;
 }
 
