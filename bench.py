@@ -178,8 +178,16 @@ def main():
     roofline = None
     if c_n:
         achieved = c_bytes / (c_ms * 1e-3) / 1e9
+        # HBM traffic of k_carve per launch from the committed rocprofv3 PMC passes of this command
+        # (separate FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
+        # note), scaled from the profiled batch size to this run's; null if the profile is missing
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_k_carve.json")
+        if os.path.exists(pmc) and args.workload == "batch4k" and args.seams is None:
+            pj = json.load(open(pmc))
+            traffic = round((2 * pj["fetch_size_kb_mean"] + pj["write_size_kb_mean"]) * 1024 / pj["images_per_launch"] * nimg)
         roofline = {"bound": "hbm", "kernel": "k_carve", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 4), "traffic": None,
+                    "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                     "avg_launch_us": round(c_ms * 1e3 / c_n, 2), "launches": c_n,
                     "alg_bytes_per_launch": round(c_bytes / c_n)}
 

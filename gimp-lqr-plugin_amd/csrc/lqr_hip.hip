@@ -880,12 +880,19 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
     if (h < 2) { if (tid == 0) c.flags[FLAG_OVF_ROW] = h; return; }
 
     const unsigned dummy = (unsigned) h * stride + PXL * tid;      // scratch row for lanes outside the image
+#ifdef BAND_TIMING
+    long long t_bar = 0, t_rows = 0, t_act = 0, t_rebase = 0;
+    const long long t_start = __builtin_readcyclecounter();
+#endif
     int y = 1, ovf = h;
     int dirty_lo = -1, dirty_hi = -1;      // dirty slots of the last finished row, window-relative (-1: none)
     int B = 0;
     bool have_window = false;
     while (y < h) {
         // ---- (re)base the window (identical decision in every wave)
+#ifdef BAND_TIMING
+        t_rebase++;
+#endif
         {
             const int t = s_touch[y];
             int lo = t & 0xffff, hi = t >> 16;                       // absolute pixel range that must be inside
@@ -973,8 +980,9 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
                                 // what the neighbours published about row y-1
                                 const BandEdge eL = s_edge[par][wave], eR = s_edge[par][wave + 2];
                                 const int t = s_touch[y];
-                                const bool touch = ((t & 0xffff) <= sx0 + SLOT - 1) && ((t >> 16) >= sx0);
-                                const bool active = own_dirty || (eL.flags & 2) || (eR.flags & 1) || touch;
+                                // no short-circuit: all LDS reads of the row are issued together (one round trip)
+                                const int touch = (int) ((t & 0xffff) <= sx0 + SLOT - 1) & (int) ((t >> 16) >= sx0);
+                                const bool active = (own_dirty | (eL.flags & 2) | (eR.flags & 1) | touch) != 0;
                                 float mo[PXL], e[PXL], mc[PXL];
                                 const uint32_t lo4 = (uint32_t) q_lo[buf][r];
 #pragma unroll
@@ -988,38 +996,48 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
                                     float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(eR.first_val), __float_as_int(mp[0]),
                                                                                          DPP_WAVE_SHL1, 0xf, 0xf, false));
                                     left = (x0 == 0) ? INF : left;
-                                    uint32_t chg = 0, lnew = 0;
+                                    uint32_t lnew = 0;
+                                    unsigned long long any = 0ull, chg_first = 0ull, chg_last = 0ull;
 #pragma unroll
                                     for (int k = 0; k < PXL; k++) {
                                         float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
                                         const float cc = mp[k];
                                         float rr = (k == PXL - 1) ? right : mp[k < PXL - 1 ? k + 1 : 0];
                                         if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
-                                        // ascending scan, strict < (LR=0) or <= (LR=1); missing neighbours are +inf
+                                        // ascending scan with strict < (LR=0: the leftmost minimum wins) or <=
+                                        // (LR=1: the rightmost); missing neighbours are +inf.  Written as value
+                                        // selects only (no scalar mask arithmetic on the dependency chain).
                                         const float best = fminf(fminf(l, cc), rr);
                                         int bdx;
-                                        if (LR) bdx = (rr <= fminf(l, cc)) ? 1 : ((cc <= l) ? 0 : -1);
-                                        else bdx = ((l <= cc) & (l <= rr)) ? -1 : ((cc <= rr) ? 0 : 1);
+                                        if (LR) { bdx = (cc == best) ? 0 : -1; bdx = (rr == best) ? 1 : bdx; }
+                                        else { bdx = (cc == best) ? 0 : 1; bdx = (l == best) ? -1 : bdx; }
                                         const float nm = __fadd_rn(e[k], best);
                                         const int lo_k = (int) (int8_t) (lo4 >> (8 * k));
-                                        // (double) fabsf(d) < 1e-5  <=>  fabsf(d) <= 1e-5f (the largest float below 1e-5)
-                                        const bool stop = (lo_k == bdx) & (fabsf(__fsub_rn(mo[k], nm)) <= 1e-5f);
-                                        const bool ok = (okmask >> k) & 1;
-                                        const bool ch = ok & !stop;
+                                        // keep rule: same parent and (double) fabsf(d) < 1e-5, i.e. fabsf(d) <= 1e-5f
+                                        float d = fabsf(__fsub_rn(mo[k], nm));
+                                        d = (lo_k == bdx) ? d : INF;                 // parent changed: never "stop"
+                                        d = ((okmask >> k) & 1) ? d : 0.0f;          // pixel not ours to recompute: never changes
+                                        const bool ch = d > 1e-5f;
                                         mc[k] = ch ? nm : mc[k];
-                                        lnew |= ((uint32_t) (ok ? bdx : lo_k) & 0xffu) << (8 * k);
-                                        chg |= ch ? (1u << k) : 0u;
+                                        const int outl = ((okmask >> k) & 1) ? bdx : lo_k;
+                                        lnew |= ((uint32_t) outl & 0xffu) << (8 * k);
+                                        const unsigned long long bk = __ballot(ch);
+                                        any |= bk;
+                                        if (k == 0) chg_first = bk;
+                                        if (k == PXL - 1) chg_last = bk;
                                     }
-                                    const unsigned long long bal = __ballot(chg != 0);
-                                    const int c0 = __builtin_amdgcn_readlane((int) chg, 0), c63 = __builtin_amdgcn_readlane((int) chg, 63);
-                                    flags = (c0 & 1) | (((c63 >> (PXL - 1)) & 1) << 1) | (bal ? 4 : 0);
+                                    flags = (int) (chg_first & 1ull) | ((int) (chg_last >> 63) << 1) | (any ? 4 : 0);
                                     // lanes outside the image write to a scratch row
                                     const unsigned so = in_img ? (unsigned) y * (unsigned) stride + (unsigned) x0 : dummy;
                                     FV tv;
 #pragma unroll
                                     for (int k = 0; k < PXL; k++) tv[k] = mc[k];
+#ifndef BAND_NOSTORE
                                     *(GFV *) (c.m + so) = tv;
                                     *(GLV *) (c.least + so) = (LV) lnew;
+#else
+                                    if (y == 123456) { *(GFV *) (c.m + so) = tv; *(GLV *) (c.least + so) = (LV) lnew; }
+#endif
                                 }
                                 own_dirty = flags & 4;
                                 par ^= 1;
@@ -1028,7 +1046,14 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
 #pragma unroll
                                 for (int k = 0; k < PXL; k++) mp[k] = mc[k];
                                 // one barrier per row: LDS only (outstanding global loads/stores keep flying)
+#ifdef BAND_TIMING
+                                const long long tb0 = __builtin_readcyclecounter();
+#endif
                                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef BAND_TIMING
+                                const long long tb1 = __builtin_readcyclecounter();
+                                t_bar += tb1 - tb0; t_rows++; t_act += active ? 1 : 0;
+#endif
                                 y++;
                             }
                         }
@@ -1038,6 +1063,13 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
         }
     }
     if (tid == 0) c.flags[FLAG_OVF_ROW] = ovf;
+#ifdef BAND_TIMING
+    if (lane == 0 && blockIdx.x == 0) {
+        const long long t_end = __builtin_readcyclecounter();
+        printf("band wave %d: total %lld cyc, rows %lld, active rows %lld, in barrier %lld cyc (%.0f/row), rest %.0f/row, rebases %lld\n", wave,
+               t_end - t_start, t_rows, t_act, t_bar, (double) t_bar / t_rows, (double) (t_end - t_start - t_bar) / t_rows, t_rebase);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1618,6 +1650,7 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         else if (g_band_variant == 4) LAUNCH_BAND_V(2, 4, 8, LRV, RIGV);                \
         else if (g_band_variant == 5) LAUNCH_BAND_V(2, 16, 8, LRV, RIGV);               \
         else if (g_band_variant == 6) LAUNCH_BAND_V(4, 8, 8, LRV, RIGV);                \
+        else if (wnew > 4200) LAUNCH_BAND_V(2, 16, 8, LRV, RIGV);   /* 8K: dirty regions up to ~900 px */ \
         else LAUNCH_BAND_V(2, 8, 8, LRV, RIGV);                                         \
     } while (0)
                     if (leftright_next) { if (p->use_rigidity) LAUNCH_BAND(true, true); else LAUNCH_BAND(true, false); }
