@@ -109,7 +109,7 @@ def main():
         raise SystemExit("bench.py: no usable HIP device: %s" % lib.lqrhip_last_error().decode())
 
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:       # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))

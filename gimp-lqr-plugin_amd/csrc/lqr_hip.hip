@@ -881,7 +881,7 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
 
     const unsigned dummy = (unsigned) h * stride + PXL * tid;      // scratch row for lanes outside the image
 #ifdef BAND_TIMING
-    long long t_bar = 0, t_rows = 0, t_act = 0, t_rebase = 0;
+    long long t_bar = 0, t_rows = 0, t_act = 0, t_rebase = 0, t_p01 = 0, t_p12 = 0, t_p2b = 0;
     const long long t_start = __builtin_readcyclecounter();
 #endif
     int y = 1, ovf = h;
@@ -977,6 +977,9 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
 #pragma unroll
                         for (int r = 0; r < R; r++) {
                             if (y < h) {
+#ifdef BAND_TIMING
+                                const long long tp0 = __builtin_readcyclecounter();
+#endif
                                 // what the neighbours published about row y-1
                                 const BandEdge eL = s_edge[par][wave], eR = s_edge[par][wave + 2];
                                 const int t = s_touch[y];
@@ -990,6 +993,9 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
 #pragma unroll
                                 for (int k = 0; k < PXL; k++) mc[k] = (x0 + k < w) ? mo[k] : INF;
                                 int flags = 0;
+#ifdef BAND_TIMING
+                                const long long tp1 = __builtin_readcyclecounter() + (active ? 0 : 0);
+#endif
                                 if (active) {
                                     float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(eL.last_val), __float_as_int(mp[PXL - 1]),
                                                                                         DPP_WAVE_SHR1, 0xf, 0xf, false));
@@ -1039,6 +1045,9 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
                                     if (y == 123456) { *(GFV *) (c.m + so) = tv; *(GLV *) (c.least + so) = (LV) lnew; }
 #endif
                                 }
+#ifdef BAND_TIMING
+                                const long long tp2 = __builtin_readcyclecounter() + (flags & 0);
+#endif
                                 own_dirty = flags & 4;
                                 par ^= 1;
                                 if (lane == 0) { s_edge[par][wave + 1].first_val = mc[0]; s_edge[par][wave + 1].flags = flags; }
@@ -1048,6 +1057,7 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
                                 // one barrier per row: LDS only (outstanding global loads/stores keep flying)
 #ifdef BAND_TIMING
                                 const long long tb0 = __builtin_readcyclecounter();
+                                t_p01 += tp1 - tp0; t_p12 += tp2 - tp1; t_p2b += tb0 - tp2;
 #endif
                                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef BAND_TIMING
@@ -1066,8 +1076,10 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
 #ifdef BAND_TIMING
     if (lane == 0 && blockIdx.x == 0) {
         const long long t_end = __builtin_readcyclecounter();
-        printf("band wave %d: total %lld cyc, rows %lld, active rows %lld, in barrier %lld cyc (%.0f/row), rest %.0f/row, rebases %lld\n", wave,
-               t_end - t_start, t_rows, t_act, t_bar, (double) t_bar / t_rows, (double) (t_end - t_start - t_bar) / t_rows, t_rebase);
+        printf("band wave %d: total %lld cyc, rows %lld, active rows %lld, in barrier %.0f/row, rest %.0f/row: reads+decide %.0f, compute+store %.0f, publish %.0f, other %.0f; rebases %lld\n", wave,
+               t_end - t_start, t_rows, t_act, (double) t_bar / t_rows, (double) (t_end - t_start - t_bar) / t_rows,
+               (double) t_p01 / t_rows, (double) t_p12 / t_rows, (double) t_p2b / t_rows,
+               (double) (t_end - t_start - t_bar - t_p01 - t_p12 - t_p2b) / t_rows, t_rebase);
     }
 #endif
 }
@@ -1650,6 +1662,9 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         else if (g_band_variant == 4) LAUNCH_BAND_V(2, 4, 8, LRV, RIGV);                \
         else if (g_band_variant == 5) LAUNCH_BAND_V(2, 16, 8, LRV, RIGV);               \
         else if (g_band_variant == 6) LAUNCH_BAND_V(4, 8, 8, LRV, RIGV);                \
+        else if (g_band_variant == 7) LAUNCH_BAND_V(2, 8, 4, LRV, RIGV);                \
+        else if (g_band_variant == 8) LAUNCH_BAND_V(2, 8, 16, LRV, RIGV);               \
+        else if (g_band_variant == 9) LAUNCH_BAND_V(2, 8, 2, LRV, RIGV);                \
         else if (wnew > 4200) LAUNCH_BAND_V(2, 16, 8, LRV, RIGV);   /* 8K: dirty regions up to ~900 px */ \
         else LAUNCH_BAND_V(2, 8, 8, LRV, RIGV);                                         \
     } while (0)

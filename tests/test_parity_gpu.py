@@ -124,6 +124,13 @@ def test_wide_bands_overflow_the_window(oracle, engine):
     both(oracle, engine, D.photo_like(1800, 500, 62), 1740, 500)
 
 
+def test_long_sessions_cross_the_frozen_plane_lag(oracle, engine):
+    """more than 128 seams in one session: the frozen pixel/bias planes are compacted mid-session
+    (FROZEN_LAG_MAX) and the energy update maps coordinates through up to 128 log entries"""
+    both(oracle, engine, D.photo_like(900, 260, 63), 590, 260)
+    both(oracle, engine, D.noise(700, 200, 64), 380, 150, pres=D.ellipse_mask(700, 200), disc=D.band_mask(700, 200, 90, 190))
+
+
 def test_enlargement(oracle, engine):
     img = D.photo_like(120, 80, 70)
     both(oracle, engine, img, 150, 80)                     # one step
