@@ -1275,17 +1275,60 @@ extern "C" int lqrhip_init(void)
     return dev;
 }
 
+// Device allocations go through a small size-class cache: the carve path allocates and frees
+// image-sized planes for every inflate / flatten / read-out, and hipMalloc / hipFree (which
+// synchronises the device) would otherwise cost more than the kernels between them.  A block is
+// only returned to the cache after the stream that used it has been synchronised.
+static std::multimap<size_t, void *> g_pool_free;
+static std::map<void *, size_t> g_pool_size;
+static size_t g_pool_cached = 0;
+static const size_t POOL_MAX_CACHED = (size_t) 24 << 30;
+
+static int pool_alloc(void **p, size_t bytes)
+{
+    const size_t sz = (bytes + ((size_t) 1 << 20) - 1) & ~(((size_t) 1 << 20) - 1);      // 1 MiB classes
+    auto it = g_pool_free.find(sz);
+    if (it != g_pool_free.end()) {
+        *p = it->second;
+        g_pool_free.erase(it);
+        g_pool_cached -= sz;
+        return 0;
+    }
+    hipError_t e = hipMalloc(p, sz);
+    if (e == hipErrorOutOfMemory && !g_pool_free.empty()) {       // give the cache back and retry once
+        (void) hipGetLastError();
+        for (auto &kv : g_pool_free) { (void) hipFree(kv.second); g_pool_size.erase(kv.second); }
+        g_pool_free.clear();
+        g_pool_cached = 0;
+        e = hipMalloc(p, sz);
+    }
+    HIPCK(e);
+    g_pool_size[*p] = sz;
+    return 0;
+}
+static void pool_free(void *p)
+{
+    auto it = g_pool_size.find(p);
+    if (it == g_pool_size.end()) { (void) hipFree(p); return; }
+    if (g_pool_cached + it->second > POOL_MAX_CACHED) {
+        (void) hipFree(p);
+        g_pool_size.erase(it);
+        return;
+    }
+    g_pool_free.emplace(it->second, p);
+    g_pool_cached += it->second;
+}
+
 template <typename T>
 static int dmalloc(T **p, size_t n)
 {
     *p = nullptr;
-    HIPCK(hipMalloc((void **) p, (n ? n : 1) * sizeof(T)));
-    return 0;
+    return pool_alloc((void **) p, (n ? n : 1) * sizeof(T));
 }
 template <typename T>
 static void dfree(T *&p)
 {
-    if (p) (void) hipFree(p);
+    if (p) pool_free((void *) p);
     p = nullptr;
 }
 
@@ -1710,25 +1753,27 @@ extern "C" int lqrhip_vs_commit(LqrHipBatch *b, int w0, int h0, int wc0, int n_s
     return 0;
 }
 
-// inflate one carver (root or aux) reading `vs_old`; new vs only for roots
-static int inflate_one(LqrHipCarver *c, const int32_t *vs_old, int32_t *nvs, int w0, int h0, int w1, int l, int max_level,
-                       hipStream_t s)
+// E14: every carver of the batch (roots and their attached carvers) is inflated by one launch
+// each, all enqueued before a single synchronisation; planes are swapped afterwards
+struct InflateJob {
+    LqrHipCarver *c;
+    uint8_t *nrgb;
+    float *nbias, *nrig;
+};
+
+static int inflate_enqueue(LqrHipCarver *c, const int32_t *vs_old, int32_t *nvs, int w0, int h0, int w1, int l, int max_level,
+                           hipStream_t s, std::vector<InflateJob> &jobs)
 {
-    uint8_t *nrgb = nullptr;
-    float *nbias = nullptr, *nrig = nullptr;
+    InflateJob j{c, nullptr, nullptr, nullptr};
     int rc;
     size_t n1 = (size_t) w1 * h0;
-    if ((rc = dmalloc(&nrgb, n1 * c->ch))) return rc;
-    if (c->bias0 && (rc = dmalloc(&nbias, n1))) return rc;
-    if (c->rig0 && (rc = dmalloc(&nrig, n1))) return rc;
-    hipLaunchKernelGGL(k_inflate, dim3(h0), dim3(256), 0, s, c->rgb0, vs_old, c->bias0, c->rig0, nrgb, nvs, nbias, nrig, w0, w1,
+    if ((rc = dmalloc(&j.nrgb, n1 * c->ch))) return rc;
+    if (c->bias0 && (rc = dmalloc(&j.nbias, n1))) return rc;
+    if (c->rig0 && (rc = dmalloc(&j.nrig, n1))) return rc;
+    hipLaunchKernelGGL(k_inflate, dim3(h0), dim3(256), 0, s, c->rgb0, vs_old, c->bias0, c->rig0, j.nrgb, nvs, j.nbias, j.nrig, w0, w1,
                        c->ch, l, max_level);
     HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(s));
-    dfree(c->rgb0); c->rgb0 = nrgb;
-    if (nbias) { dfree(c->bias0); c->bias0 = nbias; }
-    if (nrig) { dfree(c->rig0); c->rig0 = nrig; }
-    c->w0 = w1;
+    jobs.push_back(j);
     return 0;
 }
 
@@ -1736,16 +1781,28 @@ extern "C" int lqrhip_inflate(LqrHipBatch *b, int w0, int h0, int l, int max_lev
 {
     int rc;
     const int w1 = w0 + l - max_level + 1;
-    HIPCK(hipStreamSynchronize(b->stream));
+    std::vector<InflateJob> jobs;
+    std::vector<int32_t *> new_vs;
     for (auto *c : b->cs) {
         int32_t *nvs = nullptr;
         if ((rc = dmalloc(&nvs, (size_t) w1 * h0))) return rc;
+        new_vs.push_back(nvs);
         for (auto *a : c->aux)
-            if ((rc = inflate_one(a, c->vs, nullptr, w0, h0, w1, l, max_level, b->stream))) return rc;
-        if ((rc = inflate_one(c, c->vs, nvs, w0, h0, w1, l, max_level, b->stream))) return rc;
+            if ((rc = inflate_enqueue(a, c->vs, nullptr, w0, h0, w1, l, max_level, b->stream, jobs))) return rc;
+        if ((rc = inflate_enqueue(c, c->vs, nvs, w0, h0, w1, l, max_level, b->stream, jobs))) return rc;
+    }
+    HIPCK(hipStreamSynchronize(b->stream));
+    for (auto &j : jobs) {
+        dfree(j.c->rgb0); j.c->rgb0 = j.nrgb;
+        if (j.nbias) { dfree(j.c->bias0); j.c->bias0 = j.nbias; }
+        if (j.nrig) { dfree(j.c->rig0); j.c->rig0 = j.nrig; }
+        j.c->w0 = w1;
+    }
+    size_t i = 0;
+    for (auto *c : b->cs) {
         dfree(c->vs);
-        c->vs = nvs;
-        for (auto *a : c->aux) a->vs = nvs;
+        c->vs = new_vs[i++];
+        for (auto *a : c->aux) a->vs = c->vs;
     }
     b->dirty = true;
     return 0;
@@ -1848,6 +1905,14 @@ extern "C" int lqrhip_read_visible_device(LqrHipCarver *c, int w0, int h0, int w
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(g_stream0));
     return 0;
+}
+
+extern "C" void lqrhip_pool_trim(void)
+{
+    (void) hipDeviceSynchronize();
+    for (auto &kv : g_pool_free) { (void) hipFree(kv.second); g_pool_size.erase(kv.second); }
+    g_pool_free.clear();
+    g_pool_cached = 0;
 }
 
 extern "C" int lqrhip_device_sync(void)

@@ -105,6 +105,8 @@ int lqrhip_read_visible(LqrHipCarver *c, int w0, int h0, int w, int level, unsig
 /* same, but into a caller-provided device buffer (no host round trip) */
 int lqrhip_read_visible_device(LqrHipCarver *c, int w0, int h0, int w, int level, void *device_out);
 int lqrhip_device_sync(void);
+/* return the cached (freed) device blocks of the shim's allocation cache to the driver */
+void lqrhip_pool_trim(void);
 /* E12 lqr_vmap_dump (render.c:725): vs of the pixels visible at `level`
  * minus `depth` (0 stays 0), w x h in carver orientation */
 int lqrhip_read_vmap(LqrHipCarver *c, int w0, int h0, int w, int level, int depth, int *out);
