@@ -26,6 +26,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include <map>
 
 #include "../../include/lqr_hip.h"
@@ -450,23 +451,31 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
 __device__ __forceinline__ void shift_row_u32(gu32 *row, int v, int wnew, int lane)
 {
     int base = v & ~3;
-    // 4 chunks of 256 px in flight: all loads of a group are issued before its stores
+    // 4 chunks of 256 px in flight: all loads of a group are issued before its stores.  The element
+    // that follows a lane's 4 pixels is the next lane's first one (DPP); only lane 63 of the last
+    // chunk of a group has to fetch it from memory.
     for (; base < wnew; base += 1024) {
-        u32x4 a[4]; uint32_t nx[4];
+        u32x4 a[4];
+        uint32_t tail = 0;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             int x = base + u * 256 + lane * 4;
-            if (x < wnew) { a[u] = *(const GLOBAL_AS u32x4 *) (row + x); nx[u] = row[x + 4]; }
+            // x <= wnew: the group that starts at wnew holds the old last pixel, which the lane before needs
+            a[u] = (x <= wnew) ? *(const GLOBAL_AS u32x4 *) (row + x) : (u32x4) {0u, 0u, 0u, 0u};
         }
+        if (lane == 63 && base + 1024 <= wnew) tail = row[base + 1024];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             int x = base + u * 256 + lane * 4;
+            const uint32_t first_next = (u < 3) ? (uint32_t) __builtin_amdgcn_readlane((int) a[u < 3 ? u + 1 : 3].x, 0) : 0u;
+            const uint32_t lane63 = (u < 3) ? first_next : tail;
+            const uint32_t nx = (uint32_t) __builtin_amdgcn_update_dpp((int) lane63, (int) a[u].x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
             if (x < wnew) {
                 u32x4 o;
                 o.x = (x >= v) ? a[u].y : a[u].x;
                 o.y = (x + 1 >= v) ? a[u].z : a[u].y;
                 o.z = (x + 2 >= v) ? a[u].w : a[u].z;
-                o.w = (x + 3 >= v) ? nx[u] : a[u].w;
+                o.w = (x + 3 >= v) ? nx : a[u].w;
                 *(GLOBAL_AS u32x4 *) (row + x) = o;
             }
         }
@@ -506,10 +515,11 @@ __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h
 {
     const GCarver c = gview(cs[blockIdx.y]);
     const int lane = threadIdx.x & 63;
-    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (y >= h) return;
-    const int v = c.seam_x[y];
     const int wnew = w - 1;
+    // grid-stride over rows: the grid can be kept small (a few waves per CU) so that the
+    // latency-bound chain kernels of another sub-batch find free wave slots next to it
+    for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < h; y += gridDim.x * 4) {
+    const int v = c.seam_x[y];
     size_t ro = (size_t) y * stride;
     // pix and bias are NOT moved: they stay in the frame of `frozen epoch` and the energy
     // update maps current coordinates back through the seam log (k_emap_update)
@@ -519,6 +529,7 @@ __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h
         shift_row_u32((gu32 *) (c.m + ro), v, wnew, lane);
         int vprev = y > 0 ? c.seam_x[y - 1] : 0;
         shift_row_least(c.least + ro, v, vprev, y, delta, wnew, lane);
+    }
     }
 }
 
@@ -1216,6 +1227,32 @@ __global__ void k_transpose(const uint8_t *rgb, const float *bias, const float *
     }
 }
 
+// auto-size (plug-in's guess_new_size, src/layers_combo.c:275-392): one block per line counts the
+// mask pixels at or above the threshold; atomicMax over lines
+__global__ __launch_bounds__(256) void k_mask_line_max(const uint8_t *mask, int channels, int width, int a0, int b0, int line_len,
+                                                       int direction, int *out)
+{
+    __shared__ int s_cnt[4];
+    const bool has_alpha = (channels == 2 || channels == 4);
+    const int c_bpp = channels - (has_alpha ? 1 : 0);
+    const int line = blockIdx.x;
+    int cnt = 0;
+    for (int z2 = threadIdx.x; z2 < line_len; z2 += 256) {
+        // direction 0: row a0+line, columns b0+z2;  direction 1: column a0+line, rows b0+z2
+        const size_t idx = direction == 0 ? (size_t) (a0 + line) * width + (b0 + z2) : (size_t) (b0 + z2) * width + (a0 + line);
+        const uint8_t *px = mask + idx * channels;
+        double sum = 0.0;
+        for (int c = 0; c < c_bpp; c++) sum = __dadd_rn(sum, (double) px[c]);
+        sum = __ddiv_rn(sum, (double) (255 * c_bpp));
+        if (has_alpha) sum = __dmul_rn(sum, __ddiv_rn((double) px[channels - 1], 255.0));
+        cnt += (sum >= __ddiv_rn(0.5, (double) c_bpp)) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+}
+
 // ===========================================================================
 // host side of the shim
 // ===========================================================================
@@ -1645,6 +1682,7 @@ static int frozen_catchup(LqrHipBatch *b, int to, int w_at_to, int h)
 
 static int g_use_band = -1;
 static int g_band_variant = 0;
+static int g_carve_wgs = 0;          // > 0: cap on the carve kernel's workgroups (LQRHIP_CARVE_WGS)
 
 extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
                                 int full_rebuild, int leftright_next)
@@ -1656,6 +1694,8 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         g_use_band = (e && atoi(e) == 1) ? 0 : (e && atoi(e) == 2) ? 2 : 1;   // 2 = generic band kernel only
         const char *v = getenv("LQRHIP_BAND_VARIANT");  // tuning experiments
         g_band_variant = v ? atoi(v) : 0;
+        const char *cw = getenv("LQRHIP_CARVE_WGS");
+        g_carve_wgs = cw ? atoi(cw) : 0;
     }
     for (auto *c : b->cs)
         if (log_index >= c->log_cap) return LQRHIP_EARG;
@@ -1674,7 +1714,9 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         // algorithmic bytes of one carve launch: read + write of one 4-byte
         // plane over the half of each row right of the seam = 8 B * w*h/2 per image
         ProfScope ps("carve", b->stream, 4.0 * (double) w * h * n);
-        hipLaunchKernelGGL(k_carve, dim3((h + 3) / 4, n), dim3(256), 0, b->stream, b->d_desc, w, h, stride, p->delta_x, move_dp);
+        int gx = (h + 3) / 4;
+        if (g_carve_wgs > 0) gx = std::max(1, std::min(gx, g_carve_wgs / (int) n));
+        hipLaunchKernelGGL(k_carve, dim3(gx, n), dim3(256), 0, b->stream, b->d_desc, w, h, stride, p->delta_x, move_dp);
     }
     if (wnew > 1) {
         {
@@ -1905,6 +1947,26 @@ extern "C" int lqrhip_read_visible_device(LqrHipCarver *c, int w0, int h0, int w
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(g_stream0));
     return 0;
+}
+
+extern "C" int lqrhip_mask_line_max(const unsigned char *mask, int channels, int width, int height, int a0, int b0, int n_lines,
+                                    int line_len, int direction)
+{
+    if (lqrhip_init() < 0) return LQRHIP_EHIP;
+    if (n_lines <= 0 || line_len <= 0) return 0;
+    uint8_t *d = nullptr;
+    int *dout = nullptr;
+    int rc, result = 0;
+    size_t bytes = (size_t) width * height * channels;
+    if ((rc = dmalloc(&d, bytes)) || (rc = dmalloc(&dout, 1))) return rc;
+    HIPCK(hipMemcpy(d, mask, bytes, hipMemcpyHostToDevice));
+    HIPCK(hipMemset(dout, 0, sizeof(int)));
+    hipLaunchKernelGGL(k_mask_line_max, dim3(n_lines), dim3(256), 0, g_stream0, d, channels, width, a0, b0, line_len, direction, dout);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(g_stream0));
+    HIPCK(hipMemcpy(&result, dout, sizeof(int), hipMemcpyDeviceToHost));
+    dfree(d); dfree(dout);
+    return result;
 }
 
 extern "C" void lqrhip_pool_trim(void)

@@ -723,6 +723,25 @@ LqrRetVal lqrx_carver_read_image_device(LqrCarver *r, void *device_ptr)
     return LQR_OK;
 }
 
+/* ======================= auto-size (plug-in side) ======================== */
+/* guess_new_size, reference src/layers_combo.c:275-392: the geometry is resolved here, the
+ * per-line counting and the max over lines run on the device */
+gint lqrx_guess_new_size(const guchar *mask, gint channels, gint width, gint height, gint x_off, gint y_off,
+                         gint old_width, gint old_height, gint direction)
+{
+    int lw = MINI(old_width, width + x_off) - MAXI(0, x_off);
+    int lh = MINI(old_height, height + y_off) - MAXI(0, y_off);
+    int old_size = direction ? old_height : old_width, m;
+    if (direction == 0)     /* lines are mask rows z1 - y_off, z1 in [max(0,y_off), min(old_h, h+y_off)) */
+        m = lqrhip_mask_line_max(mask, channels, width, height, MAXI(0, y_off) - y_off, MAXI(0, -x_off),
+                                 MINI(old_height, height + y_off) - MAXI(0, y_off), lw, 0);
+    else
+        m = lqrhip_mask_line_max(mask, channels, width, height, MAXI(0, x_off) - x_off, MAXI(0, -y_off),
+                                 MINI(old_width, width + x_off) - MAXI(0, x_off), lh, 1);
+    if (m < 0) { fprintf(stderr, "liblqr-hip: guess_new_size failed: %s\n", lqrhip_last_error()); return old_size; }
+    return old_size - m;
+}
+
 /* ======================= test hooks ====================================== */
 LqrRetVal lqrx_carver_get_energy(LqrCarver *r, gfloat *buffer)
 {

@@ -200,6 +200,13 @@ LqrRetVal lqrx_carver_read_image(LqrCarver *r, guchar *out);
  * image orientation unless lqr_carver_get_orientation() is 1): lets a batch
  * driver hand results to RCCL without a host round trip. */
 LqrRetVal lqrx_carver_read_image_device(LqrCarver *r, void *device_ptr);
+/* The plug-in's auto-size helper guess_new_size (src/layers_combo.c:275-392): the new size that
+ * would remove the discard mask = old size - max over lines of the number of mask pixels whose
+ * value (mean colour / 255, times alpha / 255) is >= 0.5 / colour_channels.  `direction` 0 = horizontal
+ * (count along rows), 1 = vertical (count along columns); the mask layer is width x height x
+ * channels at offset (x_off, y_off) relative to the old_width x old_height image. */
+gint lqrx_guess_new_size(const guchar *mask, gint channels, gint width, gint height, gint x_off, gint y_off,
+                         gint old_width, gint old_height, gint direction);
 /* Carve n independent carvers (same geometry and configuration) in lock-step;
  * equivalent to calling lqr_carver_resize on each.  The engine runs them as one
  * batched launch sequence (the per-frame batch axis). */

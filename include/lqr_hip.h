@@ -102,6 +102,10 @@ int lqrhip_transpose(LqrHipBatch *b, int w, int h);
 /* E12 scan_line source: the pixels visible at `level`, packed w x h x channels
  * in CARVER orientation (io_functions.c:155-164 then serves rows of it). */
 int lqrhip_read_visible(LqrHipCarver *c, int w0, int h0, int w, int level, unsigned char *out);
+/* guess_new_size (src/layers_combo.c:275-392): max over lines of the count of mask pixels at or
+ * above the threshold; returns the count (>= 0) or a negative error */
+int lqrhip_mask_line_max(const unsigned char *mask, int channels, int width, int height, int a0, int b0, int n_lines, int line_len,
+                         int direction);
 /* same, but into a caller-provided device buffer (no host round trip) */
 int lqrhip_read_visible_device(LqrHipCarver *c, int w0, int h0, int w, int level, void *device_out);
 int lqrhip_device_sync(void);

@@ -1139,6 +1139,34 @@ LqrRetVal lqrx_carver_read_image_device(LqrCarver *r, void *device_ptr)
     return LQR_OK;
 }
 
+/* ======================= auto-size (plug-in side) ======================== */
+/* restates guess_new_size, reference src/layers_combo.c:275-392 (this one IS in the tree) */
+gint lqrx_guess_new_size(const guchar *mask, gint channels, gint width, gint height, gint x_off, gint y_off,
+                         gint old_width, gint old_height, gint direction)
+{
+    int has_alpha = (channels == 2 || channels == 4), c_bpp = channels - (has_alpha ? 1 : 0);
+    int lw = MINI(old_width, width + x_off) - MAXI(0, x_off);
+    int lh = MINI(old_height, height + y_off) - MAXI(0, y_off);
+    int z1, z2, k, z1min, z1max, z2max, max_mask_size = 0, old_size = direction ? old_height : old_width;
+    if (direction == 0) { z1min = MAXI(0, y_off); z1max = MINI(old_height, height + y_off); z2max = lw; }
+    else { z1min = MAXI(0, x_off); z1max = MINI(old_width, width + x_off); z2max = lh; }
+    for (z1 = z1min; z1 < z1max; z1++) {
+        int mask_size = 0;
+        for (z2 = 0; z2 < z2max; z2++) {
+            const guchar *px = direction == 0
+                ? mask + ((size_t) (z1 - y_off) * width + (MAXI(0, -x_off) + z2)) * channels
+                : mask + ((size_t) (MAXI(0, -y_off) + z2) * width + (z1 - x_off)) * channels;
+            double sum = 0;
+            for (k = 0; k < c_bpp; k++) sum += px[k];
+            sum /= (255 * c_bpp);
+            if (has_alpha) sum *= (double) px[channels - 1] / 255;
+            if (sum >= (0.5 / c_bpp)) mask_size++;
+        }
+        if (mask_size > max_mask_size) max_mask_size = mask_size;
+    }
+    return old_size - max_mask_size;
+}
+
 /* ======================= test hooks ====================================== */
 LqrRetVal lqrx_carver_get_energy(LqrCarver *r, gfloat *buffer)
 {

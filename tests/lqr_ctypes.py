@@ -100,6 +100,7 @@ SYMBOLS = {
     "lqrx_carver_read_image": (_I, [_P, _P]),
     "lqrx_carver_resize_batch": (_I, [C.POINTER(_P), _I, _I, _I]),
     "lqrx_carver_read_image_device": (_I, [_P, _P]),
+    "lqrx_guess_new_size": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I]),
 }
 # liblqr-1 proper exports only the lqr_* part
 LIBLQR_SYMBOLS = [s for s in SYMBOLS if s.startswith("lqr_")]

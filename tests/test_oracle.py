@@ -274,3 +274,33 @@ def test_resize_to_width_one(oracle):
 def test_enum_order_is_abi():
     assert (L.LQR_ERROR, L.LQR_OK, L.LQR_NOMEM) == (0, 1, 2)
     assert L.LQR_EF_GRAD_XABS == 2 and L.LQR_EF_LUMA_GRAD_NORM == 3 and L.LQR_EF_NULL == 6
+
+
+def _py_guess(mask, x_off, y_off, ow, oh, direction):
+    """loop-level restatement of guess_new_size (src/layers_combo.c:275-392)"""
+    h, w, ch = mask.shape
+    has_alpha = ch in (2, 4)
+    cb = ch - (1 if has_alpha else 0)
+    best = 0
+    lines = range(max(0, y_off), min(oh, h + y_off)) if direction == 0 else range(max(0, x_off), min(ow, w + x_off))
+    n = (min(ow, w + x_off) - max(0, x_off)) if direction == 0 else (min(oh, h + y_off) - max(0, y_off))
+    for z1 in lines:
+        cnt = 0
+        for z2 in range(max(n, 0)):
+            px = mask[z1 - y_off, max(0, -x_off) + z2] if direction == 0 else mask[max(0, -y_off) + z2, z1 - x_off]
+            s = float(sum(int(v) for v in px[:cb])) / (255 * cb)
+            if has_alpha:
+                s *= float(px[ch - 1]) / 255
+            cnt += s >= 0.5 / cb
+        best = max(best, cnt)
+    return (oh if direction else ow) - best
+
+
+@pytest.mark.parametrize("ch,x_off,y_off", [(4, 0, 0), (4, -5, 3), (3, 7, -4), (2, 2, 2), (1, -3, -3)])
+def test_guess_new_size_matches_restatement(oracle, ch, x_off, y_off):
+    rng = np.random.default_rng(100 + ch + x_off)
+    mask = rng.integers(0, 256, size=(23, 31, ch), dtype=np.uint8)
+    mask[5:15, 8:20] = 255
+    for direction in (0, 1):
+        got = oracle.lqrx_guess_new_size(mask.ctypes.data, ch, 31, 23, x_off, y_off, 28, 20, direction)
+        assert got == _py_guess(mask, x_off, y_off, 28, 20, direction)

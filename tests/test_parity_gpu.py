@@ -231,3 +231,17 @@ def test_error_returns_match(oracle, engine):
         assert api.lqr_carver_attach(c.p, aux.p) == L.LQR_ERROR
         aux.destroy()
         c.destroy()
+
+
+@pytest.mark.parametrize("ch", [1, 2, 3, 4])
+def test_guess_new_size(oracle, engine, ch):
+    """the plug-in's auto-size mask scan (src/layers_combo.c:275-392)"""
+    rng = np.random.default_rng(ch)
+    for (mw, mh, x_off, y_off, ow, oh) in [(640, 400, 0, 0, 640, 400), (500, 300, -37, 21, 640, 400), (700, 450, 50, -60, 640, 400),
+                                           (64, 48, 600, 380, 640, 400), (10, 10, 700, 10, 640, 400)]:
+        mask = rng.integers(0, 256, size=(mh, mw, ch), dtype=np.uint8)
+        mask[mh // 4: mh // 2, mw // 3: 2 * mw // 3] = 255
+        for direction in (0, 1):
+            a = oracle.lqrx_guess_new_size(mask.ctypes.data, ch, mw, mh, x_off, y_off, ow, oh, direction)
+            b = engine.lqrx_guess_new_size(mask.ctypes.data, ch, mw, mh, x_off, y_off, ow, oh, direction)
+            assert a == b, (mw, mh, x_off, y_off, direction, a, b)
