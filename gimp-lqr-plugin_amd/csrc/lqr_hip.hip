@@ -58,6 +58,7 @@ struct DevCarver {
     int32_t *seam_x;
     int32_t *seam_log;
     int32_t *flags;
+    int32_t *progress;      // [ceil(h/64)] rows carved so far, cumulative over the seams since allocation
 };
 
 // Pointers fetched from a descriptor in memory are "generic" to the compiler, which then
@@ -81,7 +82,7 @@ struct GCarver {
     gf32 *en, *m;
     gi8 *least;
     gf32 *bias, *rig;
-    gi32 *seam_x, *seam_log, *flags;
+    gi32 *seam_x, *seam_log, *flags, *progress;
 };
 
 __device__ __forceinline__ GCarver gview(const DevCarver &d)
@@ -90,7 +91,7 @@ __device__ __forceinline__ GCarver gview(const DevCarver &d)
     g.rgb0 = (gu8 *) d.rgb0; g.vs = (gi32 *) d.vs; g.bias0 = (gf32 *) d.bias0; g.rig0 = (gf32 *) d.rig0;
     g.pix = (gu32 *) d.pix; g.en = (gf32 *) d.en; g.m = (gf32 *) d.m; g.least = (gi8 *) d.least;
     g.bias = (gf32 *) d.bias; g.rig = (gf32 *) d.rig;
-    g.seam_x = (gi32 *) d.seam_x; g.seam_log = (gi32 *) d.seam_log; g.flags = (gi32 *) d.flags;
+    g.seam_x = (gi32 *) d.seam_x; g.seam_log = (gi32 *) d.seam_log; g.flags = (gi32 *) d.flags; g.progress = (gi32 *) d.progress;
     return g;
 }
 
@@ -107,6 +108,7 @@ struct DpK {
 static thread_local std::string g_err;
 static int g_device = -1;
 
+#define HIPCK_VOID(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { g_err = std::string(#expr) + ": " + hipGetErrorString(e__); (void) hipGetLastError(); } } while (0)
 #define HIPCK(expr)                                                                   \
     do {                                                                              \
         hipError_t e__ = (expr);                                                      \
@@ -448,6 +450,12 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
 // The back-pointer plane is re-based on the fly: a stored dx stays valid unless
 // pixel and parent are on different sides of the seam.
 // ---------------------------------------------------------------------------
+// write-through (sc1) stores: the data reaches memory without a release fence (buffer_wbl2), so a
+// drained wave (s_waitcnt vmcnt(0)) can publish a flag that a consumer on another XCD may trust
+__device__ __forceinline__ void store_sc1_x4(gu32 *p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_sc1_x1(gu32 *p, uint32_t v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+
+template <bool SC1>
 __device__ __forceinline__ void shift_row_u32(gu32 *row, int v, int wnew, int lane)
 {
     int base = v & ~3;
@@ -476,12 +484,14 @@ __device__ __forceinline__ void shift_row_u32(gu32 *row, int v, int wnew, int la
                 o.y = (x + 1 >= v) ? a[u].z : a[u].y;
                 o.z = (x + 2 >= v) ? a[u].w : a[u].z;
                 o.w = (x + 3 >= v) ? nx : a[u].w;
-                *(GLOBAL_AS u32x4 *) (row + x) = o;
+                if (SC1) store_sc1_x4(row + x, o);
+                else *(GLOBAL_AS u32x4 *) (row + x) = o;
             }
         }
     }
 }
 
+template <bool SC1>
 __device__ __forceinline__ void shift_row_least(gi8 *row, int v, int vprev, int y, int delta, int wnew, int lane)
 {
     int start = (y > 0) ? min(v, vprev - delta) : v;
@@ -506,29 +516,39 @@ __device__ __forceinline__ void shift_row_least(gi8 *row, int v, int vprev, int 
                 }
                 o |= (uint32_t) (uint8_t) (int8_t) dx << (8 * j);
             }
-            row32[x >> 2] = o;
+            if (SC1) store_sc1_x1(row32 + (x >> 2), o);
+            else row32[x >> 2] = o;
         }
     }
 }
 
+template <bool SIGNAL>
 __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h, int stride, int delta, int move_dp)
 {
-    const GCarver c = gview(cs[blockIdx.y]);
+    // blockIdx.x = image (fastest): workgroups are dispatched row-block by row-block across ALL
+    // images, so every image's top rows are carved first and the band update (which walks down the
+    // image on another stream) can follow close behind
+    const GCarver c = gview(cs[blockIdx.x]);
     const int lane = threadIdx.x & 63;
     const int wnew = w - 1;
-    // grid-stride over rows: the grid can be kept small (a few waves per CU) so that the
-    // latency-bound chain kernels of another sub-batch find free wave slots next to it
-    for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < h; y += gridDim.x * 4) {
+    for (int y = blockIdx.y * 4 + (threadIdx.x >> 6); y < h; y += gridDim.y * 4) {
     const int v = c.seam_x[y];
     size_t ro = (size_t) y * stride;
     // pix and bias are NOT moved: they stay in the frame of `frozen epoch` and the energy
     // update maps current coordinates back through the seam log (k_emap_update)
-    shift_row_u32((gu32 *) (c.en + ro), v, wnew, lane);
-    if (c.rig) shift_row_u32((gu32 *) (c.rig + ro), v, wnew, lane);
+    shift_row_u32<SIGNAL>((gu32 *) (c.en + ro), v, wnew, lane);
+    if (c.rig) shift_row_u32<SIGNAL>((gu32 *) (c.rig + ro), v, wnew, lane);
     if (move_dp) {
-        shift_row_u32((gu32 *) (c.m + ro), v, wnew, lane);
+        shift_row_u32<SIGNAL>((gu32 *) (c.m + ro), v, wnew, lane);
         int vprev = y > 0 ? c.seam_x[y - 1] : 0;
-        shift_row_least(c.least + ro, v, vprev, y, delta, wnew, lane);
+        shift_row_least<SIGNAL>(c.least + ro, v, vprev, y, delta, wnew, lane);
+    }
+    if (SIGNAL) {
+        // publish "row y is carved" to the band kernel running concurrently on another stream: the
+        // row was stored write-through (sc1); drain this wave's stores, then one relaxed agent-scope
+        // add on the chunk counter (no buffer_wbl2: a release fence per row costs 6x the carve)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(c.progress + (y >> 6), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     }
 }
@@ -570,7 +590,7 @@ __device__ __forceinline__ int block_rank_256(bool flag, int *s_wave, int &total
 #define EU_NT 12            // brightness samples per row tile
 #define EU_ROWS 62          // rows per block (+2 halo rows)
 template <int NRG>
-__global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, int w, int h, int stride, int k, int epoch)
+__global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, int w, int h, int stride, int k, int epoch, int pre_shift)
 {
     const GCarver c = gview(cs[blockIdx.y]);
     __shared__ double bt[64][EU_NT];
@@ -612,7 +632,9 @@ __global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, 
     for (int x = xmin; x <= xmax; x++) {
         float e = grad_energy_f<NRG>([&](int xx, int yy) { const int t = tid + (yy - y); return bt[t][xx - slo[t]]; }, x, y, w, h);
         if (c.bias) e = __fadd_rn(e, __fdiv_rn(bb[tid][x - lo], (float) p.w_start));
-        c.en[(size_t) y * stride + x] = e;
+        // pre_shift: the carve has not run yet -- write where the carve will pick the value up
+        const int xo = (pre_shift && x >= c.seam_x[y]) ? x + 1 : x;
+        c.en[(size_t) y * stride + xo] = e;
     }
 }
 
@@ -855,7 +877,7 @@ struct BandEdge {          // what a wave publishes about the row it just finish
 };
 
 template <int PXL, int NW, int R, bool LR, bool RIG>
-__global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs, DpK p, int w, int h, int stride)
+__global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs, DpK p, int w, int h, int stride, int gate)
 {
     typedef typename PxVec<PXL>::F FV;
     typedef typename PxVec<PXL>::L LV;
@@ -868,6 +890,23 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
     const float INF = __int_as_float(0x7f800000);
     constexpr int SLOT = 64 * PXL, WIN = SLOT * NW;
     const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
+
+    // gate > 0: the carve of this seam runs concurrently (other stream); rows may only be touched once
+    // their 64-row chunk has been carved `gate` times (cumulative counter, agent-scope acquire)
+    int ready = 0;
+    bool acquired = true;
+    auto wait_rows = [&](int upto) {
+        if (!gate) return;
+        const int cu = min(upto, h - 1) >> 6;
+        while (ready <= cu) {
+            const int need = gate * min(64, h - 64 * ready);
+            while (__hip_atomic_load(c.progress + ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+            ready++;
+            acquired = false;
+        }
+        if (!acquired) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
+    };
+    wait_rows(0);
 
     // pixels of row y whose inputs the carve changed: energy (liblqr's update_emap interval)
     // and parent sets next to the seam; a superset is fine
@@ -931,6 +970,7 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
         }
 
         // previous row: rows < y were stored by this workgroup -> make them visible, then load
+        wait_rows(y + R - 1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -984,6 +1024,7 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
                         dirty_lo = __builtin_amdgcn_readfirstlane(lo);
                         dirty_hi = __builtin_amdgcn_readfirstlane(hi);
                     } else {
+                        wait_rows(y + 2 * R - 1);
                         issue(buf ^ 1, y + R);            // next batch in flight while this one is processed
 #pragma unroll
                         for (int r = 0; r < R; r++) {
@@ -1269,7 +1310,8 @@ struct LqrHipCarver {
     uint32_t *pix = nullptr;
     float *en = nullptr, *m = nullptr, *bias = nullptr, *rig = nullptr;
     int8_t *least = nullptr;
-    int32_t *seam_x = nullptr, *seam_log = nullptr, *flags = nullptr;
+    int32_t *seam_x = nullptr, *seam_log = nullptr, *flags = nullptr, *progress = nullptr;
+    int carve_epoch = 0;            // carve launches since `progress` was zeroed
     int log_cap = 0, log_h = 0;
     int frozen_epoch = 0;           // pix / bias are in the frame before seam `frozen_epoch` of the session
     LqrHipCarver *root = nullptr;
@@ -1281,6 +1323,8 @@ struct LqrHipBatch {
     std::vector<LqrHipCarver *> cs;
     DevCarver *d_desc = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;          // the carve of a seam runs here, concurrently with the band update
+    hipEvent_t ev_ready = nullptr, ev_carved = nullptr;
     bool dirty = true;
 };
 
@@ -1395,7 +1439,7 @@ extern "C" LqrHipCarver *lqrhip_carver_create(const unsigned char *rgb, int w, i
 static void free_working(LqrHipCarver *c)
 {
     dfree(c->pix); dfree(c->en); dfree(c->m); dfree(c->least); dfree(c->bias); dfree(c->rig);
-    dfree(c->seam_x); dfree(c->seam_log); dfree(c->flags);
+    dfree(c->seam_x); dfree(c->seam_log); dfree(c->flags); dfree(c->progress);
     c->log_cap = 0;
 }
 
@@ -1431,7 +1475,7 @@ static int ensure_working(LqrHipCarver *c, int w, int h)
     size_t n = (size_t) stride * (h + 1) + 1024;
     int rc;
     if ((rc = dmalloc(&c->pix, n)) || (rc = dmalloc(&c->en, n)) || (rc = dmalloc(&c->m, n)) || (rc = dmalloc(&c->least, n)) ||
-        (rc = dmalloc(&c->seam_x, (size_t) h + 8)) || (rc = dmalloc(&c->flags, FLAG_COUNT)))
+        (rc = dmalloc(&c->seam_x, (size_t) h + 8)) || (rc = dmalloc(&c->flags, FLAG_COUNT)) || (rc = dmalloc(&c->progress, (size_t) h / 64 + 2)))
         return rc;
     if (need_bias && (rc = dmalloc(&c->bias, n))) return rc;
     if (need_rig && (rc = dmalloc(&c->rig, n))) return rc;
@@ -1440,6 +1484,8 @@ static int ensure_working(LqrHipCarver *c, int w, int h)
     HIPCK(hipMemset(c->en, 0, n * sizeof(float)));
     HIPCK(hipMemset(c->pix, 0, n * sizeof(uint32_t)));
     HIPCK(hipMemset(c->flags, 0, FLAG_COUNT * sizeof(int32_t)));
+    HIPCK(hipMemset(c->progress, 0, ((size_t) h / 64 + 2) * sizeof(int32_t)));
+    c->carve_epoch = 0;
     c->stride = stride; c->wk_h = h;
     if (c->batch) c->batch->dirty = true;
     return 0;
@@ -1505,6 +1551,9 @@ extern "C" LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n)
         carvers[i]->batch = b;
     }
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_carved, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **) &b->d_desc, sizeof(DevCarver) * n) != hipSuccess) {
         g_err = "batch_create failed";
         delete b;
@@ -1517,6 +1566,9 @@ extern "C" void lqrhip_batch_destroy(LqrHipBatch *b)
 {
     if (!b) return;
     if (b->stream) { (void) hipStreamSynchronize(b->stream); (void) hipStreamDestroy(b->stream); }
+    if (b->stream2) { (void) hipStreamSynchronize(b->stream2); (void) hipStreamDestroy(b->stream2); }
+    if (b->ev_ready) (void) hipEventDestroy(b->ev_ready);
+    if (b->ev_carved) (void) hipEventDestroy(b->ev_carved);
     for (auto *c : b->cs) if (c->batch == b) c->batch = nullptr;
     if (b->d_desc) (void) hipFree(b->d_desc);
     delete b;
@@ -1534,7 +1586,7 @@ static DevCarver make_desc(const LqrHipCarver *c)
     DevCarver d;
     d.rgb0 = c->rgb0; d.vs = c->vs; d.bias0 = c->bias0; d.rig0 = c->rig0;
     d.pix = c->pix; d.en = c->en; d.m = c->m; d.least = c->least; d.bias = c->bias; d.rig = c->rig;
-    d.seam_x = c->seam_x; d.seam_log = c->seam_log; d.flags = c->flags;
+    d.seam_x = c->seam_x; d.seam_log = c->seam_log; d.flags = c->flags; d.progress = c->progress;
     return d;
 }
 
@@ -1683,6 +1735,7 @@ static int frozen_catchup(LqrHipBatch *b, int to, int w_at_to, int h)
 static int g_use_band = -1;
 static int g_band_variant = 0;
 static int g_carve_wgs = 0;          // > 0: cap on the carve kernel's workgroups (LQRHIP_CARVE_WGS)
+static int g_overlap = 1;            // carve || band update on two streams (LQRHIP_OVERLAP=0 disables)
 
 extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
                                 int full_rebuild, int leftright_next)
@@ -1696,6 +1749,8 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         g_band_variant = v ? atoi(v) : 0;
         const char *cw = getenv("LQRHIP_CARVE_WGS");
         g_carve_wgs = cw ? atoi(cw) : 0;
+        const char *ov = getenv("LQRHIP_OVERLAP");
+        g_overlap = ov ? atoi(ov) : 1;
     }
     for (auto *c : b->cs)
         if (log_index >= c->log_cap) return LQRHIP_EARG;
@@ -1710,54 +1765,88 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     }
     const int wnew = w - 1;
     const int move_dp = (wnew > 1 && !full_rebuild) ? 1 : 0;
-    {
+    bool has_rigmask = false;
+    for (auto *c : b->cs) has_rigmask |= (c->rig != nullptr);
+    const bool fast_band = move_dp && g_use_band == 1 && p->delta_x == 1 && !has_rigmask && (size_t) h * sizeof(int) <= 60 * 1024;
+    // overlap: the bandwidth-bound carve (stream2) runs concurrently with the latency-bound band
+    // update (stream), which follows it down the image chunk by chunk (progress counters)
+    // (only pays when the carve is long enough to hide something: measured break-even ~8 images of 4K)
+    const bool overlap = fast_band && g_overlap && (size_t) n * (size_t) w * (size_t) h >= (size_t) 12 * 3840 * 2160;
+    const int gate = c0->carve_epoch + 1;
+
+    auto launch_emap_update = [&](int pre_shift) -> int {
+        ProfScope ps("emap_update", b->stream, 0);
+        if (log_index + 1 - c0->frozen_epoch > FROZEN_LAG_MAX) {
+            int rc2 = frozen_catchup(b, log_index + 1, wnew, h);
+            if (rc2) return rc2;
+        }
+        const int epoch = c0->frozen_epoch;
+#define LAUNCH_EUPD(N) hipLaunchKernelGGL((k_emap_update<N>), dim3((h + EU_ROWS - 1) / EU_ROWS, n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, log_index, epoch, pre_shift)
+        NRG_DISPATCH(p->nrg_func, LAUNCH_EUPD)
+#undef LAUNCH_EUPD
+        return 0;
+    };
+    auto launch_carve = [&](hipStream_t st) {
         // algorithmic bytes of one carve launch: read + write of one 4-byte
         // plane over the half of each row right of the seam = 8 B * w*h/2 per image
-        ProfScope ps("carve", b->stream, 4.0 * (double) w * h * n);
+        ProfScope ps("carve", st, 4.0 * (double) w * h * n);
         int gx = (h + 3) / 4;
         if (g_carve_wgs > 0) gx = std::max(1, std::min(gx, g_carve_wgs / (int) n));
-        hipLaunchKernelGGL(k_carve, dim3(gx, n), dim3(256), 0, b->stream, b->d_desc, w, h, stride, p->delta_x, move_dp);
-    }
-    if (wnew > 1) {
-        {
-            ProfScope ps("emap_update", b->stream, 0);
-            if (log_index + 1 - c0->frozen_epoch > FROZEN_LAG_MAX) {
-                if ((rc = frozen_catchup(b, log_index + 1, wnew, h))) return rc;
-            }
-            const int epoch = c0->frozen_epoch;
-#define LAUNCH_EUPD(N) hipLaunchKernelGGL((k_emap_update<N>), dim3((h + EU_ROWS - 1) / EU_ROWS, n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, log_index, epoch)
-            NRG_DISPATCH(p->nrg_func, LAUNCH_EUPD)
-#undef LAUNCH_EUPD
+        if (overlap) {
+            hipLaunchKernelGGL(k_carve<true>, dim3(n, gx), dim3(256), 0, st, b->d_desc, w, h, stride, p->delta_x, move_dp);
+            for (auto *c : b->cs) c->carve_epoch = gate;      // counts the signalling carves only
+        } else {
+            hipLaunchKernelGGL(k_carve<false>, dim3(n, gx), dim3(256), 0, st, b->d_desc, w, h, stride, p->delta_x, move_dp);
         }
+    };
+    auto launch_fast_band = [&](int gate_arg) {
+        ProfScope ps("band_update", b->stream, 0);
+#define LAUNCH_BAND_V(PX, NWV, RV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_mw<PX, NWV, RV, LRV, RIGV>), dim3(n), dim3(64 * NWV), (size_t) h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, gate_arg)
+#define LAUNCH_BAND(LRV, RIGV)                                                          \
+    do {                                                                                \
+        if (g_band_variant == 1) LAUNCH_BAND_V(4, 4, 8, LRV, RIGV);                     \
+        else if (g_band_variant == 4) LAUNCH_BAND_V(2, 4, 8, LRV, RIGV);                \
+        else if (g_band_variant == 5) LAUNCH_BAND_V(2, 16, 8, LRV, RIGV);               \
+        else if (g_band_variant == 6) LAUNCH_BAND_V(4, 8, 8, LRV, RIGV);                \
+        else if (wnew > 4200) LAUNCH_BAND_V(2, 16, 8, LRV, RIGV);   /* 8K: dirty regions up to ~900 px */ \
+        else LAUNCH_BAND_V(2, 8, 8, LRV, RIGV);                                         \
+    } while (0)
+        if (leftright_next) { if (p->use_rigidity) LAUNCH_BAND(true, true); else LAUNCH_BAND(true, false); }
+        else { if (p->use_rigidity) LAUNCH_BAND(false, true); else LAUNCH_BAND(false, false); }
+#undef LAUNCH_BAND_V
+#undef LAUNCH_BAND
+    };
+
+    if (overlap) {
+        // the energy update does not read any plane the carve moves (pix/bias are frozen): it runs
+        // first and writes en where the carve will pick it up
+        if ((rc = launch_emap_update(1))) return rc;
+        HIPCK(hipEventRecord(b->ev_ready, b->stream));
+        HIPCK(hipStreamWaitEvent(b->stream2, b->ev_ready, 0));
+        launch_carve(b->stream2);
+        HIPCK(hipEventRecord(b->ev_carved, b->stream2));
+        launch_fast_band(gate);
+        HIPCK(hipStreamWaitEvent(b->stream, b->ev_carved, 0));       // everything after needs the whole carve
+        {
+            ProfScope ps("dp_update", b->stream, 0);
+            if ((rc = launch_dp<true>(b, k, wnew, h, leftright_next))) return rc;
+        }
+        HIPCK(hipGetLastError());
+        return 0;
+    }
+
+    launch_carve(b->stream);
+    if (wnew > 1) {
+        if ((rc = launch_emap_update(0))) return rc;
         if (full_rebuild) {
             ProfScope ps("dp_sweep", b->stream, 9.0 * wnew * h * n);
             if ((rc = launch_dp<false>(b, k, wnew, h, leftright_next))) return rc;
         } else {
             if (g_use_band) {
-                ProfScope ps("band_update", b->stream, 0);
-                bool has_rigmask = false;
-                for (auto *c : b->cs) has_rigmask |= (c->rig != nullptr);
-                if (p->delta_x == 1 && !has_rigmask && g_use_band == 1 && (size_t) h * sizeof(int) <= 60 * 1024) {
-#define LAUNCH_BAND_V(PX, NWV, RV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_mw<PX, NWV, RV, LRV, RIGV>), dim3(n), dim3(64 * NWV), (size_t) h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride)
-#define LAUNCH_BAND(LRV, RIGV)                                                          \
-    do {                                                                                \
-        if (g_band_variant == 1) LAUNCH_BAND_V(4, 4, 8, LRV, RIGV);                     \
-        else if (g_band_variant == 2) LAUNCH_BAND_V(1, 16, 8, LRV, RIGV);               \
-        else if (g_band_variant == 3) LAUNCH_BAND_V(4, 2, 8, LRV, RIGV);                \
-        else if (g_band_variant == 4) LAUNCH_BAND_V(2, 4, 8, LRV, RIGV);                \
-        else if (g_band_variant == 5) LAUNCH_BAND_V(2, 16, 8, LRV, RIGV);               \
-        else if (g_band_variant == 6) LAUNCH_BAND_V(4, 8, 8, LRV, RIGV);                \
-        else if (g_band_variant == 7) LAUNCH_BAND_V(2, 8, 4, LRV, RIGV);                \
-        else if (g_band_variant == 8) LAUNCH_BAND_V(2, 8, 16, LRV, RIGV);               \
-        else if (g_band_variant == 9) LAUNCH_BAND_V(2, 8, 2, LRV, RIGV);                \
-        else if (wnew > 4200) LAUNCH_BAND_V(2, 16, 8, LRV, RIGV);   /* 8K: dirty regions up to ~900 px */ \
-        else LAUNCH_BAND_V(2, 8, 8, LRV, RIGV);                                         \
-    } while (0)
-                    if (leftright_next) { if (p->use_rigidity) LAUNCH_BAND(true, true); else LAUNCH_BAND(true, false); }
-                    else { if (p->use_rigidity) LAUNCH_BAND(false, true); else LAUNCH_BAND(false, false); }
-#undef LAUNCH_BAND_V
-#undef LAUNCH_BAND
+                if (fast_band) {
+                    launch_fast_band(0);
                 } else {
+                    ProfScope ps("band_update", b->stream, 0);
                     hipLaunchKernelGGL(k_band_update, dim3(n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, leftright_next);
                 }
             } else {
