@@ -191,6 +191,24 @@ def main():
                     "avg_launch_us": round(c_ms * 1e3 / c_n, 2), "launches": c_n,
                     "alg_bytes_per_launch": round(c_bytes / c_n)}
 
+    # ---- the roofline kernel in isolation: in the timed region k_carve runs concurrently with the
+    # band update (that is what makes the step faster), which stretches its launch time; one extra
+    # untimed step with the two kernels back to back gives the kernel's own bandwidth
+    if roofline and nimg > 1 and rank == 0 and os.environ.get("LQRHIP_OVERLAP", "1") != "0":
+        extra = new_carvers()
+        lib.lqrhip_set_overlap(0)
+        lib.lqrhip_prof_reset(); lib.lqrhip_prof_enable(1)
+        run_step(extra); sync()
+        lib.lqrhip_prof_enable(0); lib.lqrhip_set_overlap(-1)
+        i_ms, i_n, i_bytes = prof("carve")
+        if i_n:
+            ia = i_bytes / (i_ms * 1e-3) / 1e9
+            roofline["concurrent_with"] = "k_band_update_mw (second stream)"
+            roofline["isolated"] = {"achieved": round(ia, 1), "frac": round(ia / 8000.0, 4), "avg_launch_us": round(i_ms * 1e3 / i_n, 2),
+                                    "note": "same kernel, same batch, carve and band update back to back (untimed extra step)"}
+        for c in extra:
+            c.destroy()
+
     # ---- results of the last step: gather to rank 0 over RCCL (outside the timed region)
     gather_ms = None
     last = steps[-1]

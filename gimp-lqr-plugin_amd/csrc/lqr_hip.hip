@@ -1631,6 +1631,9 @@ struct ProfScope {
 };
 
 extern "C" void lqrhip_prof_enable(int on) { g_prof = on != 0; }
+static int g_overlap_override = -1;
+// -1: LQRHIP_OVERLAP / default; 0: carve and band update back to back on one stream; 1: overlapped
+extern "C" void lqrhip_set_overlap(int mode) { g_overlap_override = mode; }
 extern "C" void lqrhip_prof_reset(void)
 {
     for (auto &kv : g_profrec) for (auto &e : kv.second.ev) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
@@ -1771,7 +1774,7 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     // overlap: the bandwidth-bound carve (stream2) runs concurrently with the latency-bound band
     // update (stream), which follows it down the image chunk by chunk (progress counters)
     // (only pays when the carve is long enough to hide something: measured break-even ~8 images of 4K)
-    const bool overlap = fast_band && g_overlap && (size_t) n * (size_t) w * (size_t) h >= (size_t) 12 * 3840 * 2160;
+    const bool overlap = fast_band && (g_overlap_override >= 0 ? g_overlap_override : g_overlap) && (size_t) n * (size_t) w * (size_t) h >= (size_t) 12 * 3840 * 2160;
     const int gate = c0->carve_epoch + 1;
 
     auto launch_emap_update = [&](int pre_shift) -> int {

@@ -120,6 +120,8 @@ int lqrhip_read_working(LqrHipCarver *c, int w, int h, float *en, float *m, int 
 /* kernel-time accounting for bench.py: accumulated HIP-event time (ms) and
  * launch count of the carve kernel (the roofline kernel) since the last reset */
 void lqrhip_prof_enable(int on);
+/* -1 default (LQRHIP_OVERLAP env, on for large batches), 0 carve and band update back to back, 1 overlapped */
+void lqrhip_set_overlap(int mode);
 void lqrhip_prof_reset(void);
 int lqrhip_prof_get(const char *kernel, double *ms_total, long long *launches, double *bytes_total);
 
