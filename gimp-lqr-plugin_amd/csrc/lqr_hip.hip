@@ -877,7 +877,7 @@ struct BandEdge {          // what a wave publishes about the row it just finish
 };
 
 template <int PXL, int NW, int R, bool LR, bool RIG>
-__global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs, DpK p, int w, int h, int stride, int gate)
+__global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs, DpK p, int w, int h, int stride, int gate, int resume)
 {
     typedef typename PxVec<PXL>::F FV;
     typedef typename PxVec<PXL>::L LV;
@@ -890,6 +890,11 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
     const float INF = __int_as_float(0x7f800000);
     constexpr int SLOT = 64 * PXL, WIN = SLOT * NW;
     const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
+    // resume: the single-wave kernel handled rows < flags[OVF_ROW] and left the extent of its last
+    // row's changes as a hint for the first window
+    const int y_start = resume ? c.flags[FLAG_OVF_ROW] : 1;
+    if (y_start >= h) return;
+    const int hint_lo = resume ? c.flags[1] : -1, hint_hi = resume ? c.flags[2] : -1;
 
     // gate > 0: the carve of this seam runs concurrently (other stream); rows may only be touched once
     // their 64-row chunk has been carved `gate` times (cumulative counter, agent-scope acquire)
@@ -898,10 +903,16 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
     auto wait_rows = [&](int upto) {
         if (!gate) return;
         const int cu = min(upto, h - 1) >> 6;
-        while (ready <= cu) {
-            const int need = gate * min(64, h - 64 * ready);
-            while (__hip_atomic_load(c.progress + ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
-            ready++;
+        if (ready <= cu) {
+            // one polling wave per workgroup, long sleeps: hundreds of spinning waves would eat into
+            // the very bandwidth the carve needs; the others wait at the (LDS-only) barrier
+            if (wave == 0)
+                for (int ch = ready; ch <= cu; ch++) {
+                    const int need = gate * min(64, h - 64 * ch);
+                    while (__hip_atomic_load(c.progress + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(64);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            ready = cu + 1;
             acquired = false;
         }
         if (!acquired) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
@@ -919,7 +930,7 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
         BandEdge e; e.first_val = INF; e.last_val = INF; e.flags = 0; e.pad = 0;
         s_edge[tid / (NW + 2)][tid % (NW + 2)] = e;
     }
-    {   // row 0: m = en on liblqr's interval
+    if (!resume) {   // row 0: m = en on liblqr's interval
         const int v0 = c.seam_x[0], vp = c.seam_x[min(1, h - 1)];
         int lo = v0, hi = v0 - 1;
         if (p.radius) { lo = min(v0, vp) - 1; hi = max(v0, vp); }
@@ -934,7 +945,7 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
     long long t_bar = 0, t_rows = 0, t_act = 0, t_rebase = 0, t_p01 = 0, t_p12 = 0, t_p2b = 0;
     const long long t_start = __builtin_readcyclecounter();
 #endif
-    int y = 1, ovf = h;
+    int y = y_start, ovf = h;
     int dirty_lo = -1, dirty_hi = -1;      // dirty slots of the last finished row, window-relative (-1: none)
     int B = 0;
     bool have_window = false;
@@ -947,12 +958,18 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
             const int t = s_touch[y];
             int lo = t & 0xffff, hi = t >> 16;                       // absolute pixel range that must be inside
             if (have_window && dirty_lo >= 0) { lo = min(lo, B + SLOT * dirty_lo - 1); hi = max(hi, B + SLOT * (dirty_hi + 1)); }
+            if (!have_window && hint_lo >= 0) { lo = min(lo, hint_lo - 1); hi = max(hi, hint_hi + 1); }
             lo = max(lo, 0); hi = min(hi, w - 1);
-            if (hi - lo + 1 > WIN - 2 * SLOT - 2 * (R + 2) && hi - lo + 1 < w) { ovf = y; break; }
+            if (hi - lo + 1 > WIN - 2 * SLOT - 2 * (R + 2) - 8 && hi - lo + 1 < w) { ovf = y; break; }
             int nb = (((lo + hi) >> 1) - WIN / 2) & ~3;
             nb = max(0, min(nb, (w - WIN + 3) & ~3));
             B = __builtin_amdgcn_readfirstlane(nb);
             have_window = true;
+            // the first and last slot must stay clean for the next R rows (same test as at the batch
+            // boundaries below); if even the re-centred window cannot promise that, hand over
+            const bool left_ok = (B == 0) || (lo - (R + 2) >= B + SLOT);
+            const bool right_ok = (B + WIN >= w) || (hi + (R + 2) < B + WIN - SLOT);
+            if (!(left_ok && right_ok)) { ovf = y; break; }
         }
         const int x0 = B + SLOT * wave + PXL * lane;          // first pixel of this lane
         const int sx0 = B + SLOT * wave;                      // first pixel of this wave's slot
@@ -1134,6 +1151,203 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
                (double) (t_end - t_start - t_bar - t_p01 - t_p12 - t_p2b) / t_rows, t_rebase);
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// E9 update_mmap, delta_x == 1, single-wave form: ONE wave per image recomputes a
+// 512-pixel window (8 consecutive pixels per lane) on every row -- by section 4.4 of
+// DESIGN.md any superset of the changed-input pixels gives liblqr's result, and
+// the whole window is the simplest superset.  No LDS traffic, no barrier, no band
+// bookkeeping on the per-row chain: neighbours inside a lane are registers, across
+// lanes DPP wave shifts.  The window follows the changes; when they no longer fit
+// (wider than ~480 px) the kernel leaves the row and the extent of the changes in
+// flags[] and the multi-wave kernel (k_band_update_mw, resume) carries on.
+// ---------------------------------------------------------------------------
+#define FLAG_HINT_LO 1
+#define FLAG_HINT_HI 2
+template <int R, bool LR, bool RIG>
+__global__ __launch_bounds__(64) void k_band_update_sw(const DevCarver *cs, DpK p, int w, int h, int stride, int gate)
+{
+    constexpr int PXL = 8, WIN = 64 * PXL, MARG = R + 8;
+    const GCarver c = gview(cs[blockIdx.x]);
+    extern __shared__ int s_touch[];                  // [h] packed (t0 | t1 << 16)
+    const int lane = threadIdx.x;
+    const float INF = __int_as_float(0x7f800000);
+    const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
+
+    int ready = 0;
+    bool acquired = true;
+    auto wait_rows = [&](int upto) {          // see k_band_update_mw
+        if (!gate) return;
+        const int cu = min(upto, h - 1) >> 6;
+        for (; ready <= cu; ready++) {
+            const int need = gate * min(64, h - 64 * ready);
+            while (__hip_atomic_load(c.progress + ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(64);
+            acquired = false;
+        }
+        if (!acquired) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
+    };
+    wait_rows(0);
+
+    for (int y = lane; y < h; y += 64) {
+        const int v0 = c.seam_x[y], vm = c.seam_x[max(y - 1, 0)], vp = c.seam_x[min(y + 1, h - 1)];
+        const int t0 = max(min(min(v0, vm), vp) - 2, 0), t1 = min(max(max(v0, vm), vp) + 1, w - 1);
+        s_touch[y] = t0 | (t1 << 16);
+    }
+    {   // row 0: m = en on liblqr's interval
+        const int v0 = c.seam_x[0], vp = c.seam_x[min(1, h - 1)];
+        int lo = v0, hi = v0 - 1;
+        if (p.radius) { lo = min(v0, vp) - 1; hi = max(v0, vp); }
+        const int a = max(lo, 0), b = min(hi, w - 1);
+        for (int x = a + lane; x <= b; x += 64) c.m[x] = c.en[x];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (h < 2) { if (lane == 0) { c.flags[FLAG_OVF_ROW] = h; } return; }
+
+    const unsigned dummy = (unsigned) h * stride + PXL * lane;
+    int y = 1, ovf = h;
+    int d_lo = -1, d_hi = -1;          // absolute pixel extent of the changes of the last finished row
+    while (y < h) {
+        // ---- (re)base the window on what must be inside it
+        int B;
+        {
+            const int t = s_touch[y];
+            int lo = t & 0xffff, hi = t >> 16;
+            if (d_lo >= 0) { lo = min(lo, d_lo - 1); hi = max(hi, d_hi + 1); }
+            lo = max(lo, 0); hi = min(hi, w - 1);
+            if (hi - lo + 1 > WIN - 2 * MARG - 24 && w > WIN) { ovf = y; break; }
+            int nb = (((lo + hi) >> 1) - WIN / 2) & ~7;
+            nb = max(0, min(nb, (w - WIN + 7) & ~7));
+            B = __builtin_amdgcn_readfirstlane(nb);
+            // the window must pass the batch-boundary test below right away, otherwise this loop
+            // would re-base forever: hand the rest of the image over instead
+            const bool left_ok = (B == 0) || (lo - MARG >= B);
+            const bool right_ok = (B + WIN >= w) || (hi + MARG < B + WIN);
+            if (!(left_ok && right_ok)) { ovf = y; break; }
+        }
+        const int x0 = B + PXL * lane;
+        const unsigned lo_off = (unsigned) min(x0, stride - PXL);
+        const bool in_img = x0 < w;
+        uint32_t okmask = 0;       // pixels this lane may recompute (see k_band_update_mw)
+#pragma unroll
+        for (int k = 0; k < PXL; k++) {
+            const int x = x0 + k;
+            const bool ok = (x < w) && !(B > 0 && x == B) && !(B + WIN < w && x == B + WIN - 1);
+            okmask |= ok ? (1u << k) : 0u;
+        }
+
+        wait_rows(y + R - 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        float mp[PXL];
+        {
+            gf32 *mrow = c.m + (size_t) (y - 1) * stride;
+#pragma unroll
+            for (int k = 0; k < PXL; k++)
+                mp[k] = (x0 + k < w) ? __hip_atomic_load(mrow + x0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
+        }
+
+        f32x4 q_mo[2][R][2], q_e[2][R][2];
+        uint64_t q_lo[2][R];
+        auto issue = [&](int buf, int ybase) {           // one batch of R rows, unconditional
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const unsigned ro = (unsigned) min(ybase + r, h - 1) * (unsigned) stride + lo_off;
+                q_mo[buf][r][0] = *(const GLOBAL_AS f32x4 *) (c.m + ro);
+                q_mo[buf][r][1] = *(const GLOBAL_AS f32x4 *) (c.m + ro + 4);
+                q_e[buf][r][0] = *(const GLOBAL_AS f32x4 *) (c.en + ro);
+                q_e[buf][r][1] = *(const GLOBAL_AS f32x4 *) (c.en + ro + 4);
+                q_lo[buf][r] = *(const GLOBAL_AS uint64_t *) (c.least + ro);
+            }
+        };
+        issue(0, y);
+
+        uint32_t chg_last = 0;             // per-lane change bits of the last finished row
+        bool have_last = false;
+        bool rebase = false;
+        while (y < h && !rebase) {
+#pragma unroll
+            for (int buf = 0; buf < 2; buf++) {
+                if (y < h && !rebase) {
+                    // ---- batch boundary: extent of the last row's changes; does the window hold R more rows?
+                    if (have_last) {
+                        const unsigned long long bal = __ballot(chg_last != 0);
+                        if (bal) {
+                            const int fl = __ffsll((long long) bal) - 1, ll = 63 - __clzll((long long) bal);
+                            const uint32_t mf = (uint32_t) __builtin_amdgcn_readlane((int) chg_last, fl);
+                            const uint32_t ml = (uint32_t) __builtin_amdgcn_readlane((int) chg_last, ll);
+                            d_lo = B + PXL * fl + (__ffs((int) mf) - 1);
+                            d_hi = B + PXL * ll + (31 - __clz((int) ml));
+                        } else {
+                            d_lo = -1; d_hi = -1;
+                        }
+                    }
+                    {
+                        const int t = s_touch[y];
+                        int lo = (t & 0xffff), hi = (t >> 16);
+                        if (d_lo >= 0) { lo = min(lo, d_lo); hi = max(hi, d_hi); }
+                        const bool left_ok = (B == 0) || (lo - MARG >= B);
+                        const bool right_ok = (B + WIN >= w) || (hi + MARG < B + WIN);
+                        rebase = !(left_ok && right_ok);
+                    }
+                    if (!rebase) {
+                        wait_rows(y + 2 * R - 1);
+                        issue(buf ^ 1, y + R);
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            if (y < h) {
+                                float mo[PXL], e[PXL], mc[PXL];
+                                const uint64_t lo8 = q_lo[buf][r];
+#pragma unroll
+                                for (int k = 0; k < PXL; k++) { mo[k] = q_mo[buf][r][k >> 2][k & 3]; e[k] = q_e[buf][r][k >> 2][k & 3]; }
+                                float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[PXL - 1]),
+                                                                                    DPP_WAVE_SHR1, 0xf, 0xf, false));
+                                float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[0]),
+                                                                                     DPP_WAVE_SHL1, 0xf, 0xf, false));
+                                uint32_t chg = 0;
+                                uint64_t lnew = 0;
+#pragma unroll
+                                for (int k = 0; k < PXL; k++) {
+                                    float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
+                                    const float cc = mp[k];
+                                    float rr = (k == PXL - 1) ? right : mp[k < PXL - 1 ? k + 1 : 0];
+                                    if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
+                                    const float best = fminf(fminf(l, cc), rr);
+                                    int bdx;
+                                    if (LR) { bdx = (cc == best) ? 0 : -1; bdx = (rr == best) ? 1 : bdx; }
+                                    else { bdx = (cc == best) ? 0 : 1; bdx = (l == best) ? -1 : bdx; }
+                                    const float nm = __fadd_rn(e[k], best);
+                                    const int lo_k = (int) (int8_t) (lo8 >> (8 * k));
+                                    float d = fabsf(__fsub_rn(mo[k], nm));
+                                    d = (lo_k == bdx) ? d : INF;
+                                    d = ((okmask >> k) & 1) ? d : 0.0f;
+                                    const bool ch = d > 1e-5f;          // keep rule: (double) fabsf(d) < 1e-5 keeps the stale value
+                                    mc[k] = ch ? nm : ((x0 + k < w) ? mo[k] : INF);
+                                    const int outl = ((okmask >> k) & 1) ? bdx : lo_k;
+                                    lnew |= (uint64_t) ((uint32_t) outl & 0xffu) << (8 * k);
+                                    chg |= ch ? (1u << k) : 0u;
+                                }
+                                const unsigned so = in_img ? (unsigned) y * (unsigned) stride + (unsigned) x0 : dummy;
+                                f32x4 t0 = {mc[0], mc[1], mc[2], mc[3]}, t1 = {mc[4], mc[5], mc[6], mc[7]};
+                                *(GLOBAL_AS f32x4 *) (c.m + so) = t0;
+                                *(GLOBAL_AS f32x4 *) (c.m + so + 4) = t1;
+                                *(GLOBAL_AS uint64_t *) (c.least + so) = lnew;
+#pragma unroll
+                                for (int k = 0; k < PXL; k++) mp[k] = mc[k];
+                                chg_last = chg;
+                                have_last = true;
+                                y++;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (y >= h && have_last) {       // extent of the final row is not needed
+        }
+    }
+    if (lane == 0) { c.flags[FLAG_OVF_ROW] = ovf; c.flags[FLAG_HINT_LO] = d_lo; c.flags[FLAG_HINT_HI] = d_hi; }
 }
 
 // ---------------------------------------------------------------------------
@@ -1738,6 +1952,8 @@ static int frozen_catchup(LqrHipBatch *b, int to, int w_at_to, int h)
 static int g_use_band = -1;
 static int g_band_variant = 0;
 static int g_carve_wgs = 0;          // > 0: cap on the carve kernel's workgroups (LQRHIP_CARVE_WGS)
+static int g_band_sw = 0;            // LQRHIP_BAND_SW=1: single-wave band kernel first.  Measured no faster than the
+                                     // multi-wave one (a lone wave issues 1 instruction / 4 cycles: ~184 instr/row), so off
 static int g_overlap = 1;            // carve || band update on two streams (LQRHIP_OVERLAP=0 disables)
 
 extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
@@ -1752,6 +1968,8 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         g_band_variant = v ? atoi(v) : 0;
         const char *cw = getenv("LQRHIP_CARVE_WGS");
         g_carve_wgs = cw ? atoi(cw) : 0;
+        const char *sw = getenv("LQRHIP_BAND_SW");
+        g_band_sw = sw ? atoi(sw) : 0;
         const char *ov = getenv("LQRHIP_OVERLAP");
         g_overlap = ov ? atoi(ov) : 1;
     }
@@ -1803,8 +2021,18 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         }
     };
     auto launch_fast_band = [&](int gate_arg) {
+        const int resume = g_band_sw ? 1 : 0;
+        if (g_band_sw) {
+            // single-wave kernel first; what it cannot hold (changes wider than its 512-px window) is
+            // finished by the multi-wave kernel from the recorded row
+            ProfScope ps("band_update_sw", b->stream, 0);
+#define LAUNCH_SW(LRV, RIGV) hipLaunchKernelGGL((k_band_update_sw<8, LRV, RIGV>), dim3(n), dim3(64), (size_t) h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, gate_arg)
+            if (leftright_next) { if (p->use_rigidity) LAUNCH_SW(true, true); else LAUNCH_SW(true, false); }
+            else { if (p->use_rigidity) LAUNCH_SW(false, true); else LAUNCH_SW(false, false); }
+#undef LAUNCH_SW
+        }
         ProfScope ps("band_update", b->stream, 0);
-#define LAUNCH_BAND_V(PX, NWV, RV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_mw<PX, NWV, RV, LRV, RIGV>), dim3(n), dim3(64 * NWV), (size_t) h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, gate_arg)
+#define LAUNCH_BAND_V(PX, NWV, RV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_mw<PX, NWV, RV, LRV, RIGV>), dim3(n), dim3(64 * NWV), (size_t) h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, gate_arg, resume)
 #define LAUNCH_BAND(LRV, RIGV)                                                          \
     do {                                                                                \
         if (g_band_variant == 1) LAUNCH_BAND_V(4, 4, 8, LRV, RIGV);                     \
