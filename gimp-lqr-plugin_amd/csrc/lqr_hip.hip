@@ -900,8 +900,14 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
     // their 64-row chunk has been carved `gate` times (cumulative counter, agent-scope acquire)
     int ready = 0;
     bool acquired = true;
-    auto wait_rows = [&](int upto) {
-        if (!gate) return;
+    __shared__ int s_abort;
+    if (tid == 0) s_abort = 0;
+    __syncthreads();
+    // returns false if the carve did not show up within ~2 s (every spin is bounded): the caller then
+    // records the current row and leaves; the full-width sweep, which the host orders after the
+    // carve, finishes the image correctly
+    auto wait_rows = [&](int upto) -> bool {
+        if (!gate) return true;
         const int cu = min(upto, h - 1) >> 6;
         if (ready <= cu) {
             // one polling wave per workgroup, long sleeps: hundreds of spinning waves would eat into
@@ -909,15 +915,21 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
             if (wave == 0)
                 for (int ch = ready; ch <= cu; ch++) {
                     const int need = gate * min(64, h - 64 * ch);
-                    while (__hip_atomic_load(c.progress + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(64);
+                    int spins = 0;
+                    while (__hip_atomic_load(c.progress + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                        __builtin_amdgcn_s_sleep(64);
+                        if (++spins > (1 << 20)) { if (lane == 0) s_abort = 1; break; }
+                    }
                 }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (s_abort) return false;
             ready = cu + 1;
             acquired = false;
         }
         if (!acquired) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
+        return true;
     };
-    wait_rows(0);
+    if (!wait_rows(0)) { if (tid == 0) c.flags[FLAG_OVF_ROW] = resume ? y_start : 0; return; }
 
     // pixels of row y whose inputs the carve changed: energy (liblqr's update_emap interval)
     // and parent sets next to the seam; a superset is fine
@@ -949,7 +961,8 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
     int dirty_lo = -1, dirty_hi = -1;      // dirty slots of the last finished row, window-relative (-1: none)
     int B = 0;
     bool have_window = false;
-    while (y < h) {
+    bool abort_all = false;
+    while (y < h && !abort_all) {
         // ---- (re)base the window (identical decision in every wave)
 #ifdef BAND_TIMING
         t_rebase++;
@@ -987,7 +1000,7 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
         }
 
         // previous row: rows < y were stored by this workgroup -> make them visible, then load
-        wait_rows(y + R - 1);
+        if (!wait_rows(y + R - 1)) { ovf = y; break; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1041,7 +1054,7 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
                         dirty_lo = __builtin_amdgcn_readfirstlane(lo);
                         dirty_hi = __builtin_amdgcn_readfirstlane(hi);
                     } else {
-                        wait_rows(y + 2 * R - 1);
+                        if (!wait_rows(y + 2 * R - 1)) { ovf = y; abort_all = true; rebase = true; break; }
                         issue(buf ^ 1, y + R);            // next batch in flight while this one is processed
 #pragma unroll
                         for (int r = 0; r < R; r++) {
@@ -1177,17 +1190,22 @@ __global__ __launch_bounds__(64) void k_band_update_sw(const DevCarver *cs, DpK 
 
     int ready = 0;
     bool acquired = true;
-    auto wait_rows = [&](int upto) {          // see k_band_update_mw
-        if (!gate) return;
+    auto wait_rows = [&](int upto) -> bool {          // see k_band_update_mw; false = the carve never showed up
+        if (!gate) return true;
         const int cu = min(upto, h - 1) >> 6;
         for (; ready <= cu; ready++) {
             const int need = gate * min(64, h - 64 * ready);
-            while (__hip_atomic_load(c.progress + ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(64);
+            int spins = 0;
+            while (__hip_atomic_load(c.progress + ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(64);
+                if (++spins > (1 << 20)) return false;
+            }
             acquired = false;
         }
         if (!acquired) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
+        return true;
     };
-    wait_rows(0);
+    if (!wait_rows(0)) { if (lane == 0) { c.flags[FLAG_OVF_ROW] = 0; c.flags[FLAG_HINT_LO] = -1; c.flags[FLAG_HINT_HI] = -1; } return; }
 
     for (int y = lane; y < h; y += 64) {
         const int v0 = c.seam_x[y], vm = c.seam_x[max(y - 1, 0)], vp = c.seam_x[min(y + 1, h - 1)];
@@ -1208,7 +1226,8 @@ __global__ __launch_bounds__(64) void k_band_update_sw(const DevCarver *cs, DpK 
     const unsigned dummy = (unsigned) h * stride + PXL * lane;
     int y = 1, ovf = h;
     int d_lo = -1, d_hi = -1;          // absolute pixel extent of the changes of the last finished row
-    while (y < h) {
+    bool aborted = false;
+    while (y < h && !aborted) {
         // ---- (re)base the window on what must be inside it
         int B;
         {
@@ -1237,7 +1256,7 @@ __global__ __launch_bounds__(64) void k_band_update_sw(const DevCarver *cs, DpK 
             okmask |= ok ? (1u << k) : 0u;
         }
 
-        wait_rows(y + R - 1);
+        if (!wait_rows(y + R - 1)) { ovf = y; break; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         float mp[PXL];
@@ -1292,7 +1311,7 @@ __global__ __launch_bounds__(64) void k_band_update_sw(const DevCarver *cs, DpK 
                         rebase = !(left_ok && right_ok);
                     }
                     if (!rebase) {
-                        wait_rows(y + 2 * R - 1);
+                        if (!wait_rows(y + 2 * R - 1)) { ovf = y; aborted = true; rebase = true; break; }
                         issue(buf ^ 1, y + R);
 #pragma unroll
                         for (int r = 0; r < R; r++) {
@@ -1756,6 +1775,18 @@ extern "C" int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int c
 }
 
 // ---- batch -----------------------------------------------------------------
+// the carve stream: optionally with a different priority than the chain stream (LQRHIP_CARVE_PRIO:
+// 1 = highest, -1 = lowest, 0/unset = default)
+static hipError_t create_stream2(hipStream_t *s)
+{
+    const char *e = getenv("LQRHIP_CARVE_PRIO");
+    int mode = e ? atoi(e) : 0;
+    if (mode == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    int lo = 0, hi = 0;
+    (void) hipDeviceGetStreamPriorityRange(&lo, &hi);       // lo = least, hi = greatest priority (numerically lower)
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, mode > 0 ? hi : lo);
+}
+
 extern "C" LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n)
 {
     if (lqrhip_init() < 0 || n <= 0) return nullptr;
@@ -1765,7 +1796,7 @@ extern "C" LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n)
         carvers[i]->batch = b;
     }
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess ||
+        create_stream2(&b->stream2) != hipSuccess ||
         hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&b->ev_carved, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **) &b->d_desc, sizeof(DevCarver) * n) != hipSuccess) {
