@@ -1370,6 +1370,98 @@ __global__ __launch_bounds__(64) void k_band_update_sw(const DevCarver *cs, DpK 
 }
 
 // ---------------------------------------------------------------------------
+// E5 build_mmap, multi-CU form (delta_x == 1, no rigidity mask): trapezoid tiling of the
+// dependency cone.  One launch covers DPT_ROWS rows of every image; one WAVE per tile of
+// 192 own columns + 32 halo columns on each side (4 px per lane, lanes 8..55 own).  The wave
+// loads row y0-1 of m over own+halo, then computes DPT_ROWS rows entirely in registers (DPP
+// neighbours, no LDS, no barrier): the halo is recomputed redundantly and goes stale by one
+// pixel per row from the outside in, which is exactly what 32 columns allow for 32 rows.  Only
+// own columns are stored.  H/32 dependent launches instead of H barriers of one workgroup:
+// a 4K sweep takes ~20 x less wall time and uses the whole chip for a batch.
+// ---------------------------------------------------------------------------
+#define DPT_ROWS 32
+#define DPT_OWN 192
+template <bool LR, bool RIG>
+__global__ __launch_bounds__(64) void k_dp_tile(const DevCarver *cs, DpK p, int w, int h, int stride, int y0)
+{
+    const GCarver c = gview(cs[blockIdx.y]);
+    const int lane = threadIdx.x;
+    const float INF = __int_as_float(0x7f800000);
+    const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
+    const int own0 = blockIdx.x * DPT_OWN;                  // first own column of the tile
+    const int x0 = own0 - 32 + 4 * lane;                    // first pixel of this lane (may be < 0 or >= w)
+    const bool own = (lane >= 8 && lane < 56) && x0 < w;
+    const int nrows = min(DPT_ROWS, h - y0);
+    // clamped load offset: lanes outside the row read something valid and ignore it
+    const unsigned lo_off = (unsigned) min(max(x0, 0), stride - 4);
+    const bool lane_in = (x0 >= 0);                          // x0 is a multiple of 4: a lane is entirely in or left of the image
+
+    float mp[4];
+    if (y0 > 0) {
+        const f32x4 v = *(const GLOBAL_AS f32x4 *) (c.m + (size_t) (y0 - 1) * stride + lo_off);
+#pragma unroll
+        for (int k = 0; k < 4; k++) mp[k] = (lane_in && x0 + k < w) ? v[k] : INF;
+    }
+    constexpr int R = 8;
+    f32x4 q_e[2][R];
+    auto issue = [&](int buf, int ybase) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const unsigned ro = (unsigned) min(ybase + r, h - 1) * (unsigned) stride + lo_off;
+            q_e[buf][r] = *(const GLOBAL_AS f32x4 *) (c.en + ro);
+        }
+    };
+    issue(0, y0);
+#pragma unroll
+    for (int b4 = 0; b4 < DPT_ROWS / R; b4++) {
+        const int buf = b4 & 1;
+        if (b4 * R < nrows) {
+            if ((b4 + 1) * R < nrows) issue(buf ^ 1, y0 + (b4 + 1) * R);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int y = y0 + b4 * R + r;
+                if (b4 * R + r < nrows) {
+                    float mc[4];
+                    uint32_t lnew = 0;
+                    const f32x4 e = q_e[buf][r];
+                    if (y == 0) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) mc[k] = (lane_in && x0 + k < w) ? e[k] : INF;     // row 0: m = en
+                    } else {
+                        float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[3]), DPP_WAVE_SHR1,
+                                                                            0xf, 0xf, false));
+                        float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[0]), DPP_WAVE_SHL1,
+                                                                             0xf, 0xf, false));
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
+                            const float cc = mp[k];
+                            float rr = (k == 3) ? right : mp[k < 3 ? k + 1 : 0];
+                            if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
+                            const float best = fminf(fminf(l, cc), rr);
+                            int bdx;
+                            if (LR) { bdx = (cc == best) ? 0 : -1; bdx = (rr == best) ? 1 : bdx; }
+                            else { bdx = (cc == best) ? 0 : 1; bdx = (l == best) ? -1 : bdx; }
+                            const float nm = __fadd_rn(e[k], best);
+                            mc[k] = (lane_in && x0 + k < w) ? nm : INF;
+                            lnew |= ((uint32_t) bdx & 0xffu) << (8 * k);
+                        }
+                    }
+                    if (own) {
+                        const unsigned so = (unsigned) y * (unsigned) stride + (unsigned) x0;
+                        f32x4 t = {mc[0], mc[1], mc[2], mc[3]};
+                        *(GLOBAL_AS f32x4 *) (c.m + so) = t;
+                        *(gu32 *) (c.least + so) = lnew;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) mp[k] = mc[k];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // visibility map: seam log -> levels in the base layout (E8 update_vsmap for a
 // whole session), inflate (E14), flatten / read-out compaction (E11, E12),
 // transpose (E11)
@@ -1929,10 +2021,33 @@ extern "C" int lqrhip_emap_build(LqrHipBatch *b, const LqrHipDpParams *p, int w,
     return 0;
 }
 
+static int g_dp_tiled = -1;
+
+// E5 as H/32 dependent launches of one wave per 192-column tile (k_dp_tile)
+static int launch_dp_tiled(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
+{
+    LqrHipCarver *c0 = b->cs[0];
+    const dim3 grid((w + DPT_OWN - 1) / DPT_OWN, (unsigned) b->cs.size());
+    for (int y0 = 0; y0 < h; y0 += DPT_ROWS) {
+        if (lr) { if (k.use_rig) hipLaunchKernelGGL((k_dp_tile<true, true>), grid, dim3(64), 0, b->stream, b->d_desc, k, w, h, c0->stride, y0);
+                  else hipLaunchKernelGGL((k_dp_tile<true, false>), grid, dim3(64), 0, b->stream, b->d_desc, k, w, h, c0->stride, y0); }
+        else { if (k.use_rig) hipLaunchKernelGGL((k_dp_tile<false, true>), grid, dim3(64), 0, b->stream, b->d_desc, k, w, h, c0->stride, y0);
+               else hipLaunchKernelGGL((k_dp_tile<false, false>), grid, dim3(64), 0, b->stream, b->d_desc, k, w, h, c0->stride, y0); }
+    }
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
 template <bool UPDATE>
 static int launch_dp(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
 {
     LqrHipCarver *c0 = b->cs[0];
+    if (!UPDATE) {
+        if (g_dp_tiled < 0) { const char *e = getenv("LQRHIP_DP_TILED"); g_dp_tiled = e ? atoi(e) : 1; }
+        bool has_rigmask = false;
+        for (auto *c : b->cs) has_rigmask |= (c->rig != nullptr);
+        if (g_dp_tiled && k.delta == 1 && !has_rigmask) return launch_dp_tiled(b, k, w, h, lr);
+    }
     int pxt = (w + DP_THREADS - 1) / DP_THREADS;
     size_t lds = (size_t) 2 * ((w + 3) & ~3) * sizeof(float);
     dim3 grid((unsigned) b->cs.size()), block(DP_THREADS);
