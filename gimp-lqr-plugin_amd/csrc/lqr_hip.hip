@@ -53,6 +53,8 @@ struct DevCarver {
     float *en;
     float *m;
     int8_t *least;
+    float *m2;              // second m / back-pointer planes: output of the out-of-place tiled update,
+    int8_t *least2;         // swapped with m / least afterwards (k_swap_planes)
     float *bias;
     float *rig;
     int32_t *seam_x;
@@ -79,8 +81,8 @@ struct GCarver {
     gi32 *vs;
     gf32 *bias0, *rig0;
     gu32 *pix;
-    gf32 *en, *m;
-    gi8 *least;
+    gf32 *en, *m, *m2;
+    gi8 *least, *least2;
     gf32 *bias, *rig;
     gi32 *seam_x, *seam_log, *flags, *progress;
 };
@@ -90,6 +92,7 @@ __device__ __forceinline__ GCarver gview(const DevCarver &d)
     GCarver g;
     g.rgb0 = (gu8 *) d.rgb0; g.vs = (gi32 *) d.vs; g.bias0 = (gf32 *) d.bias0; g.rig0 = (gf32 *) d.rig0;
     g.pix = (gu32 *) d.pix; g.en = (gf32 *) d.en; g.m = (gf32 *) d.m; g.least = (gi8 *) d.least;
+    g.m2 = (gf32 *) d.m2; g.least2 = (gi8 *) d.least2;
     g.bias = (gf32 *) d.bias; g.rig = (gf32 *) d.rig;
     g.seam_x = (gi32 *) d.seam_x; g.seam_log = (gi32 *) d.seam_log; g.flags = (gi32 *) d.flags; g.progress = (gi32 *) d.progress;
     return g;
@@ -1462,6 +1465,158 @@ __global__ __launch_bounds__(64) void k_dp_tile(const DevCarver *cs, DpK p, int 
 }
 
 // ---------------------------------------------------------------------------
+// Persistent form of k_dp_tile for small batches (every tile co-resident): one launch per
+// sweep, one wave per 128-column tile + 64-px halos, blocks of 64 rows.  Instead of a kernel
+// boundary between row blocks a tile waits for its two neighbours only: each publishes "block j
+// done" on its own counter after storing the block's last row write-through (sc1), and the halo
+// columns of that row are re-read (agent-scope loads) by the neighbours.
+// UPDATE = liblqr's update_mmap keep-rule applied to every pixel (a superset of the band,
+// section 4.4), reading m / least and writing m2 / least2 (tiles overlap in their halos, so an
+// in-place update would let a tile read a neighbour's half-updated (m, least) pair); the host
+// swaps the plane pointers afterwards (k_swap_planes).
+// ---------------------------------------------------------------------------
+constexpr int DPP_HALO = 64;                    // halo columns on each side = rows per block
+constexpr int DPP_OWN = 256 - 2 * DPP_HALO;     // columns a tile owns
+constexpr int DPP_MAX_WGS = 1024;               // co-residency bound for the spin waits
+
+template <bool LR, bool RIG, bool UPDATE>
+__global__ __launch_bounds__(64) void k_dp_tile_p(const DevCarver *cs, DpK p, int w, int h, int stride, int *tile_flags)
+{
+    const GCarver c = gview(cs[blockIdx.y]);
+    gf32 *m_out = UPDATE ? c.m2 : c.m;
+    gi8 *least_out = UPDATE ? c.least2 : c.least;
+    const int ntiles = gridDim.x, tile = blockIdx.x;
+    gi32 *flags = (gi32 *) (tile_flags + (size_t) blockIdx.y * ntiles);
+    const int lane = threadIdx.x;
+    const float INF = __int_as_float(0x7f800000);
+    const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
+    const int x0 = tile * DPP_OWN - DPP_HALO + 4 * lane;    // first pixel of this lane (may be < 0 or >= w)
+    const bool own_lane = lane >= DPP_HALO / 4 && lane < 64 - DPP_HALO / 4;
+    const bool own = own_lane && x0 < w;
+    const unsigned lo_off = (unsigned) min(max(x0, 0), stride - 4);
+    const bool lane_in = (x0 >= 0);
+    bool in[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) in[k] = lane_in && x0 + k < w;
+
+    constexpr int R = 8;
+    f32x4 q_e[2][R], q_mo[2][R];
+    uint32_t q_lo[2][R];
+    auto issue = [&](int buf, int ybase) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const unsigned ro = (unsigned) min(ybase + r, h - 1) * (unsigned) stride + lo_off;
+            q_e[buf][r] = *(const GLOBAL_AS f32x4 *) (c.en + ro);
+            if (UPDATE) {
+                q_mo[buf][r] = *(const GLOBAL_AS f32x4 *) (c.m + ro);
+                q_lo[buf][r] = *(const gu32 *) (c.least + ro);
+            }
+        }
+    };
+    float mp[4] = {INF, INF, INF, INF};
+    auto batch = [&](int buf, int ybase, int ylast) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int y = ybase + r;
+            if (y < h) {
+                float mc[4];
+                uint32_t lnew = 0;
+                const f32x4 e = q_e[buf][r];
+                if (y == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) mc[k] = in[k] ? e[k] : INF;     // row 0: m = en
+                } else {
+                    const float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[3]), DPP_WAVE_SHR1,
+                                                                              0xf, 0xf, false));
+                    const float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[0]), DPP_WAVE_SHL1,
+                                                                               0xf, 0xf, false));
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
+                        const float cc = mp[k];
+                        float rr = (k == 3) ? right : mp[k < 3 ? k + 1 : 0];
+                        if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
+                        const float best = fminf(fminf(l, cc), rr);
+                        int bdx;
+                        if (LR) { bdx = (cc == best) ? 0 : -1; bdx = (rr == best) ? 1 : bdx; }
+                        else { bdx = (cc == best) ? 0 : 1; bdx = (l == best) ? -1 : bdx; }
+                        float nm = __fadd_rn(e[k], best);
+                        if (UPDATE) {
+                            // keep the stale value iff same parent and (double) fabsf(d) < 1e-5
+                            const float mo = q_mo[buf][r][k];
+                            const int lo_k = (int) (int8_t) (q_lo[buf][r] >> (8 * k));
+                            float d = fabsf(__fsub_rn(mo, nm));
+                            d = (lo_k == bdx) ? d : INF;
+                            nm = (d > 1e-5f) ? nm : mo;
+                        }
+                        mc[k] = in[k] ? nm : INF;
+                        lnew |= ((uint32_t) bdx & 0xffu) << (8 * k);
+                    }
+                }
+                if (own) {
+                    const unsigned so = (unsigned) y * (unsigned) stride + (unsigned) x0;
+                    u32x4 t = {__float_as_uint(mc[0]), __float_as_uint(mc[1]), __float_as_uint(mc[2]), __float_as_uint(mc[3])};
+                    if (y == ylast) store_sc1_x4((gu32 *) (m_out + so), t);      // the row the neighbours will read
+                    else *(GLOBAL_AS u32x4 *) (m_out + so) = t;
+                    *(gu32 *) (least_out + so) = lnew;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) mp[k] = mc[k];
+            }
+        }
+    };
+
+    const int nblk = (h + DPP_HALO - 1) / DPP_HALO;
+    issue(0, 0);
+    for (int j = 0; j < nblk; j++) {
+        const int y0 = j * DPP_HALO;
+        if (j > 0) {
+            // neighbours must have published block j-1; every spin is bounded (a tile that never shows up
+            // means the grid was not co-resident: trap, the host sees the error at its next sync)
+            for (int side = -1; side <= 1; side += 2) {
+                const int nb = tile + side;
+                if (nb < 0 || nb >= ntiles) continue;
+                int spins = 0;
+                while (__hip_atomic_load(flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < j) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1 << 24)) __builtin_trap();
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (!own_lane) {
+                // halo columns: this wave's own values there are contaminated from the tile edge inwards
+                const gf32 *mrow = m_out + (size_t) (y0 - 1) * stride;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    mp[k] = in[k] ? __hip_atomic_load(mrow + x0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
+            }
+        }
+        const int ylast = min(y0 + DPP_HALO, h) - 1;
+#pragma unroll 1
+        for (int b2 = 0; b2 < DPP_HALO / (2 * R); b2++) {
+            const int yb = y0 + b2 * 2 * R;
+            if (yb < h) {
+                issue(1, yb + R);
+                batch(0, yb, ylast);
+                issue(0, yb + 2 * R);
+                batch(1, yb + R, ylast);
+            }
+        }
+        // publish: the last row went out write-through; drain this wave's stores, then one relaxed add
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(flags + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ void k_swap_planes(DevCarver *cs, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float *m = cs[i].m; cs[i].m = cs[i].m2; cs[i].m2 = m;
+    int8_t *l = cs[i].least; cs[i].least = cs[i].least2; cs[i].least2 = l;
+}
+
+// ---------------------------------------------------------------------------
 // visibility map: seam log -> levels in the base layout (E8 update_vsmap for a
 // whole session), inflate (E14), flatten / read-out compaction (E11, E12),
 // transpose (E11)
@@ -1633,8 +1788,8 @@ struct LqrHipCarver {
     int active = 0;
     int stride = 0, wk_h = 0;
     uint32_t *pix = nullptr;
-    float *en = nullptr, *m = nullptr, *bias = nullptr, *rig = nullptr;
-    int8_t *least = nullptr;
+    float *en = nullptr, *m = nullptr, *m2 = nullptr, *bias = nullptr, *rig = nullptr;
+    int8_t *least = nullptr, *least2 = nullptr;
     int32_t *seam_x = nullptr, *seam_log = nullptr, *flags = nullptr, *progress = nullptr;
     int carve_epoch = 0;            // carve launches since `progress` was zeroed
     int log_cap = 0, log_h = 0;
@@ -1650,6 +1805,8 @@ struct LqrHipBatch {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;          // the carve of a seam runs here, concurrently with the band update
     hipEvent_t ev_ready = nullptr, ev_carved = nullptr;
+    int *tile_flags = nullptr;              // k_dp_tile_p: row blocks finished, per image and tile
+    size_t tile_flags_elems = 0;
     bool dirty = true;
 };
 
@@ -1738,6 +1895,14 @@ static void dfree(T *&p)
     p = nullptr;
 }
 
+// zero device memory and wait: hipMemset on the null stream is asynchronous for device memory and the
+// engine's streams are non-blocking, so a null-stream memset is not ordered with the kernels after it
+static hipError_t dzero(void *p, size_t bytes)
+{
+    hipError_t e = hipMemsetAsync(p, 0, bytes, g_stream0);
+    return e != hipSuccess ? e : hipStreamSynchronize(g_stream0);
+}
+
 static int batch_sync_of(LqrHipCarver *c)
 {
     LqrHipCarver *r = c->root ? c->root : c;
@@ -1753,7 +1918,7 @@ extern "C" LqrHipCarver *lqrhip_carver_create(const unsigned char *rgb, int w, i
     size_t n = (size_t) w * h;
     if (dmalloc(&c->rgb0, n * channels) || dmalloc(&c->vs, n)) { lqrhip_carver_destroy(c); return nullptr; }
     if (hipMemcpy(c->rgb0, rgb, n * channels, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(c->vs, 0, n * sizeof(int32_t)) != hipSuccess) {
+        dzero(c->vs, n * sizeof(int32_t)) != hipSuccess) {
         g_err = "upload failed";
         lqrhip_carver_destroy(c);
         return nullptr;
@@ -1763,7 +1928,7 @@ extern "C" LqrHipCarver *lqrhip_carver_create(const unsigned char *rgb, int w, i
 
 static void free_working(LqrHipCarver *c)
 {
-    dfree(c->pix); dfree(c->en); dfree(c->m); dfree(c->least); dfree(c->bias); dfree(c->rig);
+    dfree(c->pix); dfree(c->en); dfree(c->m); dfree(c->least); dfree(c->m2); dfree(c->least2); dfree(c->bias); dfree(c->rig);
     dfree(c->seam_x); dfree(c->seam_log); dfree(c->flags); dfree(c->progress);
     c->log_cap = 0;
 }
@@ -1804,12 +1969,12 @@ static int ensure_working(LqrHipCarver *c, int w, int h)
         return rc;
     if (need_bias && (rc = dmalloc(&c->bias, n))) return rc;
     if (need_rig && (rc = dmalloc(&c->rig, n))) return rc;
-    HIPCK(hipMemset(c->least, 0, n));
-    HIPCK(hipMemset(c->m, 0, n * sizeof(float)));
-    HIPCK(hipMemset(c->en, 0, n * sizeof(float)));
-    HIPCK(hipMemset(c->pix, 0, n * sizeof(uint32_t)));
-    HIPCK(hipMemset(c->flags, 0, FLAG_COUNT * sizeof(int32_t)));
-    HIPCK(hipMemset(c->progress, 0, ((size_t) h / 64 + 2) * sizeof(int32_t)));
+    HIPCK(dzero(c->least, n));
+    HIPCK(dzero(c->m, n * sizeof(float)));
+    HIPCK(dzero(c->en, n * sizeof(float)));
+    HIPCK(dzero(c->pix, n * sizeof(uint32_t)));
+    HIPCK(dzero(c->flags, FLAG_COUNT * sizeof(int32_t)));
+    HIPCK(dzero(c->progress, ((size_t) h / 64 + 2) * sizeof(int32_t)));
     c->carve_epoch = 0;
     c->stride = stride; c->wk_h = h;
     if (c->batch) c->batch->dirty = true;
@@ -1844,7 +2009,7 @@ extern "C" int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int c
     float **plane = is_rigmask ? &c->rig0 : &c->bias0;
     if (!*plane) {
         if ((rc = dmalloc(plane, n))) return rc;
-        HIPCK(hipMemset(*plane, 0, n * sizeof(float)));
+        HIPCK(dzero(*plane, n * sizeof(float)));
         if (c->batch) c->batch->dirty = true;
     }
     int wt = transposed ? c->h0 : c->w0, ht = transposed ? c->w0 : c->h0;
@@ -1906,6 +2071,7 @@ extern "C" void lqrhip_batch_destroy(LqrHipBatch *b)
     if (b->stream2) { (void) hipStreamSynchronize(b->stream2); (void) hipStreamDestroy(b->stream2); }
     if (b->ev_ready) (void) hipEventDestroy(b->ev_ready);
     if (b->ev_carved) (void) hipEventDestroy(b->ev_carved);
+    dfree(b->tile_flags);
     for (auto *c : b->cs) if (c->batch == b) c->batch = nullptr;
     if (b->d_desc) (void) hipFree(b->d_desc);
     delete b;
@@ -1922,7 +2088,7 @@ static DevCarver make_desc(const LqrHipCarver *c)
 {
     DevCarver d;
     d.rgb0 = c->rgb0; d.vs = c->vs; d.bias0 = c->bias0; d.rig0 = c->rig0;
-    d.pix = c->pix; d.en = c->en; d.m = c->m; d.least = c->least; d.bias = c->bias; d.rig = c->rig;
+    d.pix = c->pix; d.en = c->en; d.m = c->m; d.least = c->least; d.m2 = c->m2; d.least2 = c->least2; d.bias = c->bias; d.rig = c->rig;
     d.seam_x = c->seam_x; d.seam_log = c->seam_log; d.flags = c->flags; d.progress = c->progress;
     return d;
 }
@@ -2023,18 +2189,64 @@ extern "C" int lqrhip_emap_build(LqrHipBatch *b, const LqrHipDpParams *p, int w,
 
 static int g_dp_tiled = -1;
 
-// E5 as H/32 dependent launches of one wave per 192-column tile (k_dp_tile)
+// E5 as H/32 dependent launches of one wave per 192-column tile (any batch size)
 static int launch_dp_tiled(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
 {
     LqrHipCarver *c0 = b->cs[0];
     const dim3 grid((w + DPT_OWN - 1) / DPT_OWN, (unsigned) b->cs.size());
+#define LAUNCH_TILE(LRV, RIGV) hipLaunchKernelGGL((k_dp_tile<LRV, RIGV>), grid, dim3(64), 0, b->stream, b->d_desc, k, w, h, c0->stride, y0)
     for (int y0 = 0; y0 < h; y0 += DPT_ROWS) {
-        if (lr) { if (k.use_rig) hipLaunchKernelGGL((k_dp_tile<true, true>), grid, dim3(64), 0, b->stream, b->d_desc, k, w, h, c0->stride, y0);
-                  else hipLaunchKernelGGL((k_dp_tile<true, false>), grid, dim3(64), 0, b->stream, b->d_desc, k, w, h, c0->stride, y0); }
-        else { if (k.use_rig) hipLaunchKernelGGL((k_dp_tile<false, true>), grid, dim3(64), 0, b->stream, b->d_desc, k, w, h, c0->stride, y0);
-               else hipLaunchKernelGGL((k_dp_tile<false, false>), grid, dim3(64), 0, b->stream, b->d_desc, k, w, h, c0->stride, y0); }
+        if (lr) { if (k.use_rig) LAUNCH_TILE(true, true); else LAUNCH_TILE(true, false); }
+        else { if (k.use_rig) LAUNCH_TILE(false, true); else LAUNCH_TILE(false, false); }
     }
+#undef LAUNCH_TILE
     HIPCK(hipGetLastError());
+    return 0;
+}
+
+// can the persistent tiled sweep (k_dp_tile_p) take this batch?  Its tiles spin on each other, so the
+// whole grid has to be resident at once.
+static bool dp_persistent_ok(const LqrHipBatch *b, int w)
+{
+    return (size_t) ((w + DPP_OWN - 1) / DPP_OWN) * b->cs.size() <= (size_t) DPP_MAX_WGS;
+}
+
+// E5 (UPDATE = false) or the full-width form of E9 (UPDATE = true) as one persistent launch
+template <bool UPDATE>
+static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
+{
+    LqrHipCarver *c0 = b->cs[0];
+    const size_t n = b->cs.size();
+    const int ntiles = (w + DPP_OWN - 1) / DPP_OWN;
+    int rc;
+    if (b->tile_flags_elems < (size_t) ntiles * n) {
+        HIPCK(hipStreamSynchronize(b->stream));
+        dfree(b->tile_flags);
+        if ((rc = dmalloc(&b->tile_flags, (size_t) ntiles * n + 64))) return rc;
+        b->tile_flags_elems = (size_t) ntiles * n + 64;
+    }
+    if (UPDATE && !c0->m2) {
+        // second planes, allocated on first use
+        HIPCK(hipStreamSynchronize(b->stream));
+        for (auto *c : b->cs) {
+            const size_t pe = (size_t) c->stride * (c->wk_h + 1) + 1024;
+            if ((rc = dmalloc(&c->m2, pe)) || (rc = dmalloc(&c->least2, pe))) return rc;
+        }
+        b->dirty = true;
+        if ((rc = batch_upload(b))) return rc;
+    }
+    HIPCK(hipMemsetAsync(b->tile_flags, 0, (size_t) ntiles * n * sizeof(int), b->stream));
+    const dim3 grid(ntiles, (unsigned) n);
+#define LAUNCH_TILE(LRV, RIGV) hipLaunchKernelGGL((k_dp_tile_p<LRV, RIGV, UPDATE>), grid, dim3(64), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->tile_flags)
+    if (lr) { if (k.use_rig) LAUNCH_TILE(true, true); else LAUNCH_TILE(true, false); }
+    else { if (k.use_rig) LAUNCH_TILE(false, true); else LAUNCH_TILE(false, false); }
+#undef LAUNCH_TILE
+    HIPCK(hipGetLastError());
+    if (UPDATE) {
+        hipLaunchKernelGGL(k_swap_planes, dim3((unsigned) (n + 63) / 64), dim3(64), 0, b->stream, b->d_desc, (int) n);
+        HIPCK(hipGetLastError());
+        for (auto *c : b->cs) { std::swap(c->m, c->m2); std::swap(c->least, c->least2); }
+    }
     return 0;
 }
 
@@ -2046,7 +2258,7 @@ static int launch_dp(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
         if (g_dp_tiled < 0) { const char *e = getenv("LQRHIP_DP_TILED"); g_dp_tiled = e ? atoi(e) : 1; }
         bool has_rigmask = false;
         for (auto *c : b->cs) has_rigmask |= (c->rig != nullptr);
-        if (g_dp_tiled && k.delta == 1 && !has_rigmask) return launch_dp_tiled(b, k, w, h, lr);
+        if (g_dp_tiled && k.delta == 1 && !has_rigmask) return dp_persistent_ok(b, w) ? launch_dp_persistent<false>(b, k, w, h, lr) : launch_dp_tiled(b, k, w, h, lr);
     }
     int pxt = (w + DP_THREADS - 1) / DP_THREADS;
     size_t lds = (size_t) 2 * ((w + 3) & ~3) * sizeof(float);
@@ -2100,6 +2312,7 @@ static int g_band_variant = 0;
 static int g_carve_wgs = 0;          // > 0: cap on the carve kernel's workgroups (LQRHIP_CARVE_WGS)
 static int g_band_sw = 0;            // LQRHIP_BAND_SW=1: single-wave band kernel first.  Measured no faster than the
                                      // multi-wave one (a lone wave issues 1 instruction / 4 cycles: ~184 instr/row), so off
+static long long g_tiled_update_px = 2LL * 3840 * 2160 + 1;   // batches up to this many pixels use the tiled update (LQRHIP_TILED_UPDATE_PX)
 static int g_overlap = 1;            // carve || band update on two streams (LQRHIP_OVERLAP=0 disables)
 
 extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
@@ -2116,6 +2329,9 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         g_carve_wgs = cw ? atoi(cw) : 0;
         const char *sw = getenv("LQRHIP_BAND_SW");
         g_band_sw = sw ? atoi(sw) : 0;
+        const char *tu = getenv("LQRHIP_TILED_UPDATE_PX");
+        if (tu) g_tiled_update_px = atoll(tu);
+        if (g_dp_tiled < 0) { const char *dt = getenv("LQRHIP_DP_TILED"); g_dp_tiled = dt ? atoi(dt) : 1; }
         const char *ov = getenv("LQRHIP_OVERLAP");
         g_overlap = ov ? atoi(ov) : 1;
     }
@@ -2134,7 +2350,12 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     const int move_dp = (wnew > 1 && !full_rebuild) ? 1 : 0;
     bool has_rigmask = false;
     for (auto *c : b->cs) has_rigmask |= (c->rig != nullptr);
-    const bool fast_band = move_dp && g_use_band == 1 && p->delta_x == 1 && !has_rigmask && (size_t) h * sizeof(int) <= 60 * 1024;
+    // small batches: the whole chip recomputing every row (tiled full-width keep-rule sweep) beats the
+    // one-workgroup-per-image band walk, which is instruction-issue bound at ~1 ms per 4K seam; for
+    // large batches its 14 B/px of traffic would not
+    const bool tiled_update = move_dp && g_use_band == 1 && g_dp_tiled != 0 && p->delta_x == 1 && !has_rigmask &&
+                              (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px && dp_persistent_ok(b, w);
+    const bool fast_band = !tiled_update && move_dp && g_use_band == 1 && p->delta_x == 1 && !has_rigmask && (size_t) h * sizeof(int) <= 60 * 1024;
     // overlap: the bandwidth-bound carve (stream2) runs concurrently with the latency-bound band
     // update (stream), which follows it down the image chunk by chunk (progress counters)
     // (only pays when the carve is long enough to hide something: measured break-even ~8 images of 4K)
@@ -2219,6 +2440,12 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
             ProfScope ps("dp_sweep", b->stream, 9.0 * wnew * h * n);
             if ((rc = launch_dp<false>(b, k, wnew, h, leftright_next))) return rc;
         } else {
+            if (tiled_update) {
+                ProfScope ps("dp_update_tiled", b->stream, 0);
+                if ((rc = launch_dp_persistent<true>(b, k, wnew, h, leftright_next))) return rc;
+                HIPCK(hipGetLastError());
+                return 0;
+            }
             if (g_use_band) {
                 if (fast_band) {
                     launch_fast_band(0);
@@ -2346,7 +2573,7 @@ extern "C" int lqrhip_flatten(LqrHipBatch *b, int w0, int h0, int w, int level)
         if ((rc = flatten_one(c, c->vs, w0, h0, w, level, b->stream))) return rc;
         dfree(c->vs);
         if ((rc = dmalloc(&c->vs, (size_t) w * h0))) return rc;
-        HIPCK(hipMemset(c->vs, 0, (size_t) w * h0 * sizeof(int32_t)));
+        HIPCK(hipMemsetAsync(c->vs, 0, (size_t) w * h0 * sizeof(int32_t), b->stream));
         for (auto *a : c->aux) a->vs = c->vs;
     }
     b->dirty = true;
@@ -2381,7 +2608,7 @@ extern "C" int lqrhip_transpose(LqrHipBatch *b, int w, int h)
         for (auto *a : c->aux)
             if ((rc = transpose_one(a, w, h, b->stream))) return rc;
         if ((rc = transpose_one(c, w, h, b->stream))) return rc;
-        HIPCK(hipMemset(c->vs, 0, (size_t) w * h * sizeof(int32_t)));   // flat carver: all zero already
+        HIPCK(hipMemsetAsync(c->vs, 0, (size_t) w * h * sizeof(int32_t), b->stream));   // flat carver: all zero already
     }
     b->dirty = true;
     return 0;
@@ -2426,7 +2653,7 @@ extern "C" int lqrhip_mask_line_max(const unsigned char *mask, int channels, int
     size_t bytes = (size_t) width * height * channels;
     if ((rc = dmalloc(&d, bytes)) || (rc = dmalloc(&dout, 1))) return rc;
     HIPCK(hipMemcpy(d, mask, bytes, hipMemcpyHostToDevice));
-    HIPCK(hipMemset(dout, 0, sizeof(int)));
+    HIPCK(dzero(dout, sizeof(int)));
     hipLaunchKernelGGL(k_mask_line_max, dim3(n_lines), dim3(256), 0, g_stream0, d, channels, width, a0, b0, line_len, direction, dout);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(g_stream0));
