@@ -20,6 +20,7 @@
 // C arithmetic of the CPU path.  No MFMA: this is stencil + scan + shift work
 // bounded by HBM bandwidth and by the H-step dependency chains.
 #include <hip/hip_runtime.h>
+#include <utility>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -442,6 +443,123 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
                 y_top -= nrows;
             }
         }
+    }
+    if (lane == 0) { seam[0] = x; logp[0] = x; }
+}
+
+// ---------------------------------------------------------------------------
+// k_vpath1: k_vpath for delta_x == 1 with the chase made branch-free and the loads
+// made unconditional, so that the compiler can count them: in k_vpath every row
+// of the chase is guarded (`r < nrows`, two taken branches per step) and the
+// predicated chunk loads make the compiler fall back to s_waitcnt vmcnt(0) before
+// the first step of a chunk, which serialises load latency and chase.  Here rows
+// above the image read a zero dword (dx = 0) instead of being skipped, the lane
+// that records the path is written with v_writelane, and a chunk's loads stay in
+// flight under the previous chunk's chase.
+// ---------------------------------------------------------------------------
+template <int r>
+__device__ __forceinline__ void vp_step(const uint32_t reg, int &x, const int xa, int &path)
+{
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(path) : "s"(x), "n"(r));      // lane r <- column at row y_top - r
+    const int o = x - xa;
+    const uint32_t dw = (uint32_t) __builtin_amdgcn_readlane((int) reg, o >> 2);
+    int d = (int) (int8_t) (dw >> (8 * (o & 3)));
+    d = (d == LEAST_INVALID) ? 0 : d;
+    x += d;
+}
+template <int... Rs>
+__device__ __forceinline__ void vp_chase(const uint32_t (&regs)[VP_ROWS], int &x, const int xa, int &path, std::integer_sequence<int, Rs...>)
+{
+    (vp_step<Rs>(regs[Rs], x, xa, path), ...);
+}
+
+__global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, int w, int h, int stride, int lr, int log_index,
+                                                           const uint32_t *zero_page)
+{
+    const GCarver c = gview(cs[blockIdx.x]);
+    __shared__ float s_val[VPATH_THREADS];
+    __shared__ int s_idx[VPATH_THREADS];
+    const int tid = threadIdx.x;
+
+    // ---- argmin over the last row: leftmost (lr=0) / rightmost (lr=1) of equals
+    const gf32 *mrow = c.m + (size_t) (h - 1) * stride;
+    float bv = __int_as_float(0x7f800000);    // +inf
+    int bi = -1;
+    for (int x = tid; x < w; x += VPATH_THREADS) {
+        float v = mrow[x];
+        if (v < bv || (v == bv && lr)) { bv = v; bi = x; }
+    }
+    s_val[tid] = bv; s_idx[tid] = bi;
+    __syncthreads();
+    for (int s = VPATH_THREADS / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            float v2 = s_val[tid + s]; int i2 = s_idx[tid + s];
+            float v1 = s_val[tid]; int i1 = s_idx[tid];
+            bool take2;
+            if (i2 < 0) take2 = false;
+            else if (i1 < 0) take2 = true;
+            else if (v2 < v1) take2 = true;
+            else if (v2 > v1) take2 = false;
+            else take2 = lr ? (i2 > i1) : (i2 < i1);
+            if (take2) { s_val[tid] = v2; s_idx[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid >= 64) return;                       // the chase is one wave
+    int x;
+    {
+        // liblqr starts from m = 2^29: a candidate must beat it (or tie it when lr == 1)
+        const float lim = 536870912.0f;
+        float v = s_val[0]; int i = s_idx[0];
+        bool ok = (i >= 0) && (v < lim || (v == lim && lr));
+        x = __builtin_amdgcn_readfirstlane(ok ? i : 0);
+    }
+
+    // ---- backtrack
+    const int lane = tid;
+    gi32 *seam = c.seam_x;
+    gi32 *logp = c.seam_log + (size_t) log_index * h;
+    const gu32 *zero = (const gu32 *) zero_page;
+    constexpr int R = VP_ROWS;
+    uint32_t regs[2][VP_ROWS];
+    auto window_base = [&](int cx) { return (cx - 126) & ~3; };
+    auto load_chunk = [&](int b, int y_top, int xa) {
+        const int xl = xa + 4 * lane;
+        const bool ok = (xl >= 0) && (xl + 3 < stride);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int y = y_top - r;
+            // rows above row 1 and columns outside the plane read a zero dword: dx = 0
+            const gu32 *src = (ok && y >= 1) ? (const gu32 *) (c.least + (size_t) y * stride + xl) : zero;
+            regs[b][r] = *src;
+        }
+    };
+    int y_top = h - 1;
+    int xa_cur = window_base(x);
+    load_chunk(0, y_top, xa_cur);
+    while (true) {
+        {
+            const int nrows = min(R, y_top);
+            const int xa_next = window_base(x);
+            load_chunk(1, y_top - R, xa_next);                                     // in flight during the chase
+            int path = 0;
+            vp_chase(regs[0], x, xa_cur, path, std::make_integer_sequence<int, R>{});
+            if (lane < nrows) { seam[y_top - lane] = path; logp[y_top - lane] = path; }
+            xa_cur = xa_next;
+            y_top -= nrows;
+        }
+        if (y_top < 1) break;
+        {
+            const int nrows = min(R, y_top);
+            const int xa_next = window_base(x);
+            load_chunk(0, y_top - R, xa_next);
+            int path = 0;
+            vp_chase(regs[1], x, xa_cur, path, std::make_integer_sequence<int, R>{});
+            if (lane < nrows) { seam[y_top - lane] = path; logp[y_top - lane] = path; }
+            xa_cur = xa_next;
+            y_top -= nrows;
+        }
+        if (y_top < 1) break;
     }
     if (lane == 0) { seam[0] = x; logp[0] = x; }
 }
@@ -1817,6 +1935,7 @@ struct ProfRec {
 static bool g_prof = false;
 static std::map<std::string, ProfRec> g_profrec;
 static hipStream_t g_stream0 = nullptr;
+static uint32_t *g_zero_page = nullptr;     // 4 KB of zeros on the device (k_vpath1 reads it for rows above the image)
 
 extern "C" const char *lqrhip_last_error(void) { return g_err.c_str(); }
 
@@ -1834,6 +1953,9 @@ extern "C" int lqrhip_init(void)
     if (lr) dev = atoi(lr) % n;
     HIPCK(hipSetDevice(dev));
     HIPCK(hipStreamCreateWithFlags(&g_stream0, hipStreamNonBlocking));
+    HIPCK(hipMalloc((void **) &g_zero_page, 4096));
+    HIPCK(hipMemsetAsync(g_zero_page, 0, 4096, g_stream0));
+    HIPCK(hipStreamSynchronize(g_stream0));
     g_device = dev;
     return dev;
 }
@@ -2137,6 +2259,9 @@ extern "C" void lqrhip_prof_enable(int on) { g_prof = on != 0; }
 static int g_overlap_override = -1;
 // -1: LQRHIP_OVERLAP / default; 0: carve and band update back to back on one stream; 1: overlapped
 extern "C" void lqrhip_set_overlap(int mode) { g_overlap_override = mode; }
+static int g_update_mode = -1;
+// -1: by batch size (LQRHIP_TILED_UPDATE_PX); 0: band kernels; 1: tiled full-width update whenever its grid fits
+extern "C" void lqrhip_set_update_mode(int mode) { g_update_mode = mode; }
 extern "C" void lqrhip_prof_reset(void)
 {
     for (auto &kv : g_profrec) for (auto &e : kv.second.ev) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
@@ -2312,7 +2437,7 @@ static int g_band_variant = 0;
 static int g_carve_wgs = 0;          // > 0: cap on the carve kernel's workgroups (LQRHIP_CARVE_WGS)
 static int g_band_sw = 0;            // LQRHIP_BAND_SW=1: single-wave band kernel first.  Measured no faster than the
                                      // multi-wave one (a lone wave issues 1 instruction / 4 cycles: ~184 instr/row), so off
-static long long g_tiled_update_px = 2LL * 3840 * 2160 + 1;   // batches up to this many pixels use the tiled update (LQRHIP_TILED_UPDATE_PX)
+static long long g_tiled_update_px = 24LL * 3840 * 2160;   // batches up to this many pixels use the tiled update (LQRHIP_TILED_UPDATE_PX)
 static int g_overlap = 1;            // carve || band update on two streams (LQRHIP_OVERLAP=0 disables)
 
 extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
@@ -2343,8 +2468,12 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     const int stride = c0->stride;
     {
         ProfScope ps("vpath", b->stream, 0);
-        hipLaunchKernelGGL(k_vpath, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, p->delta_x,
-                           log_index);
+        if (p->delta_x == 1)
+            hipLaunchKernelGGL(k_vpath1, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index,
+                               g_zero_page);
+        else
+            hipLaunchKernelGGL(k_vpath, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, p->delta_x,
+                               log_index);
     }
     const int wnew = w - 1;
     const int move_dp = (wnew > 1 && !full_rebuild) ? 1 : 0;
@@ -2354,7 +2483,8 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     // one-workgroup-per-image band walk, which is instruction-issue bound at ~1 ms per 4K seam; for
     // large batches its 14 B/px of traffic would not
     const bool tiled_update = move_dp && g_use_band == 1 && g_dp_tiled != 0 && p->delta_x == 1 && !has_rigmask &&
-                              (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px && dp_persistent_ok(b, w);
+                              (g_update_mode < 0 ? (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px : g_update_mode == 1) &&
+                              dp_persistent_ok(b, w);
     const bool fast_band = !tiled_update && move_dp && g_use_band == 1 && p->delta_x == 1 && !has_rigmask && (size_t) h * sizeof(int) <= 60 * 1024;
     // overlap: the bandwidth-bound carve (stream2) runs concurrently with the latency-bound band
     // update (stream), which follows it down the image chunk by chunk (progress counters)

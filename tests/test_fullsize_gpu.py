@@ -21,6 +21,18 @@ import lqr_ctypes as L
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["auto", "band"], autouse=True)
+def update_mode(request, engine):
+    """Every test runs twice: with the engine's default choice of update_mmap kernel (the tiled
+    full-width sweep at these sizes) and with the band kernels the large batches use."""
+    import ctypes
+    lib = engine.lib
+    lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]
+    lib.lqrhip_set_update_mode(0 if request.param == "band" else -1)
+    yield request.param
+    lib.lqrhip_set_update_mode(-1)
+
+
 def seam_frame_positions(vm, k):
     """x position of seam k on every row, in the frame it was carved from"""
     h, w = vm.shape

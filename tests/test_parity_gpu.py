@@ -15,6 +15,18 @@ import lqr_ctypes as L
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["auto", "band"], autouse=True)
+def update_mode(request, engine):
+    """Every test runs twice: with the engine's default choice of update_mmap kernel (the tiled
+    full-width sweep at these sizes) and with the band kernels the large batches use."""
+    import ctypes
+    lib = engine.lib
+    lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]
+    lib.lqrhip_set_update_mode(0 if request.param == "band" else -1)
+    yield request.param
+    lib.lqrhip_set_update_mode(-1)
+
 ENERGY_TOLERANCE_ULP = 0      # north_star allows 1; the engine mirrors every rounding step
 
 
