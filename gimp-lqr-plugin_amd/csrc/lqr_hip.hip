@@ -21,6 +21,7 @@
 // bounded by HBM bandwidth and by the H-step dependency chains.
 #include <hip/hip_runtime.h>
 #include <utility>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1584,10 +1585,18 @@ __global__ __launch_bounds__(64) void k_dp_tile(const DevCarver *cs, DpK p, int 
 
 // ---------------------------------------------------------------------------
 // Persistent form of k_dp_tile for small batches (every tile co-resident): one launch per
-// sweep, one wave per 128-column tile + 64-px halos, blocks of 64 rows.  Instead of a kernel
+// sweep, one workgroup per 128-column tile + 64-px halos, blocks of 64 rows.  Instead of a kernel
 // boundary between row blocks a tile waits for its two neighbours only: each publishes "block j
 // done" on its own counter after storing the block's last row write-through (sc1), and the halo
 // columns of that row are re-read (agent-scope loads) by the neighbours.
+//
+// The rows of a tile are a serial chain (~0.1 us each) that consumes ~2.3 KB per row; hiding a
+// ~2 us memory round trip takes ~20 rows in flight, but one wave can have only 63 memory
+// operations outstanding (vmcnt) and each row costs five (three loads, two stores).  So the
+// workgroup is two waves that take turns: wave q computes the 16-row batches q, q+2, ... and
+// hands the last row over through LDS; while the other computes, its next batch's 48 loads are
+// in flight (one batch time ~ 2.7 us of lead).  One s_barrier per batch.
+//
 // UPDATE = liblqr's update_mmap keep-rule applied to every pixel (a superset of the band,
 // section 4.4), reading m / least and writing m2 / least2 (tiles overlap in their halos, so an
 // in-place update would let a tile read a neighbour's half-updated (m, least) pair); the host
@@ -1595,17 +1604,22 @@ __global__ __launch_bounds__(64) void k_dp_tile(const DevCarver *cs, DpK p, int 
 // ---------------------------------------------------------------------------
 constexpr int DPP_HALO = 64;                    // halo columns on each side = rows per block
 constexpr int DPP_OWN = 256 - 2 * DPP_HALO;     // columns a tile owns
+constexpr int DPP_R = 16;                       // rows per batch
+constexpr int DPP_W = 2;                        // waves taking turns
+static_assert(DPP_HALO % (DPP_R * DPP_W) == 0, "a block is a whole number of rounds");
 constexpr int DPP_MAX_WGS = 1024;               // co-residency bound for the spin waits
 
 template <bool LR, bool RIG, bool UPDATE>
-__global__ __launch_bounds__(64) void k_dp_tile_p(const DevCarver *cs, DpK p, int w, int h, int stride, int *tile_flags)
+__global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, DpK p, int w, int h, int stride, int *tile_flags)
 {
+    __shared__ f32x4 s_mp[64];                   // the row above the next batch, handed from wave to wave
     const GCarver c = gview(cs[blockIdx.y]);
     gf32 *m_out = UPDATE ? c.m2 : c.m;
     gi8 *least_out = UPDATE ? c.least2 : c.least;
     const int ntiles = gridDim.x, tile = blockIdx.x;
     gi32 *flags = (gi32 *) (tile_flags + (size_t) blockIdx.y * ntiles);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float INF = __int_as_float(0x7f800000);
     const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
     const int x0 = tile * DPP_OWN - DPP_HALO + 4 * lane;    // first pixel of this lane (may be < 0 or >= w)
@@ -1617,30 +1631,32 @@ __global__ __launch_bounds__(64) void k_dp_tile_p(const DevCarver *cs, DpK p, in
 #pragma unroll
     for (int k = 0; k < 4; k++) in[k] = lane_in && x0 + k < w;
 
-    constexpr int R = 8;
-    f32x4 q_e[2][R], q_mo[2][R];
-    uint32_t q_lo[2][R];
-    auto issue = [&](int buf, int ybase) {
+    constexpr int R = DPP_R;
+    f32x4 q_e[R], q_mo[R];
+    uint32_t q_lo[R];
+    auto issue = [&](int ybase) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const unsigned ro = (unsigned) min(ybase + r, h - 1) * (unsigned) stride + lo_off;
-            q_e[buf][r] = *(const GLOBAL_AS f32x4 *) (c.en + ro);
+            q_e[r] = *(const GLOBAL_AS f32x4 *) (c.en + ro);
             if (UPDATE) {
-                q_mo[buf][r] = *(const GLOBAL_AS f32x4 *) (c.m + ro);
-                q_lo[buf][r] = *(const gu32 *) (c.least + ro);
+                q_mo[r] = *(const GLOBAL_AS f32x4 *) (c.m + ro);
+                q_lo[r] = *(const gu32 *) (c.least + ro);
             }
         }
     };
     float mp[4] = {INF, INF, INF, INF};
-    auto batch = [&](int buf, int ybase, int ylast) {
+    // GUARD: the batch may contain row 0 or rows past the image (first and last batch of a sweep)
+    auto batch = [&](int ybase, auto guard) {
+        constexpr bool GUARD = decltype(guard)::value;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int y = ybase + r;
-            if (y < h) {
+            if (!GUARD || y < h) {
                 float mc[4];
                 uint32_t lnew = 0;
-                const f32x4 e = q_e[buf][r];
-                if (y == 0) {
+                const f32x4 e = q_e[r];
+                if (GUARD && y == 0) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) mc[k] = in[k] ? e[k] : INF;     // row 0: m = en
                 } else {
@@ -1661,8 +1677,8 @@ __global__ __launch_bounds__(64) void k_dp_tile_p(const DevCarver *cs, DpK p, in
                         float nm = __fadd_rn(e[k], best);
                         if (UPDATE) {
                             // keep the stale value iff same parent and (double) fabsf(d) < 1e-5
-                            const float mo = q_mo[buf][r][k];
-                            const int lo_k = (int) (int8_t) (q_lo[buf][r] >> (8 * k));
+                            const float mo = q_mo[r][k];
+                            const int lo_k = (int) (int8_t) (q_lo[r] >> (8 * k));
                             float d = fabsf(__fsub_rn(mo, nm));
                             d = (lo_k == bdx) ? d : INF;
                             nm = (d > 1e-5f) ? nm : mo;
@@ -1674,8 +1690,7 @@ __global__ __launch_bounds__(64) void k_dp_tile_p(const DevCarver *cs, DpK p, in
                 if (own) {
                     const unsigned so = (unsigned) y * (unsigned) stride + (unsigned) x0;
                     u32x4 t = {__float_as_uint(mc[0]), __float_as_uint(mc[1]), __float_as_uint(mc[2]), __float_as_uint(mc[3])};
-                    if (y == ylast) store_sc1_x4((gu32 *) (m_out + so), t);      // the row the neighbours will read
-                    else *(GLOBAL_AS u32x4 *) (m_out + so) = t;
+                    *(GLOBAL_AS u32x4 *) (m_out + so) = t;
                     *(gu32 *) (least_out + so) = lnew;
                 }
 #pragma unroll
@@ -1685,44 +1700,60 @@ __global__ __launch_bounds__(64) void k_dp_tile_p(const DevCarver *cs, DpK p, in
     };
 
     const int nblk = (h + DPP_HALO - 1) / DPP_HALO;
-    issue(0, 0);
+    issue(q * R);
     for (int j = 0; j < nblk; j++) {
         const int y0 = j * DPP_HALO;
-        if (j > 0) {
-            // neighbours must have published block j-1; every spin is bounded (a tile that never shows up
-            // means the grid was not co-resident: trap, the host sees the error at its next sync)
-            for (int side = -1; side <= 1; side += 2) {
-                const int nb = tile + side;
-                if (nb < 0 || nb >= ntiles) continue;
-                int spins = 0;
-                while (__hip_atomic_load(flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < j) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1 << 24)) __builtin_trap();
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (!own_lane) {
-                // halo columns: this wave's own values there are contaminated from the tile edge inwards
-                const gf32 *mrow = m_out + (size_t) (y0 - 1) * stride;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    mp[k] = in[k] ? __hip_atomic_load(mrow + x0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
-            }
-        }
         const int ylast = min(y0 + DPP_HALO, h) - 1;
 #pragma unroll 1
-        for (int b2 = 0; b2 < DPP_HALO / (2 * R); b2++) {
-            const int yb = y0 + b2 * 2 * R;
-            if (yb < h) {
-                issue(1, yb + R);
-                batch(0, yb, ylast);
-                issue(0, yb + 2 * R);
-                batch(1, yb + R, ylast);
+        for (int bb = 0; bb < DPP_HALO / R; bb++) {
+            const int yb = y0 + bb * R;
+            if ((bb & (DPP_W - 1)) == q && yb < h) {
+                if (yb > 0) {
+                    const f32x4 v = s_mp[lane];
+                    mp[0] = v[0]; mp[1] = v[1]; mp[2] = v[2]; mp[3] = v[3];
+                }
+                if (bb == 0 && j > 0) {
+                    // neighbours must have published block j-1; every spin is bounded (a tile that never shows
+                    // up means the grid was not co-resident: trap, the host sees the error at its next sync)
+                    for (int side = -1; side <= 1; side += 2) {
+                        const int nb = tile + side;
+                        if (nb < 0 || nb >= ntiles) continue;
+                        int spins = 0;
+                        while (__hip_atomic_load(flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < j) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > (1 << 24)) __builtin_trap();
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (!own_lane) {
+                        // halo columns: the tile's own values there are contaminated from the tile edge inwards
+                        const gf32 *mrow = m_out + (size_t) (y0 - 1) * stride;
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            mp[k] = in[k] ? __hip_atomic_load(mrow + x0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
+                    }
+                }
+                if (yb > 0 && yb + R <= h) batch(yb, std::false_type{});
+                else batch(yb, std::true_type{});
+                {
+                    f32x4 v = {mp[0], mp[1], mp[2], mp[3]};
+                    s_mp[lane] = v;
+                }
+                if (yb + R > ylast) {
+                    // publish: the block's last row (still in mp) goes out again write-through, for the
+                    // neighbours' halo reload; drain this wave's stores, then one relaxed add
+                    if (own) {
+                        u32x4 t = {__float_as_uint(mp[0]), __float_as_uint(mp[1]), __float_as_uint(mp[2]), __float_as_uint(mp[3])};
+                        store_sc1_x4((gu32 *) (m_out + (unsigned) ylast * (unsigned) stride + (unsigned) x0), t);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_fetch_add(flags + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                issue(yb + DPP_W * R);
             }
+            // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. every wave's prefetch
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        // publish: the last row went out write-through; drain this wave's stores, then one relaxed add
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(flags + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -2362,7 +2393,7 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
     }
     HIPCK(hipMemsetAsync(b->tile_flags, 0, (size_t) ntiles * n * sizeof(int), b->stream));
     const dim3 grid(ntiles, (unsigned) n);
-#define LAUNCH_TILE(LRV, RIGV) hipLaunchKernelGGL((k_dp_tile_p<LRV, RIGV, UPDATE>), grid, dim3(64), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->tile_flags)
+#define LAUNCH_TILE(LRV, RIGV) hipLaunchKernelGGL((k_dp_tile_p<LRV, RIGV, UPDATE>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->tile_flags)
     if (lr) { if (k.use_rig) LAUNCH_TILE(true, true); else LAUNCH_TILE(true, false); }
     else { if (k.use_rig) LAUNCH_TILE(false, true); else LAUNCH_TILE(false, false); }
 #undef LAUNCH_TILE
