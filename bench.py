@@ -194,7 +194,8 @@ def main():
     # ---- the roofline kernel in isolation: in the timed region k_carve runs concurrently with the
     # band update (that is what makes the step faster), which stretches its launch time; one extra
     # untimed step with the two kernels back to back gives the kernel's own bandwidth
-    if roofline and nimg > 1 and rank == 0 and os.environ.get("LQRHIP_OVERLAP", "1") != "0":
+    # (only with LQRHIP_BAND_TW=0: the default band kernel runs after a plain carve, nothing concurrent)
+    if roofline and nimg > 1 and rank == 0 and os.environ.get("LQRHIP_BAND_TW", "1") == "0" and os.environ.get("LQRHIP_OVERLAP", "1") != "0":
         extra = new_carvers()
         lib.lqrhip_set_overlap(0)
         lib.lqrhip_prof_reset(); lib.lqrhip_prof_enable(1)

@@ -1289,6 +1289,276 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
 }
 
 // ---------------------------------------------------------------------------
+// E9 update_mmap, band form, "trapezoid waves" (delta_x == 1, no rigidity mask).
+//
+// k_band_update_mw pays one s_barrier and one LDS exchange per ROW (~0.49 us per row, of which the
+// recompute itself is a third).  Here the waves of a window exchange once per BATCH of 16 rows:
+// a slot is 256 columns (4 px per lane) of which the middle 224 are its own and 16 on each side
+// are halo, recomputed redundantly from the same inputs as the neighbouring slot does -- after r
+// rows the outer r halo columns are wrong, the own columns never are.  At a batch boundary every
+// slot leaves the last row of its own columns in LDS (s_row) and picks up own + halo from there.
+// Each slot is served by two waves that take turns batch by batch (as in k_dp_tile_p): while one
+// computes, the other's 48 loads for the next batch are in flight.
+//
+// In place: a slot's halo columns are its neighbour's own columns, which the neighbour overwrites.
+// A wave therefore waits for its prefetched batch BEFORE the barrier that opens that batch; nobody
+// stores rows of a batch before that barrier.
+//
+// As in k_band_update_mw there is no band bookkeeping (section 4.4: any superset of the pixels with
+// changed inputs gives liblqr's memory): a slot recomputes a batch iff the pixels changed on the
+// row above the batch, or touched by the carve on the batch's rows, are within 16 columns of it.
+// The window (NW slots) is re-centred when those pixels come within 16 columns of its ends; if
+// they do not fit the kernel records the row in flags[FLAG_OVF_ROW] and the full-width sweep
+// finishes from there.
+// ---------------------------------------------------------------------------
+constexpr int TW_R = 16;                     // rows per batch = halo columns
+constexpr int TW_OWN = 256 - 2 * TW_R;       // own columns per slot
+
+template <int NW, bool LR, bool RIG>
+__global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs, DpK p, int w, int h, int stride)
+{
+    constexpr int R = TW_R, OWN = TW_OWN, WIN = NW * OWN, NT = 128 * NW;
+    const GCarver c = gview(cs[blockIdx.x]);
+    extern __shared__ int s_tw[];                          // [2h]: per row, per batch-starting-at-row touch ranges
+    int *s_touch = s_tw, *s_touchR = s_tw + h;
+    __shared__ __attribute__((aligned(16))) float s_row[WIN + 2 * R];     // m of the last finished row over [B-R, B+WIN+R)
+    __shared__ int s_rec[2][NW][2];                        // [batch parity][slot] {lo, hi}: px changed on that row (lo > hi: none)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef TW_MAP_B
+    const int slot = wv / 2, par_w = wv % 2;
+#else
+    const int slot = wv % NW, par_w = wv / NW;             // the two waves of a slot sit on the same SIMD
+#endif
+    const float INF = __int_as_float(0x7f800000);
+    const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
+
+    // pixels of row y whose inputs the carve changed (see k_band_update_mw), then the union over the
+    // 16 rows of a batch starting at y
+    for (int y = tid; y < h; y += NT) {
+        const int v0 = c.seam_x[y], vm = c.seam_x[max(y - 1, 0)], vp = c.seam_x[min(y + 1, h - 1)];
+        const int t0 = max(min(min(v0, vm), vp) - 2, 0), t1 = min(max(max(v0, vm), vp) + 1, w - 1);
+        s_touch[y] = t0 | (t1 << 16);
+    }
+    {   // row 0: m = en on liblqr's interval
+        const int v0 = c.seam_x[0], vp = c.seam_x[min(1, h - 1)];
+        int lo = v0, hi = v0 - 1;
+        if (p.radius) { lo = min(v0, vp) - 1; hi = max(v0, vp); }
+        const int a = max(lo, 0), b = min(hi, w - 1);
+        for (int x = a + tid; x <= b; x += NT) c.m[x] = c.en[x];
+    }
+    __syncthreads();
+    for (int y = tid; y < h; y += NT) {
+        int t0 = 0xffff, t1 = 0;
+        for (int r = 0; r < R; r++) {
+            const int t = s_touch[min(y + r, h - 1)];
+            t0 = min(t0, t & 0xffff); t1 = max(t1, t >> 16);
+        }
+        s_touchR[y] = t0 | (t1 << 16);
+    }
+    __syncthreads();
+    if (h < 2) { if (tid == 0) c.flags[FLAG_OVF_ROW] = h; return; }
+
+    f32x4 q_e[R], q_mo[R];
+    uint32_t q_lo[R];
+    int B = 0;
+    auto issue = [&](int ybase) {
+        const int x0 = B + OWN * slot - R + 4 * lane;
+        const unsigned lo_off = (unsigned) min(max(x0, 0), stride - 4);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const unsigned ro = (unsigned) min(ybase + r, h - 1) * (unsigned) stride + lo_off;
+            q_e[r] = *(const GLOBAL_AS f32x4 *) (c.en + ro);
+            q_mo[r] = *(const GLOBAL_AS f32x4 *) (c.m + ro);
+            q_lo[r] = *(const gu32 *) (c.least + ro);
+        }
+    };
+    // make the compiler wait for this wave's prefetched batch here
+    auto landed = [&]() {
+#pragma unroll
+        for (int r = 0; r < R; r++) asm volatile("" ::"v"(q_e[r]), "v"(q_mo[r]), "v"(q_lo[r]));
+    };
+
+#ifdef TW_STATS
+    long long t_cmp = 0, t_land = 0, t_bar = 0, t_reb = 0, n_bat = 0, n_reb = 0, n_act = 0; const long long t_begin = __builtin_readcyclecounter();
+#endif
+    int y = 1, ovf = h, kpar = 0;
+    int dlo = 1 << 30, dhi = -1;             // px changed on the last finished row (absolute x)
+    bool have_window = false, force_active = false, just_rebased = false;
+    while (y < h) {
+        // ---- does the window hold the next batch?  (identical decision in every wave)
+        const int t = s_touchR[y];
+        int lo = t & 0xffff, hi = t >> 16;
+        if (dhi >= dlo) { lo = min(lo, dlo - 1); hi = max(hi, dhi + 1); }
+        lo = max(lo, 0); hi = min(hi, w - 1);
+        const bool fits = have_window && (B == 0 || lo - R >= B) && (B + WIN >= w || hi + R <= B + WIN - 1);
+        int y_issue = -1;                    // batch this wave prefetches at the end of the iteration (one issue site:
+                                             // a second one makes the register allocator spill the staging rows)
+#ifdef TW_STATS
+        const long long ts0 = __builtin_readcyclecounter();
+#endif
+        if (!fits) {
+            if (just_rebased || (hi - lo + 1 + 2 * R + 8 > WIN && WIN < w)) { ovf = y; break; }
+            int nb = (((lo + hi) >> 1) - WIN / 2) & ~3;
+            nb = max(0, min(nb, (w - WIN + 3) & ~3));
+            B = __builtin_amdgcn_readfirstlane(nb);
+            have_window = true;
+            // rows < y were stored by this workgroup: make them visible, then reload the row above
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            {
+                const gf32 *mrow = c.m + (size_t) (y - 1) * stride;
+                for (int i = tid; i < WIN + 2 * R; i += NT) {
+                    const int x = B - R + i;
+                    s_row[i] = (x >= 0 && x < w) ? __hip_atomic_load(mrow + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
+                }
+            }
+            kpar = 0;
+            force_active = true;             // every slot recomputes once: trivially a superset
+            just_rebased = true;
+            y_issue = y + par_w * R;
+        } else {
+        just_rebased = false;
+        const int x0 = B + OWN * slot - R + 4 * lane;
+        const int own_lo = B + OWN * slot, own_hi = own_lo + OWN - 1;
+        const bool own_lane = lane >= R / 4 && lane < 64 - R / 4;
+#ifdef TW_STATS
+        n_bat++;
+#endif
+        if (par_w == kpar) {
+            const bool active = force_active || (lo - R <= own_hi && hi + R >= own_lo);
+            bool in[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) in[k] = (x0 + k >= 0) && (x0 + k < w);
+            float mp[4];
+            {
+                const f32x4 v = *(const f32x4 *) (s_row + OWN * slot + 4 * lane);
+                mp[0] = v[0]; mp[1] = v[1]; mp[2] = v[2]; mp[3] = v[3];
+            }
+            int rlo = 1 << 30, rhi = -1;
+            const int nrows = min(R, h - y);
+            // this wave's batch landed an iteration ago; saying so here keeps the compiler from counting
+            // vmcnt down through the rows, which would make the later rows wait for the earlier rows' stores
+            landed();
+            if (active) {
+                const bool own = own_lane && x0 < w;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if (r < nrows) {
+                        const int yy = y + r;
+                        float mc[4];
+                        uint32_t lnew = 0;
+                        unsigned long long chm[4];
+                        const f32x4 e = q_e[r];
+                        const float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[3]), DPP_WAVE_SHR1,
+                                                                                  0xf, 0xf, false));
+                        const float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[0]), DPP_WAVE_SHL1,
+                                                                                   0xf, 0xf, false));
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
+                            const float cc = mp[k];
+                            float rr = (k == 3) ? right : mp[k < 3 ? k + 1 : 0];
+                            if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
+                            const float best = fminf(fminf(l, cc), rr);
+                            int bdx;
+                            if (LR) { bdx = (cc == best) ? 0 : -1; bdx = (rr == best) ? 1 : bdx; }
+                            else { bdx = (cc == best) ? 0 : 1; bdx = (l == best) ? -1 : bdx; }
+                            float nm = __fadd_rn(e[k], best);
+                            // keep the stale value iff same parent and (double) fabsf(d) < 1e-5
+                            const float mo = q_mo[r][k];
+                            const int lo_k = (int) (int8_t) (q_lo[r] >> (8 * k));
+                            float d = fabsf(__fsub_rn(mo, nm));
+                            d = (lo_k == bdx) ? d : INF;
+                            const bool ch = d > 1e-5f;
+                            nm = ch ? nm : mo;
+                            mc[k] = in[k] ? nm : INF;
+                            lnew |= ((uint32_t) bdx & 0xffu) << (8 * k);
+                            if (r == R - 1) chm[k] = __ballot(ch && in[k] && own_lane);
+                        }
+                        if (own) {
+                            const unsigned so = (unsigned) yy * (unsigned) stride + (unsigned) x0;
+                            u32x4 tv = {__float_as_uint(mc[0]), __float_as_uint(mc[1]), __float_as_uint(mc[2]), __float_as_uint(mc[3])};
+                            *(GLOBAL_AS u32x4 *) (c.m + so) = tv;
+                            *(gu32 *) (c.least + so) = lnew;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) mp[k] = mc[k];
+                        if (r == R - 1) {
+                            // extent of the changes on the batch's last row (own columns)
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                if (chm[k]) {
+                                    const int first = __builtin_ctzll(chm[k]), last = 63 - __builtin_clzll(chm[k]);
+                                    rlo = min(rlo, B + OWN * slot - R + 4 * first + k);
+                                    rhi = max(rhi, B + OWN * slot - R + 4 * last + k);
+                                }
+                            }
+                        }
+                    }
+                }
+            } else if (nrows == R) {
+                // nothing can change in this slot during the batch: its last row is what memory holds
+#pragma unroll
+                for (int k = 0; k < 4; k++) mp[k] = in[k] ? q_mo[R - 1][k] : INF;
+            }
+            if (nrows == R) {
+                // hand the last row over: own columns, and at the window's ends the halo as memory has it
+                f32x4 v = {mp[0], mp[1], mp[2], mp[3]};
+                const bool edge_halo = (slot == 0 && lane < R / 4) || (slot == NW - 1 && lane >= 64 - R / 4);
+                if (edge_halo) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[k] = in[k] ? q_mo[R - 1][k] : INF;
+                }
+                if (own_lane || edge_halo) *(f32x4 *) (s_row + OWN * slot + 4 * lane) = v;
+                if (lane == 0) { s_rec[kpar][slot][0] = rlo; s_rec[kpar][slot][1] = rhi; }
+                y_issue = y + 2 * R;
+            }
+#ifdef TW_STATS
+            t_cmp += __builtin_readcyclecounter() - ts0; n_act += active;
+#endif
+        } else {
+            landed();
+#ifdef TW_STATS
+            t_land += __builtin_readcyclecounter() - ts0;
+#endif
+        }
+#ifdef TW_STATS
+        const long long tb0 = __builtin_readcyclecounter();
+#endif
+        // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. the prefetch
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            int a = 1 << 30, b = -1;
+#pragma unroll
+            for (int v = 0; v < NW; v++) { a = min(a, s_rec[kpar][v][0]); b = max(b, s_rec[kpar][v][1]); }
+            dlo = __builtin_amdgcn_readfirstlane(a);
+            dhi = __builtin_amdgcn_readfirstlane(b);
+        }
+#ifdef TW_STATS
+        t_bar += __builtin_readcyclecounter() - tb0;
+#endif
+        y += R;
+        kpar ^= 1;
+        force_active = false;
+        }
+        if (y_issue >= 0) issue(y_issue);
+        if (just_rebased) {
+            landed();                        // before anybody stores rows >= y
+            __syncthreads();
+#ifdef TW_STATS
+            t_reb += __builtin_readcyclecounter() - ts0; n_reb++;
+#endif
+        }
+    }
+    if (tid == 0) c.flags[FLAG_OVF_ROW] = ovf;
+#ifdef TW_STATS
+    if (lane == 0 && blockIdx.x == 0 && (wv == 1 || wv == NW + 1)) printf("tw wave %d: total %lld, batches %lld (active %lld), rebases %lld; cycles compute %lld, landed-wait %lld, barrier+rec %lld, rebase %lld; ovf %d\n", wv, (long long) (__builtin_readcyclecounter() - t_begin), n_bat, n_act, n_reb, t_cmp, t_land, t_bar, t_reb, ovf);
+#endif
+}
+
+// ---------------------------------------------------------------------------
 // E9 update_mmap, delta_x == 1, single-wave form: ONE wave per image recomputes a
 // 512-pixel window (8 consecutive pixels per lane) on every row -- by section 4.4 of
 // DESIGN.md any superset of the changed-input pixels gives liblqr's result, and
@@ -2291,7 +2561,8 @@ static int g_overlap_override = -1;
 // -1: LQRHIP_OVERLAP / default; 0: carve and band update back to back on one stream; 1: overlapped
 extern "C" void lqrhip_set_overlap(int mode) { g_overlap_override = mode; }
 static int g_update_mode = -1;
-// -1: by batch size (LQRHIP_TILED_UPDATE_PX); 0: band kernels; 1: tiled full-width update whenever its grid fits
+// -1: by batch size (LQRHIP_TILED_UPDATE_PX); 0: band kernel (k_band_update_tw); 1: tiled full-width update whenever its
+// grid fits; 2: the older band kernel (k_band_update_mw, overlapped with the carve for large batches)
 extern "C" void lqrhip_set_update_mode(int mode) { g_update_mode = mode; }
 extern "C" void lqrhip_prof_reset(void)
 {
@@ -2466,9 +2737,10 @@ static int frozen_catchup(LqrHipBatch *b, int to, int w_at_to, int h)
 static int g_use_band = -1;
 static int g_band_variant = 0;
 static int g_carve_wgs = 0;          // > 0: cap on the carve kernel's workgroups (LQRHIP_CARVE_WGS)
+static int g_band_tw = 1;            // LQRHIP_BAND_TW=0: k_band_update_mw (+ carve overlap) instead of k_band_update_tw
 static int g_band_sw = 0;            // LQRHIP_BAND_SW=1: single-wave band kernel first.  Measured no faster than the
                                      // multi-wave one (a lone wave issues 1 instruction / 4 cycles: ~184 instr/row), so off
-static long long g_tiled_update_px = 24LL * 3840 * 2160;   // batches up to this many pixels use the tiled update (LQRHIP_TILED_UPDATE_PX)
+static long long g_tiled_update_px = 20LL * 3840 * 2160;   // batches up to this many pixels use the tiled update (LQRHIP_TILED_UPDATE_PX)
 static int g_overlap = 1;            // carve || band update on two streams (LQRHIP_OVERLAP=0 disables)
 
 extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
@@ -2485,6 +2757,8 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         g_carve_wgs = cw ? atoi(cw) : 0;
         const char *sw = getenv("LQRHIP_BAND_SW");
         g_band_sw = sw ? atoi(sw) : 0;
+        const char *tw = getenv("LQRHIP_BAND_TW");
+        g_band_tw = tw ? atoi(tw) : 1;
         const char *tu = getenv("LQRHIP_TILED_UPDATE_PX");
         if (tu) g_tiled_update_px = atoll(tu);
         if (g_dp_tiled < 0) { const char *dt = getenv("LQRHIP_DP_TILED"); g_dp_tiled = dt ? atoi(dt) : 1; }
@@ -2520,7 +2794,11 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     // overlap: the bandwidth-bound carve (stream2) runs concurrently with the latency-bound band
     // update (stream), which follows it down the image chunk by chunk (progress counters)
     // (only pays when the carve is long enough to hide something: measured break-even ~8 images of 4K)
-    const bool overlap = fast_band && (g_overlap_override >= 0 ? g_overlap_override : g_overlap) && (size_t) n * (size_t) w * (size_t) h >= (size_t) 12 * 3840 * 2160;
+    // the trapezoid-wave band kernel (default) is fast enough that hiding it under a slower, signalling
+    // carve no longer pays: it runs after the plain carve.  LQRHIP_BAND_TW=0 brings back
+    // k_band_update_mw and the overlap.
+    const bool band_tw = fast_band && g_band_tw && g_update_mode != 2 && (size_t) 2 * h * sizeof(int) <= 64 * 1024 && (g_overlap_override < 1);
+    const bool overlap = fast_band && !band_tw && (g_overlap_override >= 0 ? g_overlap_override : g_overlap) && (size_t) n * (size_t) w * (size_t) h >= (size_t) 12 * 3840 * 2160;
     const int gate = c0->carve_epoch + 1;
 
     auto launch_emap_update = [&](int pre_shift) -> int {
@@ -2549,6 +2827,16 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         }
     };
     auto launch_fast_band = [&](int gate_arg) {
+        if (band_tw) {
+            ProfScope ps("band_update", b->stream, 0);
+#define LAUNCH_TW(NWV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_tw<NWV, LRV, RIGV>), dim3(n), dim3(128 * NWV), (size_t) 2 * h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride)
+#define LAUNCH_TW_N(LRV, RIGV) do { if (wnew > 4200) LAUNCH_TW(8, LRV, RIGV); else LAUNCH_TW(4, LRV, RIGV); } while (0)
+            if (leftright_next) { if (p->use_rigidity) LAUNCH_TW_N(true, true); else LAUNCH_TW_N(true, false); }
+            else { if (p->use_rigidity) LAUNCH_TW_N(false, true); else LAUNCH_TW_N(false, false); }
+#undef LAUNCH_TW_N
+#undef LAUNCH_TW
+            return;
+        }
         const int resume = g_band_sw ? 1 : 0;
         if (g_band_sw) {
             // single-wave kernel first; what it cannot hold (changes wider than its 512-px window) is

@@ -122,8 +122,9 @@ int lqrhip_read_working(LqrHipCarver *c, int w, int h, float *en, float *m, int 
 void lqrhip_prof_enable(int on);
 /* -1 default (LQRHIP_OVERLAP env, on for large batches), 0 carve and band update back to back, 1 overlapped */
 void lqrhip_set_overlap(int mode);
-/* how E9 (update_mmap) runs: -1 by batch size (tiled full-width keep-rule sweep up to ~24 4K images, band
- * kernels above), 0 band kernels always, 1 tiled sweep whenever its grid fits the device */
+/* how E9 (update_mmap) runs: -1 by batch size (tiled full-width keep-rule sweep up to ~20 4K images, the band
+ * kernel k_band_update_tw above), 0 band kernel always, 1 tiled sweep whenever its grid fits the device,
+ * 2 the older band kernel k_band_update_mw (overlapped with the carve for large batches) */
 void lqrhip_set_update_mode(int mode);
 void lqrhip_prof_reset(void);
 int lqrhip_prof_get(const char *kernel, double *ms_total, long long *launches, double *bytes_total);

@@ -1,9 +1,9 @@
 #!/bin/bash
-# time single4k with alternative engine builds (variants/*.so swapped in for the in-tree library)
+# time a workload with alternative engine builds (variants/*.so swapped in for the in-tree library)
 pp='import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], {k:(round(v["ms"],1),v["launches"]) for k,v in d["kernels_ms"].items()})'
 cp gimp-lqr-plugin_amd/liblqr-hip.so /tmp/orig.so
 for v in "$@"; do
   echo "== $v"; cp variants/$v gimp-lqr-plugin_amd/liblqr-hip.so
-  timeout -s KILL 120 python bench.py --workload single4k --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "$pp"
+  LQRHIP_TILED_UPDATE_PX=0 timeout -s KILL 120 python bench.py --images-per-gpu 8 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "$pp"
 done
 cp /tmp/orig.so gimp-lqr-plugin_amd/liblqr-hip.so

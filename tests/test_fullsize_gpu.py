@@ -21,14 +21,15 @@ import lqr_ctypes as L
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "band"], autouse=True)
+@pytest.fixture(params=["auto", "band", "band-mw"], autouse=True)
 def update_mode(request, engine):
-    """Every test runs twice: with the engine's default choice of update_mmap kernel (the tiled
-    full-width sweep at these sizes) and with the band kernels the large batches use."""
+    """Every test runs three times: with the engine's default choice of update_mmap kernel (the tiled
+    full-width sweep at these sizes), with the band kernel the large batches use, and with the
+    older band kernel kept behind LQRHIP_BAND_TW=0."""
     import ctypes
     lib = engine.lib
     lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]
-    lib.lqrhip_set_update_mode(0 if request.param == "band" else -1)
+    lib.lqrhip_set_update_mode({"auto": -1, "band": 0, "band-mw": 2}[request.param])
     yield request.param
     lib.lqrhip_set_update_mode(-1)
 
