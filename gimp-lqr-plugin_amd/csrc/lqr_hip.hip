@@ -1441,11 +1441,13 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
             // this wave's batch landed an iteration ago; saying so here keeps the compiler from counting
             // vmcnt down through the rows, which would make the later rows wait for the earlier rows' stores
             landed();
-            if (active) {
+            // GUARD: the image ends inside the batch (last batch of a sweep only)
+            auto rows = [&](auto guard) {
+                constexpr bool GUARD = decltype(guard)::value;
                 const bool own = own_lane && x0 < w;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    if (r < nrows) {
+                    if (!GUARD || r < nrows) {
                         const int yy = y + r;
                         float mc[4];
                         uint32_t lnew = 0;
@@ -1498,7 +1500,9 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
                         }
                     }
                 }
-            } else if (nrows == R) {
+            };
+            if (active) { if (nrows == R) rows(std::false_type{}); else rows(std::true_type{}); }
+            else if (nrows == R) {
                 // nothing can change in this slot during the batch: its last row is what memory holds
 #pragma unroll
                 for (int k = 0; k < 4; k++) mp[k] = in[k] ? q_mo[R - 1][k] : INF;
