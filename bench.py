@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--workload", default="batch4k", choices=["batch4k", "single4k", "fhd", "8k"])
     ap.add_argument("--images-per-gpu", type=int, default=64)
     ap.add_argument("--seams", type=int, default=None)
+    ap.add_argument("--kernel-times", action="store_true",
+                    help="HIP-event time every kernel of the seam loop (kernels_ms), not only k_carve; costs ~2.5 %% of the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--switch-freq", type=int, default=2, help="lqr side switch frequency (plug-in: 2, render.c:237)")
@@ -154,7 +156,7 @@ def main():
     for k in range(args.warmup):
         run_step(steps[k])
     lib.lqrhip_prof_reset()
-    lib.lqrhip_prof_enable(1)
+    lib.lqrhip_prof_enable(1 if args.kernel_times else 2)
     barrier(); sync()
     t0 = time.perf_counter()
     for k in range(args.warmup, total_steps):

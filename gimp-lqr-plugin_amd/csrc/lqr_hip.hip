@@ -619,27 +619,42 @@ __device__ __forceinline__ void shift_row_least(gi8 *row, int v, int vprev, int 
     int start = (y > 0) ? min(v, vprev - delta) : v;
     if (start < 0) start = 0;
     gu32 *row32 = (gu32 *) row;
-    for (int base = start & ~3; base < wnew; base += 256) {
-        int x = base + lane * 4;
-        if (x < wnew) {
-            uint32_t a = row32[x >> 2], nx = row32[(x >> 2) + 1];
-            uint64_t both = ((uint64_t) nx << 32) | a;
-            uint32_t o = 0;
+    // as shift_row_u32: 4 chunks of 256 px (one dword per lane) in flight, all loads of a group before
+    // its stores; the dword that follows a lane's is the next lane's (DPP)
+    for (int base = start & ~3; base < wnew; base += 1024) {
+        uint32_t a[4];
+        uint32_t tail = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int xx = x + j;
-                bool right = (xx >= v);
-                int dx = (int8_t) (both >> (8 * (j + (right ? 1 : 0))));
-                int xo = right ? xx + 1 : xx;
-                if (y > 0 && dx != LEAST_INVALID) {
-                    int q = xo + dx;
-                    if (q == vprev) dx = LEAST_INVALID;            // parent was the carved pixel
-                    else dx = q - (q > vprev ? 1 : 0) - xx;
+        for (int u = 0; u < 4; u++) {
+            const int x = base + u * 256 + lane * 4;
+            a[u] = (x <= wnew) ? row32[x >> 2] : 0u;
+        }
+        if (lane == 63 && base + 1024 <= wnew) tail = row32[(base + 1024) >> 2];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int x = base + u * 256 + lane * 4;
+            const uint32_t first_next = (u < 3) ? (uint32_t) __builtin_amdgcn_readlane((int) a[u < 3 ? u + 1 : 3], 0) : 0u;
+            const uint32_t lane63 = (u < 3) ? first_next : tail;
+            const uint32_t nx = (uint32_t) __builtin_amdgcn_update_dpp((int) lane63, (int) a[u], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+            if (x < wnew) {
+                const uint64_t both = ((uint64_t) nx << 32) | a[u];
+                uint32_t o = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    int xx = x + j;
+                    bool right = (xx >= v);
+                    int dx = (int8_t) (both >> (8 * (j + (right ? 1 : 0))));
+                    int xo = right ? xx + 1 : xx;
+                    if (y > 0 && dx != LEAST_INVALID) {
+                        int q = xo + dx;
+                        if (q == vprev) dx = LEAST_INVALID;            // parent was the carved pixel
+                        else dx = q - (q > vprev ? 1 : 0) - xx;
+                    }
+                    o |= (uint32_t) (uint8_t) (int8_t) dx << (8 * j);
                 }
-                o |= (uint32_t) (uint8_t) (int8_t) dx << (8 * j);
+                if (SC1) store_sc1_x1(row32 + (x >> 2), o);
+                else row32[x >> 2] = o;
             }
-            if (SC1) store_sc1_x1(row32 + (x >> 2), o);
-            else row32[x >> 2] = o;
         }
     }
 }
@@ -1881,7 +1896,7 @@ constexpr int DPP_OWN = 256 - 2 * DPP_HALO;     // columns a tile owns
 constexpr int DPP_R = 16;                       // rows per batch
 constexpr int DPP_W = 2;                        // waves taking turns
 static_assert(DPP_HALO % (DPP_R * DPP_W) == 0, "a block is a whole number of rounds");
-constexpr int DPP_MAX_WGS = 1024;               // co-residency bound for the spin waits
+constexpr int DPP_MAX_WGS = 768;                // co-residency bound for the spin waits (the device holds 1024 of these workgroups)
 
 template <bool LR, bool RIG, bool UPDATE>
 __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, DpK p, int w, int h, int stride, int *tile_flags)
@@ -2229,6 +2244,10 @@ struct LqrHipBatch {
     hipStream_t stream2 = nullptr;          // the carve of a seam runs here, concurrently with the band update
     hipEvent_t ev_ready = nullptr, ev_carved = nullptr;
     int *tile_flags = nullptr;              // k_dp_tile_p: row blocks finished, per image and tile
+    // pipelined sub-batches (LQRHIP_PIPE): chain kernels and carves on CU-masked streams of their own
+    hipStream_t s_chain = nullptr, s_carve = nullptr;
+    hipEvent_t ev_main = nullptr, ev_done = nullptr;
+    bool pipe_now = false;
     size_t tile_flags_elems = 0;
     bool dirty = true;
 };
@@ -2237,7 +2256,7 @@ struct ProfRec {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     double bytes = 0;
 };
-static bool g_prof = false;
+static int g_prof = 0;                 // 0 off, 1 every kernel, 2 the roofline kernel (k_carve) only
 static std::map<std::string, ProfRec> g_profrec;
 static hipStream_t g_stream0 = nullptr;
 static uint32_t *g_zero_page = nullptr;     // 4 KB of zeros on the device (k_vpath1 reads it for rows above the image)
@@ -2499,6 +2518,10 @@ extern "C" void lqrhip_batch_destroy(LqrHipBatch *b)
     if (b->ev_ready) (void) hipEventDestroy(b->ev_ready);
     if (b->ev_carved) (void) hipEventDestroy(b->ev_carved);
     dfree(b->tile_flags);
+    if (b->s_chain) { (void) hipStreamSynchronize(b->s_chain); (void) hipStreamDestroy(b->s_chain); }
+    if (b->s_carve) { (void) hipStreamSynchronize(b->s_carve); (void) hipStreamDestroy(b->s_carve); }
+    if (b->ev_main) (void) hipEventDestroy(b->ev_main);
+    if (b->ev_done) (void) hipEventDestroy(b->ev_done);
     for (auto *c : b->cs) if (c->batch == b) c->batch = nullptr;
     if (b->d_desc) (void) hipFree(b->d_desc);
     delete b;
@@ -2546,7 +2569,9 @@ struct ProfScope {
     hipStream_t s;
     ProfScope(const char *name, hipStream_t stream, double bytes) : s(stream)
     {
-        if (!g_prof) return;
+        // every timed scope costs ~10 us of queue time (two event packets): mode 2 keeps that to the one
+        // kernel whose launch time the bench line needs
+        if (!g_prof || (g_prof == 2 && strcmp(name, "carve") != 0)) return;
         rec = &g_profrec[name];
         rec->bytes += bytes;
         (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
@@ -2560,7 +2585,7 @@ struct ProfScope {
     }
 };
 
-extern "C" void lqrhip_prof_enable(int on) { g_prof = on != 0; }
+extern "C" void lqrhip_prof_enable(int on) { g_prof = on; }
 static int g_overlap_override = -1;
 // -1: LQRHIP_OVERLAP / default; 0: carve and band update back to back on one stream; 1: overlapped
 extern "C" void lqrhip_set_overlap(int mode) { g_overlap_override = mode; }
@@ -2747,8 +2772,8 @@ static int g_band_sw = 0;            // LQRHIP_BAND_SW=1: single-wave band kerne
 static long long g_tiled_update_px = 20LL * 3840 * 2160;   // batches up to this many pixels use the tiled update (LQRHIP_TILED_UPDATE_PX)
 static int g_overlap = 1;            // carve || band update on two streams (LQRHIP_OVERLAP=0 disables)
 
-extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
-                                int full_rebuild, int leftright_next)
+static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
+                          int full_rebuild, int leftright_next)
 {
     int rc;
     LqrHipCarver *c0 = b->cs[0];
@@ -2802,7 +2827,7 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     // carve no longer pays: it runs after the plain carve.  LQRHIP_BAND_TW=0 brings back
     // k_band_update_mw and the overlap.
     const bool band_tw = fast_band && g_band_tw && g_update_mode != 2 && (size_t) 2 * h * sizeof(int) <= 64 * 1024 && (g_overlap_override < 1);
-    const bool overlap = fast_band && !band_tw && (g_overlap_override >= 0 ? g_overlap_override : g_overlap) && (size_t) n * (size_t) w * (size_t) h >= (size_t) 12 * 3840 * 2160;
+    const bool overlap = fast_band && !band_tw && !b->pipe_now && (g_overlap_override >= 0 ? g_overlap_override : g_overlap) && (size_t) n * (size_t) w * (size_t) h >= (size_t) 12 * 3840 * 2160;
     const int gate = c0->carve_epoch + 1;
 
     auto launch_emap_update = [&](int pre_shift) -> int {
@@ -2886,9 +2911,20 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         return 0;
     }
 
-    launch_carve(b->stream);
+    if (b->pipe_now) {
+        // pipelined sub-batches: this batch's carve goes to the carve stream (its own CUs), so that it
+        // runs under the other sub-batch's chain kernels; the energy update runs first (pre-shifted)
+        if (wnew > 1 && (rc = launch_emap_update(1))) return rc;
+        HIPCK(hipEventRecord(b->ev_ready, b->stream));
+        HIPCK(hipStreamWaitEvent(b->s_carve, b->ev_ready, 0));
+        launch_carve(b->s_carve);
+        HIPCK(hipEventRecord(b->ev_carved, b->s_carve));
+        HIPCK(hipStreamWaitEvent(b->stream, b->ev_carved, 0));
+    } else {
+        launch_carve(b->stream);
+        if (wnew > 1 && (rc = launch_emap_update(0))) return rc;
+    }
     if (wnew > 1) {
-        if ((rc = launch_emap_update(0))) return rc;
         if (full_rebuild) {
             ProfScope ps("dp_sweep", b->stream, 9.0 * wnew * h * n);
             if ((rc = launch_dp<false>(b, k, wnew, h, leftright_next))) return rc;
@@ -2914,6 +2950,50 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         }
     }
     HIPCK(hipGetLastError());
+    return 0;
+}
+
+// LQRHIP_PIPE=1 (with LQRHIP_SUBBATCHES=2): the chain kernels (backtrack, energy update, band update) of a
+// batch run on a stream confined to a few CUs and its carve on a stream confined to the others, so
+// that one sub-batch's HBM-bound carve runs under the other's latency-bound chain.  Without the CU
+// masks the carve's grid takes every wave slot and the other stream's kernels just queue behind it.
+static int g_pipe = -1, g_pipe_chain_cus = 64;
+static hipError_t make_masked_stream(hipStream_t *s, int lo, int hi)
+{
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = lo; i < hi && i < 256; i++) mask[i >> 5] |= 1u << (i & 31);
+    return hipExtStreamCreateWithCUMask(s, 8, mask);
+}
+
+extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
+                                int full_rebuild, int leftright_next)
+{
+    if (g_pipe < 0) {
+        const char *e = getenv("LQRHIP_PIPE");
+        g_pipe = e ? atoi(e) : 0;
+        const char *cc = getenv("LQRHIP_PIPE_CHAIN_CUS");
+        if (cc) g_pipe_chain_cus = std::max(8, std::min(atoi(cc), 248));
+    }
+    if (!g_pipe || b->cs.size() < 4) return seam_step_impl(b, p, w, h, log_index, leftright_pick, full_rebuild, leftright_next);
+    if (!b->s_chain) {
+        if (make_masked_stream(&b->s_chain, 0, g_pipe_chain_cus) != hipSuccess || make_masked_stream(&b->s_carve, g_pipe_chain_cus, 256) != hipSuccess ||
+            hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming) != hipSuccess) {
+            g_err = "cannot create CU-masked streams";
+            return LQRHIP_EHIP;
+        }
+    }
+    HIPCK(hipEventRecord(b->ev_main, b->stream));
+    HIPCK(hipStreamWaitEvent(b->s_chain, b->ev_main, 0));
+    hipStream_t main_stream = b->stream;
+    b->stream = b->s_chain;
+    b->pipe_now = true;
+    const int rc = seam_step_impl(b, p, w, h, log_index, leftright_pick, full_rebuild, leftright_next);
+    b->pipe_now = false;
+    b->stream = main_stream;
+    if (rc) return rc;
+    HIPCK(hipEventRecord(b->ev_done, b->s_chain));
+    HIPCK(hipStreamWaitEvent(b->stream, b->ev_done, 0));
     return 0;
 }
 

@@ -119,6 +119,8 @@ int lqrhip_read_working(LqrHipCarver *c, int w, int h, float *en, float *m, int 
 
 /* kernel-time accounting for bench.py: accumulated HIP-event time (ms) and
  * launch count of the carve kernel (the roofline kernel) since the last reset */
+/* 0 off; 1 HIP-event pairs around every kernel of the seam loop; 2 around k_carve only (each pair costs ~10 us
+ * of queue time, so the bench's timed region uses 2 and takes the other kernels' times from rocprofv3) */
 void lqrhip_prof_enable(int on);
 /* -1 default (LQRHIP_OVERLAP env, on for large batches), 0 carve and band update back to back, 1 overlapped */
 void lqrhip_set_overlap(int mode);

@@ -4,6 +4,6 @@ pp='import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per
 cp gimp-lqr-plugin_amd/liblqr-hip.so /tmp/orig.so
 for v in "$@"; do
   echo "== $v"; cp variants/$v gimp-lqr-plugin_amd/liblqr-hip.so
-  LQRHIP_TILED_UPDATE_PX=0 timeout -s KILL 120 python bench.py --images-per-gpu 8 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "$pp"
+  LQRHIP_TILED_UPDATE_PX=0 timeout -s KILL 120 python bench.py --images-per-gpu 8 --steps 2 --warmup 1 --no-cpu-baseline --kernel-times 2>&1 | tail -1 | python -c "$pp"
 done
 cp /tmp/orig.so gimp-lqr-plugin_amd/liblqr-hip.so
