@@ -464,9 +464,10 @@ __device__ __forceinline__ void vp_step(const uint32_t reg, int &x, const int xa
     asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(path) : "s"(x), "n"(r));      // lane r <- column at row y_top - r
     const int o = x - xa;
     const uint32_t dw = (uint32_t) __builtin_amdgcn_readlane((int) reg, o >> 2);
-    int d = (int) (int8_t) (dw >> (8 * (o & 3)));
-    d = (d == LEAST_INVALID) ? 0 : d;
-    x += d;
+    // no LEAST_INVALID test here (3 of 10 instructions on the chain): the carve marks a back pointer
+    // invalid only next to the seam, inside the interval every form of update_mmap recomputes before
+    // the next backtrack, so none survives to this point
+    x += (int) (int8_t) (dw >> (8 * (o & 3)));
 }
 template <int... Rs>
 __device__ __forceinline__ void vp_chase(const uint32_t (&regs)[VP_ROWS], int &x, const int xa, int &path, std::integer_sequence<int, Rs...>)
