@@ -1305,6 +1305,51 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
 }
 
 // ---------------------------------------------------------------------------
+// One DP row for a lane's 4 consecutive pixels (shared by the halo kernels below): E5's
+// recurrence and, with UPDATE, E9's keep-rule.  mp = the row above (this lane's pixels), left /
+// right = its neighbours' adjacent pixels.  Everything on the row's dependency chain is VALU:
+// the back pointer is produced directly as a byte in place ((dx & 0xff) << 8k: two selects of
+// constants), the four are OR-ed, and "same parent as before" is a byte compare of old ^ new.
+// MASK: some of the lane's pixels may lie outside the image (they become +inf).
+// ch[k] (UPDATE): the pixel's (m, back pointer) pair changed.
+// ---------------------------------------------------------------------------
+template <bool LR, bool RIG, bool UPDATE, bool MASK>
+__device__ __forceinline__ void dp_row4(const float (&mp)[4], const float left, const float right, const f32x4 e, const f32x4 mo, const uint32_t lo4,
+                                        const bool (&in)[4], const float rig_l, const float rig_r, float (&mc)[4], uint32_t &lnew, bool (&ch)[4])
+{
+    const float INF = __int_as_float(0x7f800000);
+    float nm[4];
+    uint32_t sel[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
+        const float cc = mp[k];
+        float rr = (k == 3) ? right : mp[k < 3 ? k + 1 : 0];
+        if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
+        // ascending scan with strict < (LR=0: the leftmost minimum wins) or <= (LR=1: the rightmost)
+        const float best = fminf(fminf(l, cc), rr);
+        const uint32_t minus = 0xffu << (8 * k), plus = 0x01u << (8 * k);
+        if (LR) { sel[k] = (cc == best) ? 0u : minus; sel[k] = (rr == best) ? plus : sel[k]; }
+        else { sel[k] = (cc == best) ? 0u : plus; sel[k] = (l == best) ? minus : sel[k]; }
+        nm[k] = __fadd_rn(e[k], best);
+    }
+    lnew = (sel[0] | sel[1]) | (sel[2] | sel[3]);
+    const uint32_t diff = lo4 ^ lnew;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float v = nm[k];
+        if (UPDATE) {
+            // keep the stale value iff same parent and (double) fabsf(d) < 1e-5, i.e. fabsf(d) <= 1e-5f
+            float d = fabsf(__fsub_rn(mo[k], v));
+            d = ((diff >> (8 * k)) & 0xffu) ? INF : d;
+            ch[k] = d > 1e-5f;
+            v = ch[k] ? v : mo[k];
+        }
+        mc[k] = (!MASK || in[k]) ? v : INF;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // E9 update_mmap, band form, "trapezoid waves" (delta_x == 1, no rigidity mask).
 //
 // k_band_update_mw pays one s_barrier and one LDS exchange per ROW (~0.49 us per row, of which the
@@ -1457,9 +1502,10 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
             // this wave's batch landed an iteration ago; saying so here keeps the compiler from counting
             // vmcnt down through the rows, which would make the later rows wait for the earlier rows' stores
             landed();
-            // GUARD: the image ends inside the batch (last batch of a sweep only)
-            auto rows = [&](auto guard) {
-                constexpr bool GUARD = decltype(guard)::value;
+            // GUARD: the image ends inside the batch (last batch of a sweep only); MASK: the slot reaches over
+            // the image's left or right border
+            auto rows = [&](auto guard, auto mask) {
+                constexpr bool GUARD = decltype(guard)::value, MASK = decltype(mask)::value;
                 const bool own = own_lane && x0 < w;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
@@ -1467,34 +1513,12 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
                         const int yy = y + r;
                         float mc[4];
                         uint32_t lnew = 0;
-                        unsigned long long chm[4];
-                        const f32x4 e = q_e[r];
+                        bool ch[4];
                         const float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[3]), DPP_WAVE_SHR1,
                                                                                   0xf, 0xf, false));
                         const float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[0]), DPP_WAVE_SHL1,
                                                                                    0xf, 0xf, false));
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
-                            const float cc = mp[k];
-                            float rr = (k == 3) ? right : mp[k < 3 ? k + 1 : 0];
-                            if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
-                            const float best = fminf(fminf(l, cc), rr);
-                            int bdx;
-                            if (LR) { bdx = (cc == best) ? 0 : -1; bdx = (rr == best) ? 1 : bdx; }
-                            else { bdx = (cc == best) ? 0 : 1; bdx = (l == best) ? -1 : bdx; }
-                            float nm = __fadd_rn(e[k], best);
-                            // keep the stale value iff same parent and (double) fabsf(d) < 1e-5
-                            const float mo = q_mo[r][k];
-                            const int lo_k = (int) (int8_t) (q_lo[r] >> (8 * k));
-                            float d = fabsf(__fsub_rn(mo, nm));
-                            d = (lo_k == bdx) ? d : INF;
-                            const bool ch = d > 1e-5f;
-                            nm = ch ? nm : mo;
-                            mc[k] = in[k] ? nm : INF;
-                            lnew |= ((uint32_t) bdx & 0xffu) << (8 * k);
-                            if (r == R - 1) chm[k] = __ballot(ch && in[k] && own_lane);
-                        }
+                        dp_row4<LR, RIG, true, MASK>(mp, left, right, q_e[r], q_mo[r], q_lo[r], in, rig_l, rig_r, mc, lnew, ch);
                         if (own) {
                             const unsigned so = (unsigned) yy * (unsigned) stride + (unsigned) x0;
                             u32x4 tv = {__float_as_uint(mc[0]), __float_as_uint(mc[1]), __float_as_uint(mc[2]), __float_as_uint(mc[3])};
@@ -1507,8 +1531,9 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
                             // extent of the changes on the batch's last row (own columns)
 #pragma unroll
                             for (int k = 0; k < 4; k++) {
-                                if (chm[k]) {
-                                    const int first = __builtin_ctzll(chm[k]), last = 63 - __builtin_clzll(chm[k]);
+                                const unsigned long long chm = __ballot(ch[k] && (!MASK || in[k]) && own_lane);
+                                if (chm) {
+                                    const int first = __builtin_ctzll(chm), last = 63 - __builtin_clzll(chm);
                                     rlo = min(rlo, B + OWN * slot - R + 4 * first + k);
                                     rhi = max(rhi, B + OWN * slot - R + 4 * last + k);
                                 }
@@ -1517,7 +1542,11 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
                     }
                 }
             };
-            if (active) { if (nrows == R) rows(std::false_type{}); else rows(std::true_type{}); }
+            const bool interior = (x0 - 4 * lane >= 0) && (x0 - 4 * lane + 256 <= w);      // uniform per wave
+            if (active) {
+                if (nrows == R) { if (interior) rows(std::false_type{}, std::false_type{}); else rows(std::false_type{}, std::true_type{}); }
+                else rows(std::true_type{}, std::true_type{});
+            }
             else if (nrows == R) {
                 // nothing can change in this slot during the batch: its last row is what memory holds
 #pragma unroll
@@ -1936,9 +1965,10 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, D
         }
     };
     float mp[4] = {INF, INF, INF, INF};
-    // GUARD: the batch may contain row 0 or rows past the image (first and last batch of a sweep)
-    auto batch = [&](int ybase, auto guard) {
-        constexpr bool GUARD = decltype(guard)::value;
+    // GUARD: the batch may contain row 0 or rows past the image (first and last batch of a sweep);
+    // MASK: the tile reaches over the image's left or right border
+    auto batch = [&](int ybase, auto guard, auto mask) {
+        constexpr bool GUARD = decltype(guard)::value, MASK = decltype(mask)::value;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int y = ybase + r;
@@ -1954,28 +1984,8 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, D
                                                                               0xf, 0xf, false));
                     const float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[0]), DPP_WAVE_SHL1,
                                                                                0xf, 0xf, false));
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
-                        const float cc = mp[k];
-                        float rr = (k == 3) ? right : mp[k < 3 ? k + 1 : 0];
-                        if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
-                        const float best = fminf(fminf(l, cc), rr);
-                        int bdx;
-                        if (LR) { bdx = (cc == best) ? 0 : -1; bdx = (rr == best) ? 1 : bdx; }
-                        else { bdx = (cc == best) ? 0 : 1; bdx = (l == best) ? -1 : bdx; }
-                        float nm = __fadd_rn(e[k], best);
-                        if (UPDATE) {
-                            // keep the stale value iff same parent and (double) fabsf(d) < 1e-5
-                            const float mo = q_mo[r][k];
-                            const int lo_k = (int) (int8_t) (q_lo[r] >> (8 * k));
-                            float d = fabsf(__fsub_rn(mo, nm));
-                            d = (lo_k == bdx) ? d : INF;
-                            nm = (d > 1e-5f) ? nm : mo;
-                        }
-                        mc[k] = in[k] ? nm : INF;
-                        lnew |= ((uint32_t) bdx & 0xffu) << (8 * k);
-                    }
+                    bool ch[4];
+                    dp_row4<LR, RIG, UPDATE, MASK>(mp, left, right, e, q_mo[r], q_lo[r], in, rig_l, rig_r, mc, lnew, ch);
                 }
                 if (own) {
                     const unsigned so = (unsigned) y * (unsigned) stride + (unsigned) x0;
@@ -1988,6 +1998,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, D
             }
         }
     };
+    const bool interior = (x0 - 4 * lane >= 0) && (x0 - 4 * lane + 256 <= w);      // uniform: the whole tile window is inside the image
 
     const int nblk = (h + DPP_HALO - 1) / DPP_HALO;
     issue(q * R);
@@ -2023,8 +2034,8 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, D
                             mp[k] = in[k] ? __hip_atomic_load(mrow + x0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
                     }
                 }
-                if (yb > 0 && yb + R <= h) batch(yb, std::false_type{});
-                else batch(yb, std::true_type{});
+                if (yb > 0 && yb + R <= h) { if (interior) batch(yb, std::false_type{}, std::false_type{}); else batch(yb, std::false_type{}, std::true_type{}); }
+                else batch(yb, std::true_type{}, std::true_type{});
                 {
                     f32x4 v = {mp[0], mp[1], mp[2], mp[3]};
                     s_mp[lane] = v;
