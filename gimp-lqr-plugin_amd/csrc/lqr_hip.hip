@@ -1423,15 +1423,22 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
     f32x4 q_e[R], q_mo[R];
     uint32_t q_lo[R];
     int B = 0;
-    auto issue = [&](int ybase) {
+    // full = false: the slot cannot become active in that batch (see the prediction at the issue site);
+    // only the row it hands over is needed.  The CU's vector-memory path takes ~16 cycles per 64-lane
+    // 16-byte access, so four slots' 3 loads + 2 stores per row (320 cycles) would be the bound.
+    auto issue = [&](int ybase, bool full) {
         const int x0 = B + OWN * slot - R + 4 * lane;
         const unsigned lo_off = (unsigned) min(max(x0, 0), stride - 4);
+        if (full) {
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const unsigned ro = (unsigned) min(ybase + r, h - 1) * (unsigned) stride + lo_off;
-            q_e[r] = *(const GLOBAL_AS f32x4 *) (c.en + ro);
-            q_mo[r] = *(const GLOBAL_AS f32x4 *) (c.m + ro);
-            q_lo[r] = *(const gu32 *) (c.least + ro);
+            for (int r = 0; r < R; r++) {
+                const unsigned ro = (unsigned) min(ybase + r, h - 1) * (unsigned) stride + lo_off;
+                q_e[r] = *(const GLOBAL_AS f32x4 *) (c.en + ro);
+                q_mo[r] = *(const GLOBAL_AS f32x4 *) (c.m + ro);
+                q_lo[r] = *(const gu32 *) (c.least + ro);
+            }
+        } else {
+            q_mo[R - 1] = *(const GLOBAL_AS f32x4 *) (c.m + (unsigned) min(ybase + R - 1, h - 1) * (unsigned) stride + lo_off);
         }
     };
     // make the compiler wait for this wave's prefetched batch here
@@ -1444,6 +1451,7 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
     long long t_cmp = 0, t_land = 0, t_bar = 0, t_reb = 0, n_bat = 0, n_reb = 0, n_act = 0; const long long t_begin = __builtin_readcyclecounter();
 #endif
     int y = 1, ovf = h, kpar = 0;
+    bool loads_full = true;                  // does this wave's staged batch hold all rows (or only the hand-over row)?
     int dlo = 1 << 30, dhi = -1;             // px changed on the last finished row (absolute x)
     bool have_window = false, force_active = false, just_rebased = false;
     while (y < h) {
@@ -1453,6 +1461,7 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
         if (dhi >= dlo) { lo = min(lo, dlo - 1); hi = max(hi, dhi + 1); }
         lo = max(lo, 0); hi = min(hi, w - 1);
         const bool fits = have_window && (B == 0 || lo - R >= B) && (B + WIN >= w || hi + R <= B + WIN - 1);
+        bool issue_full = true;
         int y_issue = -1;                    // batch this wave prefetches at the end of the iteration (one issue site:
                                              // a second one makes the register allocator spill the staging rows)
 #ifdef TW_STATS
@@ -1489,6 +1498,7 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
 #endif
         if (par_w == kpar) {
             const bool active = force_active || (lo - R <= own_hi && hi + R >= own_lo);
+            if (active && !loads_full) __builtin_trap();      // the prediction below is a superset by construction
             bool in[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) in[k] = (x0 + k >= 0) && (x0 + k < w);
@@ -1588,11 +1598,22 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
 #ifdef TW_STATS
         t_bar += __builtin_readcyclecounter() - tb0;
 #endif
+        if (y_issue >= 0 && y_issue < h) {
+            // can this slot be active in the batch it is about to prefetch (two batches down)?  Changes move
+            // one column per row: whatever is dirty now, or touched in the next batch, is at most 2R columns
+            // away by then; touches of that batch itself R
+            int plo = 1 << 30, phi = -1;
+            if (dhi >= dlo) { plo = dlo - 2 * R - 3; phi = dhi + 2 * R + 3; }
+            const int t1 = s_touchR[min(y + R, h - 1)], t2 = s_touchR[y_issue];
+            plo = min(plo, min((t1 & 0xffff) - 2 * R - 3, (t2 & 0xffff) - R - 3));
+            phi = max(phi, max((t1 >> 16) + 2 * R + 3, (t2 >> 16) + R + 3));
+            issue_full = (plo <= own_hi && phi >= own_lo);
+        }
         y += R;
         kpar ^= 1;
         force_active = false;
         }
-        if (y_issue >= 0) issue(y_issue);
+        if (y_issue >= 0) { issue(y_issue, issue_full); loads_full = issue_full; }
         if (just_rebased) {
             landed();                        // before anybody stores rows >= y
             __syncthreads();
