@@ -2860,7 +2860,10 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     // the trapezoid-wave band kernel (default) is fast enough that hiding it under a slower, signalling
     // carve no longer pays: it runs after the plain carve.  LQRHIP_BAND_TW=0 brings back
     // k_band_update_mw and the overlap.
-    const bool band_tw = fast_band && g_band_tw && g_update_mode != 2 && (size_t) 2 * h * sizeof(int) <= 64 * 1024 && (g_overlap_override < 1);
+    // (rows wider than ~4200 px: the changes outgrow its 896-column window too often, and the 8-slot build
+    // spills registers -- 3.9 ms per 8K seam against k_band_update_mw's ~2.5)
+    const bool band_tw = fast_band && g_band_tw && g_update_mode != 2 && wnew <= 4200 && (size_t) 2 * h * sizeof(int) <= 64 * 1024 &&
+                         (g_overlap_override < 1);
     const bool overlap = fast_band && !band_tw && !b->pipe_now && (g_overlap_override >= 0 ? g_overlap_override : g_overlap) && (size_t) n * (size_t) w * (size_t) h >= (size_t) 12 * 3840 * 2160;
     const int gate = c0->carve_epoch + 1;
 
@@ -2893,7 +2896,7 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
         if (band_tw) {
             ProfScope ps("band_update", b->stream, 0);
 #define LAUNCH_TW(NWV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_tw<NWV, LRV, RIGV>), dim3(n), dim3(128 * NWV), (size_t) 2 * h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride)
-#define LAUNCH_TW_N(LRV, RIGV) do { if (wnew > 4200) LAUNCH_TW(8, LRV, RIGV); else LAUNCH_TW(4, LRV, RIGV); } while (0)
+#define LAUNCH_TW_N(LRV, RIGV) LAUNCH_TW(4, LRV, RIGV)
             if (leftright_next) { if (p->use_rigidity) LAUNCH_TW_N(true, true); else LAUNCH_TW_N(true, false); }
             else { if (p->use_rigidity) LAUNCH_TW_N(false, true); else LAUNCH_TW_N(false, false); }
 #undef LAUNCH_TW_N
