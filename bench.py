@@ -175,7 +175,7 @@ def main():
         ms, n, by = C.c_double(0), C.c_longlong(0), C.c_double(0)
         lib.lqrhip_prof_get(name.encode(), C.byref(ms), C.byref(n), C.byref(by))
         return ms.value, n.value, by.value
-    kern = {k: prof(k) for k in ("carve", "vpath", "band_update", "band_update_sw", "dp_update", "dp_update_tiled", "dp_sweep", "emap_update")}
+    kern = {k: prof(k) for k in ("carve", "vpath", "band_update", "dp_update", "dp_update_tiled", "dp_sweep", "emap_update")}
     c_ms, c_n, c_bytes = kern["carve"]
     roofline = None
     if c_n:

@@ -1092,10 +1092,6 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
     if (h < 2) { if (tid == 0) c.flags[FLAG_OVF_ROW] = h; return; }
 
     const unsigned dummy = (unsigned) h * stride + PXL * tid;      // scratch row for lanes outside the image
-#ifdef BAND_TIMING
-    long long t_bar = 0, t_rows = 0, t_act = 0, t_rebase = 0, t_p01 = 0, t_p12 = 0, t_p2b = 0;
-    const long long t_start = __builtin_readcyclecounter();
-#endif
     int y = y_start, ovf = h;
     int dirty_lo = -1, dirty_hi = -1;      // dirty slots of the last finished row, window-relative (-1: none)
     int B = 0;
@@ -1103,9 +1099,6 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
     bool abort_all = false;
     while (y < h && !abort_all) {
         // ---- (re)base the window (identical decision in every wave)
-#ifdef BAND_TIMING
-        t_rebase++;
-#endif
         {
             const int t = s_touch[y];
             int lo = t & 0xffff, hi = t >> 16;                       // absolute pixel range that must be inside
@@ -1198,9 +1191,6 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
 #pragma unroll
                         for (int r = 0; r < R; r++) {
                             if (y < h) {
-#ifdef BAND_TIMING
-                                const long long tp0 = __builtin_readcyclecounter();
-#endif
                                 // what the neighbours published about row y-1
                                 const BandEdge eL = s_edge[par][wave], eR = s_edge[par][wave + 2];
                                 const int t = s_touch[y];
@@ -1214,9 +1204,6 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
 #pragma unroll
                                 for (int k = 0; k < PXL; k++) mc[k] = (x0 + k < w) ? mo[k] : INF;
                                 int flags = 0;
-#ifdef BAND_TIMING
-                                const long long tp1 = __builtin_readcyclecounter() + (active ? 0 : 0);
-#endif
                                 if (active) {
                                     float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(eL.last_val), __float_as_int(mp[PXL - 1]),
                                                                                         DPP_WAVE_SHR1, 0xf, 0xf, false));
@@ -1259,16 +1246,9 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
                                     FV tv;
 #pragma unroll
                                     for (int k = 0; k < PXL; k++) tv[k] = mc[k];
-#ifndef BAND_NOSTORE
                                     *(GFV *) (c.m + so) = tv;
                                     *(GLV *) (c.least + so) = (LV) lnew;
-#else
-                                    if (y == 123456) { *(GFV *) (c.m + so) = tv; *(GLV *) (c.least + so) = (LV) lnew; }
-#endif
                                 }
-#ifdef BAND_TIMING
-                                const long long tp2 = __builtin_readcyclecounter() + (flags & 0);
-#endif
                                 own_dirty = flags & 4;
                                 par ^= 1;
                                 if (lane == 0) { s_edge[par][wave + 1].first_val = mc[0]; s_edge[par][wave + 1].flags = flags; }
@@ -1276,15 +1256,7 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
 #pragma unroll
                                 for (int k = 0; k < PXL; k++) mp[k] = mc[k];
                                 // one barrier per row: LDS only (outstanding global loads/stores keep flying)
-#ifdef BAND_TIMING
-                                const long long tb0 = __builtin_readcyclecounter();
-                                t_p01 += tp1 - tp0; t_p12 += tp2 - tp1; t_p2b += tb0 - tp2;
-#endif
                                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#ifdef BAND_TIMING
-                                const long long tb1 = __builtin_readcyclecounter();
-                                t_bar += tb1 - tb0; t_rows++; t_act += active ? 1 : 0;
-#endif
                                 y++;
                             }
                         }
@@ -1294,15 +1266,6 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
         }
     }
     if (tid == 0) c.flags[FLAG_OVF_ROW] = ovf;
-#ifdef BAND_TIMING
-    if (lane == 0 && blockIdx.x == 0) {
-        const long long t_end = __builtin_readcyclecounter();
-        printf("band wave %d: total %lld cyc, rows %lld, active rows %lld, in barrier %.0f/row, rest %.0f/row: reads+decide %.0f, compute+store %.0f, publish %.0f, other %.0f; rebases %lld\n", wave,
-               t_end - t_start, t_rows, t_act, (double) t_bar / t_rows, (double) (t_end - t_start - t_bar) / t_rows,
-               (double) t_p01 / t_rows, (double) t_p12 / t_rows, (double) t_p2b / t_rows,
-               (double) (t_end - t_start - t_bar - t_p01 - t_p12 - t_p2b) / t_rows, t_rebase);
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1387,11 +1350,7 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
     __shared__ int s_rec[2][NW][2];                        // [batch parity][slot] {lo, hi}: px changed on that row (lo > hi: none)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef TW_MAP_B
-    const int slot = wv / 2, par_w = wv % 2;
-#else
     const int slot = wv % NW, par_w = wv / NW;             // the two waves of a slot sit on the same SIMD
-#endif
     const float INF = __int_as_float(0x7f800000);
     const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
 
@@ -1448,9 +1407,6 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
         for (int r = 0; r < R; r++) asm volatile("" ::"v"(q_e[r]), "v"(q_mo[r]), "v"(q_lo[r]));
     };
 
-#ifdef TW_STATS
-    long long t_cmp = 0, t_land = 0, t_bar = 0, t_reb = 0, n_bat = 0, n_reb = 0, n_act = 0; const long long t_begin = __builtin_readcyclecounter();
-#endif
     int y = 1, ovf = h, kpar = 0;
     bool loads_full = true;                  // does this wave's staged batch hold all rows (or only the hand-over row)?
     int dlo = 1 << 30, dhi = -1;             // px changed on the last finished row (absolute x)
@@ -1465,9 +1421,6 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
         bool issue_full = true;
         int y_issue = -1;                    // batch this wave prefetches at the end of the iteration (one issue site:
                                              // a second one makes the register allocator spill the staging rows)
-#ifdef TW_STATS
-        const long long ts0 = __builtin_readcyclecounter();
-#endif
         if (!fits) {
             if (just_rebased || (hi - lo + 1 + 2 * R + 8 > WIN && WIN < w)) { ovf = y; break; }
             int nb = (((lo + hi) >> 1) - WIN / 2) & ~3;
@@ -1494,9 +1447,6 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
         const int x0 = B + OWN * slot - R + 4 * lane;
         const int own_lo = B + OWN * slot, own_hi = own_lo + OWN - 1;
         const bool own_lane = lane >= R / 4 && lane < 64 - R / 4;
-#ifdef TW_STATS
-        n_bat++;
-#endif
         if (par_w == kpar) {
             const bool active = force_active || (lo - R <= own_hi && hi + R >= own_lo);
             if (active && !loads_full) __builtin_trap();      // the prediction below is a superset by construction
@@ -1575,18 +1525,9 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
                 if (lane == 0) { s_rec[kpar][slot][0] = rlo; s_rec[kpar][slot][1] = rhi; }
                 y_issue = y + 2 * R;
             }
-#ifdef TW_STATS
-            t_cmp += __builtin_readcyclecounter() - ts0; n_act += active;
-#endif
         } else {
             landed();
-#ifdef TW_STATS
-            t_land += __builtin_readcyclecounter() - ts0;
-#endif
         }
-#ifdef TW_STATS
-        const long long tb0 = __builtin_readcyclecounter();
-#endif
         // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. the prefetch
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         {
@@ -1596,9 +1537,6 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
             dlo = __builtin_amdgcn_readfirstlane(a);
             dhi = __builtin_amdgcn_readfirstlane(b);
         }
-#ifdef TW_STATS
-        t_bar += __builtin_readcyclecounter() - tb0;
-#endif
         if (y_issue >= 0 && y_issue < h) {
             // can this slot be active in the batch it is about to prefetch (two batches down)?  Changes move
             // one column per row: whatever is dirty now, or touched in the next batch, is at most 2R columns
@@ -1618,218 +1556,9 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
         if (just_rebased) {
             landed();                        // before anybody stores rows >= y
             __syncthreads();
-#ifdef TW_STATS
-            t_reb += __builtin_readcyclecounter() - ts0; n_reb++;
-#endif
         }
     }
     if (tid == 0) c.flags[FLAG_OVF_ROW] = ovf;
-#ifdef TW_STATS
-    if (lane == 0 && blockIdx.x == 0 && (wv == 1 || wv == NW + 1)) printf("tw wave %d: total %lld, batches %lld (active %lld), rebases %lld; cycles compute %lld, landed-wait %lld, barrier+rec %lld, rebase %lld; ovf %d\n", wv, (long long) (__builtin_readcyclecounter() - t_begin), n_bat, n_act, n_reb, t_cmp, t_land, t_bar, t_reb, ovf);
-#endif
-}
-
-// ---------------------------------------------------------------------------
-// E9 update_mmap, delta_x == 1, single-wave form: ONE wave per image recomputes a
-// 512-pixel window (8 consecutive pixels per lane) on every row -- by section 4.4 of
-// DESIGN.md any superset of the changed-input pixels gives liblqr's result, and
-// the whole window is the simplest superset.  No LDS traffic, no barrier, no band
-// bookkeeping on the per-row chain: neighbours inside a lane are registers, across
-// lanes DPP wave shifts.  The window follows the changes; when they no longer fit
-// (wider than ~480 px) the kernel leaves the row and the extent of the changes in
-// flags[] and the multi-wave kernel (k_band_update_mw, resume) carries on.
-// ---------------------------------------------------------------------------
-#define FLAG_HINT_LO 1
-#define FLAG_HINT_HI 2
-template <int R, bool LR, bool RIG>
-__global__ __launch_bounds__(64) void k_band_update_sw(const DevCarver *cs, DpK p, int w, int h, int stride, int gate)
-{
-    constexpr int PXL = 8, WIN = 64 * PXL, MARG = R + 8;
-    const GCarver c = gview(cs[blockIdx.x]);
-    extern __shared__ int s_touch[];                  // [h] packed (t0 | t1 << 16)
-    const int lane = threadIdx.x;
-    const float INF = __int_as_float(0x7f800000);
-    const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
-
-    int ready = 0;
-    bool acquired = true;
-    auto wait_rows = [&](int upto) -> bool {          // see k_band_update_mw; false = the carve never showed up
-        if (!gate) return true;
-        const int cu = min(upto, h - 1) >> 6;
-        for (; ready <= cu; ready++) {
-            const int need = gate * min(64, h - 64 * ready);
-            int spins = 0;
-            while (__hip_atomic_load(c.progress + ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                __builtin_amdgcn_s_sleep(64);
-                if (++spins > (1 << 20)) return false;
-            }
-            acquired = false;
-        }
-        if (!acquired) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
-        return true;
-    };
-    if (!wait_rows(0)) { if (lane == 0) { c.flags[FLAG_OVF_ROW] = 0; c.flags[FLAG_HINT_LO] = -1; c.flags[FLAG_HINT_HI] = -1; } return; }
-
-    for (int y = lane; y < h; y += 64) {
-        const int v0 = c.seam_x[y], vm = c.seam_x[max(y - 1, 0)], vp = c.seam_x[min(y + 1, h - 1)];
-        const int t0 = max(min(min(v0, vm), vp) - 2, 0), t1 = min(max(max(v0, vm), vp) + 1, w - 1);
-        s_touch[y] = t0 | (t1 << 16);
-    }
-    {   // row 0: m = en on liblqr's interval
-        const int v0 = c.seam_x[0], vp = c.seam_x[min(1, h - 1)];
-        int lo = v0, hi = v0 - 1;
-        if (p.radius) { lo = min(v0, vp) - 1; hi = max(v0, vp); }
-        const int a = max(lo, 0), b = min(hi, w - 1);
-        for (int x = a + lane; x <= b; x += 64) c.m[x] = c.en[x];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (h < 2) { if (lane == 0) { c.flags[FLAG_OVF_ROW] = h; } return; }
-
-    const unsigned dummy = (unsigned) h * stride + PXL * lane;
-    int y = 1, ovf = h;
-    int d_lo = -1, d_hi = -1;          // absolute pixel extent of the changes of the last finished row
-    bool aborted = false;
-    while (y < h && !aborted) {
-        // ---- (re)base the window on what must be inside it
-        int B;
-        {
-            const int t = s_touch[y];
-            int lo = t & 0xffff, hi = t >> 16;
-            if (d_lo >= 0) { lo = min(lo, d_lo - 1); hi = max(hi, d_hi + 1); }
-            lo = max(lo, 0); hi = min(hi, w - 1);
-            if (hi - lo + 1 > WIN - 2 * MARG - 24 && w > WIN) { ovf = y; break; }
-            int nb = (((lo + hi) >> 1) - WIN / 2) & ~7;
-            nb = max(0, min(nb, (w - WIN + 7) & ~7));
-            B = __builtin_amdgcn_readfirstlane(nb);
-            // the window must pass the batch-boundary test below right away, otherwise this loop
-            // would re-base forever: hand the rest of the image over instead
-            const bool left_ok = (B == 0) || (lo - MARG >= B);
-            const bool right_ok = (B + WIN >= w) || (hi + MARG < B + WIN);
-            if (!(left_ok && right_ok)) { ovf = y; break; }
-        }
-        const int x0 = B + PXL * lane;
-        const unsigned lo_off = (unsigned) min(x0, stride - PXL);
-        const bool in_img = x0 < w;
-        uint32_t okmask = 0;       // pixels this lane may recompute (see k_band_update_mw)
-#pragma unroll
-        for (int k = 0; k < PXL; k++) {
-            const int x = x0 + k;
-            const bool ok = (x < w) && !(B > 0 && x == B) && !(B + WIN < w && x == B + WIN - 1);
-            okmask |= ok ? (1u << k) : 0u;
-        }
-
-        if (!wait_rows(y + R - 1)) { ovf = y; break; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        float mp[PXL];
-        {
-            gf32 *mrow = c.m + (size_t) (y - 1) * stride;
-#pragma unroll
-            for (int k = 0; k < PXL; k++)
-                mp[k] = (x0 + k < w) ? __hip_atomic_load(mrow + x0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
-        }
-
-        f32x4 q_mo[2][R][2], q_e[2][R][2];
-        uint64_t q_lo[2][R];
-        auto issue = [&](int buf, int ybase) {           // one batch of R rows, unconditional
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const unsigned ro = (unsigned) min(ybase + r, h - 1) * (unsigned) stride + lo_off;
-                q_mo[buf][r][0] = *(const GLOBAL_AS f32x4 *) (c.m + ro);
-                q_mo[buf][r][1] = *(const GLOBAL_AS f32x4 *) (c.m + ro + 4);
-                q_e[buf][r][0] = *(const GLOBAL_AS f32x4 *) (c.en + ro);
-                q_e[buf][r][1] = *(const GLOBAL_AS f32x4 *) (c.en + ro + 4);
-                q_lo[buf][r] = *(const GLOBAL_AS uint64_t *) (c.least + ro);
-            }
-        };
-        issue(0, y);
-
-        uint32_t chg_last = 0;             // per-lane change bits of the last finished row
-        bool have_last = false;
-        bool rebase = false;
-        while (y < h && !rebase) {
-#pragma unroll
-            for (int buf = 0; buf < 2; buf++) {
-                if (y < h && !rebase) {
-                    // ---- batch boundary: extent of the last row's changes; does the window hold R more rows?
-                    if (have_last) {
-                        const unsigned long long bal = __ballot(chg_last != 0);
-                        if (bal) {
-                            const int fl = __ffsll((long long) bal) - 1, ll = 63 - __clzll((long long) bal);
-                            const uint32_t mf = (uint32_t) __builtin_amdgcn_readlane((int) chg_last, fl);
-                            const uint32_t ml = (uint32_t) __builtin_amdgcn_readlane((int) chg_last, ll);
-                            d_lo = B + PXL * fl + (__ffs((int) mf) - 1);
-                            d_hi = B + PXL * ll + (31 - __clz((int) ml));
-                        } else {
-                            d_lo = -1; d_hi = -1;
-                        }
-                    }
-                    {
-                        const int t = s_touch[y];
-                        int lo = (t & 0xffff), hi = (t >> 16);
-                        if (d_lo >= 0) { lo = min(lo, d_lo); hi = max(hi, d_hi); }
-                        const bool left_ok = (B == 0) || (lo - MARG >= B);
-                        const bool right_ok = (B + WIN >= w) || (hi + MARG < B + WIN);
-                        rebase = !(left_ok && right_ok);
-                    }
-                    if (!rebase) {
-                        if (!wait_rows(y + 2 * R - 1)) { ovf = y; aborted = true; rebase = true; break; }
-                        issue(buf ^ 1, y + R);
-#pragma unroll
-                        for (int r = 0; r < R; r++) {
-                            if (y < h) {
-                                float mo[PXL], e[PXL], mc[PXL];
-                                const uint64_t lo8 = q_lo[buf][r];
-#pragma unroll
-                                for (int k = 0; k < PXL; k++) { mo[k] = q_mo[buf][r][k >> 2][k & 3]; e[k] = q_e[buf][r][k >> 2][k & 3]; }
-                                float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[PXL - 1]),
-                                                                                    DPP_WAVE_SHR1, 0xf, 0xf, false));
-                                float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[0]),
-                                                                                     DPP_WAVE_SHL1, 0xf, 0xf, false));
-                                uint32_t chg = 0;
-                                uint64_t lnew = 0;
-#pragma unroll
-                                for (int k = 0; k < PXL; k++) {
-                                    float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
-                                    const float cc = mp[k];
-                                    float rr = (k == PXL - 1) ? right : mp[k < PXL - 1 ? k + 1 : 0];
-                                    if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
-                                    const float best = fminf(fminf(l, cc), rr);
-                                    int bdx;
-                                    if (LR) { bdx = (cc == best) ? 0 : -1; bdx = (rr == best) ? 1 : bdx; }
-                                    else { bdx = (cc == best) ? 0 : 1; bdx = (l == best) ? -1 : bdx; }
-                                    const float nm = __fadd_rn(e[k], best);
-                                    const int lo_k = (int) (int8_t) (lo8 >> (8 * k));
-                                    float d = fabsf(__fsub_rn(mo[k], nm));
-                                    d = (lo_k == bdx) ? d : INF;
-                                    d = ((okmask >> k) & 1) ? d : 0.0f;
-                                    const bool ch = d > 1e-5f;          // keep rule: (double) fabsf(d) < 1e-5 keeps the stale value
-                                    mc[k] = ch ? nm : ((x0 + k < w) ? mo[k] : INF);
-                                    const int outl = ((okmask >> k) & 1) ? bdx : lo_k;
-                                    lnew |= (uint64_t) ((uint32_t) outl & 0xffu) << (8 * k);
-                                    chg |= ch ? (1u << k) : 0u;
-                                }
-                                const unsigned so = in_img ? (unsigned) y * (unsigned) stride + (unsigned) x0 : dummy;
-                                f32x4 t0 = {mc[0], mc[1], mc[2], mc[3]}, t1 = {mc[4], mc[5], mc[6], mc[7]};
-                                *(GLOBAL_AS f32x4 *) (c.m + so) = t0;
-                                *(GLOBAL_AS f32x4 *) (c.m + so + 4) = t1;
-                                *(GLOBAL_AS uint64_t *) (c.least + so) = lnew;
-#pragma unroll
-                                for (int k = 0; k < PXL; k++) mp[k] = mc[k];
-                                chg_last = chg;
-                                have_last = true;
-                                y++;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (y >= h && have_last) {       // extent of the final row is not needed
-        }
-    }
-    if (lane == 0) { c.flags[FLAG_OVF_ROW] = ovf; c.flags[FLAG_HINT_LO] = d_lo; c.flags[FLAG_HINT_HI] = d_hi; }
 }
 
 // ---------------------------------------------------------------------------
@@ -2801,7 +2530,6 @@ static int g_use_band = -1;
 static int g_band_variant = 0;
 static int g_carve_wgs = 0;          // > 0: cap on the carve kernel's workgroups (LQRHIP_CARVE_WGS)
 static int g_band_tw = 1;            // LQRHIP_BAND_TW=0: k_band_update_mw (+ carve overlap) instead of k_band_update_tw
-static int g_band_sw = 0;            // LQRHIP_BAND_SW=1: single-wave band kernel first.  Measured no faster than the
                                      // multi-wave one (a lone wave issues 1 instruction / 4 cycles: ~184 instr/row), so off
 static long long g_tiled_update_px = 20LL * 3840 * 2160;   // batches up to this many pixels use the tiled update (LQRHIP_TILED_UPDATE_PX)
 static int g_overlap = 1;            // carve || band update on two streams (LQRHIP_OVERLAP=0 disables)
@@ -2818,8 +2546,6 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
         g_band_variant = v ? atoi(v) : 0;
         const char *cw = getenv("LQRHIP_CARVE_WGS");
         g_carve_wgs = cw ? atoi(cw) : 0;
-        const char *sw = getenv("LQRHIP_BAND_SW");
-        g_band_sw = sw ? atoi(sw) : 0;
         const char *tw = getenv("LQRHIP_BAND_TW");
         g_band_tw = tw ? atoi(tw) : 1;
         const char *tu = getenv("LQRHIP_TILED_UPDATE_PX");
@@ -2903,16 +2629,7 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
 #undef LAUNCH_TW
             return;
         }
-        const int resume = g_band_sw ? 1 : 0;
-        if (g_band_sw) {
-            // single-wave kernel first; what it cannot hold (changes wider than its 512-px window) is
-            // finished by the multi-wave kernel from the recorded row
-            ProfScope ps("band_update_sw", b->stream, 0);
-#define LAUNCH_SW(LRV, RIGV) hipLaunchKernelGGL((k_band_update_sw<8, LRV, RIGV>), dim3(n), dim3(64), (size_t) h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, gate_arg)
-            if (leftright_next) { if (p->use_rigidity) LAUNCH_SW(true, true); else LAUNCH_SW(true, false); }
-            else { if (p->use_rigidity) LAUNCH_SW(false, true); else LAUNCH_SW(false, false); }
-#undef LAUNCH_SW
-        }
+        const int resume = 0;
         ProfScope ps("band_update", b->stream, 0);
 #define LAUNCH_BAND_V(PX, NWV, RV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_mw<PX, NWV, RV, LRV, RIGV>), dim3(n), dim3(64 * NWV), (size_t) h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, gate_arg, resume)
 #define LAUNCH_BAND(LRV, RIGV)                                                          \
