@@ -2531,7 +2531,7 @@ static int g_band_variant = 0;
 static int g_carve_wgs = 0;          // > 0: cap on the carve kernel's workgroups (LQRHIP_CARVE_WGS)
 static int g_band_tw = 1;            // LQRHIP_BAND_TW=0: k_band_update_mw (+ carve overlap) instead of k_band_update_tw
                                      // multi-wave one (a lone wave issues 1 instruction / 4 cycles: ~184 instr/row), so off
-static long long g_tiled_update_px = 20LL * 3840 * 2160;   // batches up to this many pixels use the tiled update (LQRHIP_TILED_UPDATE_PX)
+static long long g_tiled_update_px = 12LL * 3840 * 2160;   // batches up to this many pixels use the tiled update (LQRHIP_TILED_UPDATE_PX)
 static int g_overlap = 1;            // carve || band update on two streams (LQRHIP_OVERLAP=0 disables)
 
 static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,

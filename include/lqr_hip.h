@@ -124,7 +124,7 @@ int lqrhip_read_working(LqrHipCarver *c, int w, int h, float *en, float *m, int 
 void lqrhip_prof_enable(int on);
 /* -1 default (LQRHIP_OVERLAP env, on for large batches), 0 carve and band update back to back, 1 overlapped */
 void lqrhip_set_overlap(int mode);
-/* how E9 (update_mmap) runs: -1 by batch size (tiled full-width keep-rule sweep up to ~20 4K images, the band
+/* how E9 (update_mmap) runs: -1 by batch size (tiled full-width keep-rule sweep up to ~12 4K images, the band
  * kernel k_band_update_tw above), 0 band kernel always, 1 tiled sweep whenever its grid fits the device,
  * 2 the older band kernel k_band_update_mw (overlapped with the carve for large batches) */
 void lqrhip_set_update_mode(int mode);
