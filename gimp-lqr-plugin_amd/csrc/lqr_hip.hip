@@ -856,6 +856,9 @@ __global__ __launch_bounds__(64) void k_band_update(const DevCarver *cs, DpK p, 
             nrg_interval(seam, y, h, w, p.radius, n0, n1);
             na = max(min(a, n0) - delta, 0);
             nb = min(max(b, n1) + delta, w - 1);
+            // the children of the pixel carved on the row above are always in the band (oracle: spec delta 6)
+            na = min(na, max(seam[y - 1] - delta - 1, 0));
+            nb = max(nb, min(seam[y - 1] + delta, w - 1));
         }
         if (nb - na + 1 + 2 * delta > BAND_WIN - 8) { ovf = y; break; }
         int centre = (na + nb) >> 1;
@@ -905,6 +908,8 @@ __global__ __launch_bounds__(64) void k_band_update(const DevCarver *cs, DpK p, 
                     nrg_interval(seam, y, h, w, p.radius, n0, n1);
                     int ra = max(min(a, n0) - delta, 0);
                     int rb = min(max(b, n1) + delta, w - 1);
+                    ra = min(ra, max(seam[y - 1] - delta - 1, 0));
+                    rb = max(rb, min(seam[y - 1] + delta, w - 1));
                     // the band (plus its parents) must sit inside the window
                     bool fits = (ra - delta >= B || B == 0) && (rb + delta < B + BAND_WIN || B + BAND_WIN >= w);
                     if (!fits) {

@@ -745,6 +745,16 @@ static LqrRetVal update_mmap(LqrCarver *r)
         x_min = MAXI(x_min - r->delta_x, 0);
         x_max = MINI(x_max + r->delta_x, r->w - 1);
         {
+            /* Spec delta 6: the children of the pixel carved on the row above are
+             * always inside the band.  With heavily tied maps (null energy + masks) the band can shrink
+             * past them, and a pixel would keep a back pointer to the carved pixel; what liblqr does
+             * then is undefined (it follows a dangling pixel id).  For every other pixel the extra
+             * evaluations are no-ops. */
+            const int p = r->vpath_x[y - 1];
+            x_min = MINI(x_min, MAXI(p - r->delta_x - 1, 0));
+            x_max = MAXI(x_max, MINI(p + r->delta_x, r->w - 1));
+        }
+        {
             long long bw = (long long) x_max - x_min + 1;
             if (bw < 0) bw = 0;
             g_stats[0]++; g_stats[1] += bw;

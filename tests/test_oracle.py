@@ -304,3 +304,27 @@ def test_guess_new_size_matches_restatement(oracle, ch, x_off, y_off):
     for direction in (0, 1):
         got = oracle.lqrx_guess_new_size(mask.ctypes.data, ch, 31, 23, x_off, y_off, 28, 20, direction)
         assert got == _py_guess(mask, x_off, y_off, 28, 20, direction)
+
+
+def test_null_energy_with_masks_never_leaves_dangling_back_pointers(oracle):
+    """found by scripts/fuzz_parity.py: with the null energy function and preserve/discard masks the maps are
+    so heavily tied that update_mmap's band used to shrink past the children of the carved pixel, leaving a
+    back pointer to a pixel that no longer exists (spec delta 6)"""
+    import ctypes
+    import datasets as D
+    import harness as H
+    w, h = 276, 80
+    img = D.noise(w, h, 790234955, channels=1)
+    oracle.lib.olqrx_set_debug.argtypes = [ctypes.c_int]
+    oracle.lib.olqr_oracle_get_stats.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
+    oracle.lib.olqrx_set_debug(1)
+    oracle.lib.olqr_oracle_reset_stats()
+    try:
+        r = H.run_case(oracle, img, 260, 55, nrg_func=6, switch_freq=2, res_order=0,
+                       pres=D.ellipse_mask(w, h), disc=D.band_mask(w, h, w // 5, w // 3))
+    finally:
+        oracle.lib.olqrx_set_debug(0)
+    st = (ctypes.c_longlong * 8)()
+    oracle.lib.olqr_oracle_get_stats(st)
+    assert r["ret"] == 1 and r["image"].shape[:2] == (55, 260)
+    assert st[7] == 0, "back pointers to carved pixels: %d" % st[7]

@@ -131,6 +131,14 @@ def test_tie_heavy_inputs(oracle, engine):
     both(oracle, engine, D.flat_blocks(300, 200, 9, nblocks=40), 200, 150)
 
 
+def test_null_energy_with_masks(oracle, engine):
+    """heavily tied maps (fuzz find): every pixel whose parent was carved must be recomputed"""
+    w, h = 276, 80
+    both(oracle, engine, D.noise(w, h, 790234955, channels=1), 260, 55, nrg_func=6,
+         pres=D.ellipse_mask(w, h), disc=D.band_mask(w, h, w // 5, w // 3))
+    both(oracle, engine, D.flat_blocks(300, 90, 5), 250, 90, nrg_func=6, pres=D.ellipse_mask(300, 90), delta_x=2)
+
+
 def test_wide_bands_overflow_the_window(oracle, engine):
     """a band wider than the band kernel's window exercises the full-width continuation"""
     both(oracle, engine, D.noise(1500, 700, 61), 1440, 700)
