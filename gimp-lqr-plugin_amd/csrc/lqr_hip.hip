@@ -1682,7 +1682,9 @@ constexpr int DPP_OWN = 256 - 2 * DPP_HALO;     // columns a tile owns
 constexpr int DPP_R = 16;                       // rows per batch
 constexpr int DPP_W = 2;                        // waves taking turns
 static_assert(DPP_HALO % (DPP_R * DPP_W) == 0, "a block is a whole number of rounds");
-constexpr int DPP_MAX_WGS = 768;                // co-residency bound for the spin waits (the device holds 1024 of these workgroups)
+// co-residency bound for the spin waits: a CU holds 4 of these workgroups (2 waves, <=192 VGPRs each);
+// three per CU are used (768 on the 256 CUs of an MI355X), set from the device properties in lqrhip_init
+static int g_dpp_max_wgs = 768;
 
 template <bool LR, bool RIG, bool UPDATE>
 __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, DpK p, int w, int h, int stride, int *tile_flags)
@@ -2048,6 +2050,10 @@ extern "C" int lqrhip_init(void)
     HIPCK(hipMalloc((void **) &g_zero_page, 4096));
     HIPCK(hipMemsetAsync(g_zero_page, 0, 4096, g_stream0));
     HIPCK(hipStreamSynchronize(g_stream0));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g_dpp_max_wgs = 3 * prop.multiProcessorCount;
+    }
     g_device = dev;
     return dev;
 }
@@ -2432,7 +2438,7 @@ static int launch_dp_tiled(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
 // whole grid has to be resident at once.
 static bool dp_persistent_ok(const LqrHipBatch *b, int w)
 {
-    return (size_t) ((w + DPP_OWN - 1) / DPP_OWN) * b->cs.size() <= (size_t) DPP_MAX_WGS;
+    return (size_t) ((w + DPP_OWN - 1) / DPP_OWN) * b->cs.size() <= (size_t) g_dpp_max_wgs;
 }
 
 // E5 (UPDATE = false) or the full-width form of E9 (UPDATE = true) as one persistent launch
