@@ -1351,7 +1351,10 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
     const GCarver c = gview(cs[blockIdx.x]);
     extern __shared__ int s_tw[];                          // [2h]: per row, per batch-starting-at-row touch ranges
     int *s_touch = s_tw, *s_touchR = s_tw + h;
-    __shared__ __attribute__((aligned(16))) float s_row[WIN + 2 * R];     // m of the last finished row over [B-R, B+WIN+R)
+    // m of the last finished row over [B-R, B+WIN+R), double-buffered by batch parity: a slot reads its halo
+    // (the neighbours' own columns) at the start of a batch, and a neighbour that is a whole batch faster
+    // must not have overwritten them yet
+    __shared__ __attribute__((aligned(16))) float s_row[2][WIN + 2 * R];
     __shared__ int s_rec[2][NW][2];                        // [batch parity][slot] {lo, hi}: px changed on that row (lo > hi: none)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1440,7 +1443,7 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
                 const gf32 *mrow = c.m + (size_t) (y - 1) * stride;
                 for (int i = tid; i < WIN + 2 * R; i += NT) {
                     const int x = B - R + i;
-                    s_row[i] = (x >= 0 && x < w) ? __hip_atomic_load(mrow + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
+                    s_row[1][i] = (x >= 0 && x < w) ? __hip_atomic_load(mrow + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;     // read as [kpar ^ 1]
                 }
             }
             kpar = 0;
@@ -1460,7 +1463,7 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
             for (int k = 0; k < 4; k++) in[k] = (x0 + k >= 0) && (x0 + k < w);
             float mp[4];
             {
-                const f32x4 v = *(const f32x4 *) (s_row + OWN * slot + 4 * lane);
+                const f32x4 v = *(const f32x4 *) (s_row[kpar ^ 1] + OWN * slot + 4 * lane);
                 mp[0] = v[0]; mp[1] = v[1]; mp[2] = v[2]; mp[3] = v[3];
             }
             int rlo = 1 << 30, rhi = -1;
@@ -1526,7 +1529,7 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
 #pragma unroll
                     for (int k = 0; k < 4; k++) v[k] = in[k] ? q_mo[R - 1][k] : INF;
                 }
-                if (own_lane || edge_halo) *(f32x4 *) (s_row + OWN * slot + 4 * lane) = v;
+                if (own_lane || edge_halo) *(f32x4 *) (s_row[kpar] + OWN * slot + 4 * lane) = v;
                 if (lane == 0) { s_rec[kpar][slot][0] = rlo; s_rec[kpar][slot][1] = rhi; }
                 y_issue = y + 2 * R;
             }
