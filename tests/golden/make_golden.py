@@ -38,12 +38,19 @@ def cases():
                              rigidity=5.0, resize_aux_layers=True, output_seams=True))
     c["null_energy_disc_40x24"] = (D.noise(40, 24, 14), 32, 24, dict(disc=D.band_mask(40, 24, 10, 18), nrg_func=L.LQR_EF_NULL))
     c["switch_every_seam_48x32"] = (D.photo_like(48, 32, 15), 30, 32, dict(switch_freq=1000))
+    # heavily tied maps: the case in which update_mmap's band used to shrink past the carved pixel's children
+    # (spec delta 6)
+    c["null_energy_masks_276x80"] = (D.noise(276, 80, 790234955, channels=1), 260, 80,
+                                     dict(pres=D.ellipse_mask(276, 80), disc=D.band_mask(276, 80, 55, 92), nrg_func=L.LQR_EF_NULL))
     return c
 
 
 def main():
     api = L.oracle_api()
+    only = set(sys.argv[1:])          # optional: names of the fixtures to (re)write
     for name, (img, nw, nh, kw) in cases().items():
+        if only and name not in only:
+            continue
         r = H.run_case(api, img, nw, nh, **kw)
         arrays = dict(img=img, new_size=np.array([nw, nh]), image=r["image"], vmap=r["vmap"]["data"],
                       vmap_meta=np.array([r["vmap"]["depth"], r["vmap"]["orientation"]]),
