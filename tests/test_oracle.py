@@ -328,3 +328,90 @@ def test_null_energy_with_masks_never_leaves_dangling_back_pointers(oracle):
     oracle.lib.olqr_oracle_get_stats(st)
     assert r["ret"] == 1 and r["image"].shape[:2] == (55, 260)
     assert st[7] == 0, "back pointers to carved pixels: %d" % st[7]
+
+
+# ---------------------------------------------------------------------------
+# an independent restatement of a whole session (several seams): energy is recomputed from
+# scratch for every seam and update_mmap's keep-rule is applied to EVERY pixel instead of
+# liblqr's band -- by DESIGN.md section 4.4 (any superset of the pixels with changed inputs
+# gives the same memory) both must agree bit for bit, here and in the GPU kernels that rely
+# on it (k_dp_tile_p<UPDATE>, k_band_update_tw)
+# ---------------------------------------------------------------------------
+def py_session(img, n_seams, leftright=0):
+    h, w, ch = img.shape
+    rows = [[(y, x) for x in range(w)] for y in range(h)]            # surviving pixels, by id
+    m, least = {}, {}
+
+    def energy():
+        cur = np.array([[img[p] for p in r] for r in rows], dtype=np.uint8).reshape(h, len(rows[0]), ch)
+        return py_energy_xabs(cur)
+
+    def best_parent(y, x):
+        wc = len(rows[y])
+        cands = [xx for xx in (x - 1, x, x + 1) if 0 <= xx < wc]
+        bx = cands[0]
+        for xx in cands[1:]:
+            a, b = m[rows[y - 1][xx]], m[rows[y - 1][bx]]
+            if a < b or (a == b and leftright == 1):
+                bx = xx
+        return rows[y - 1][bx]
+
+    e = energy()
+    for x, p in enumerate(rows[0]):
+        m[p] = e[0, x]
+    for y in range(1, h):
+        for x, p in enumerate(rows[y]):
+            q = best_parent(y, x)
+            least[p] = q
+            m[p] = np.float32(e[y, x] + m[q])
+    seams = []
+    for s in range(n_seams):
+        wc = len(rows[0])
+        best, bx = np.float32(2 ** 29), 0
+        for x in range(wc):
+            v = m[rows[h - 1][x]]
+            if v < best or (v == best and leftright == 1):
+                best, bx = v, x
+        p = rows[h - 1][bx]
+        seam = [None] * h
+        for y in range(h - 1, -1, -1):
+            seam[y] = p
+            if y > 0:
+                p = least[p]
+                assert p in rows[y - 1], "dangling back pointer"
+        seams.append(seam)
+        for y in range(h):
+            rows[y].remove(seam[y])
+        if len(rows[0]) <= 1:
+            break
+        e = energy()
+        for x, p in enumerate(rows[0]):
+            m[p] = e[0, x]
+        for y in range(1, h):
+            for x, p in enumerate(rows[y]):
+                q = best_parent(y, x)
+                new_m = np.float32(e[y, x] + m[q])
+                if least[p] == q and float(abs(np.float32(m[p] - new_m))) < 1e-5:
+                    pass                                   # the stale value is kept
+                else:
+                    m[p] = new_m
+                least[p] = q
+    out = np.array([[img[p] for p in r] for r in rows], dtype=np.uint8).reshape(h, len(rows[0]), ch)
+    return out, seams
+
+
+@pytest.mark.parametrize("gen,seed,ch", [("noise", 5, 4), ("photo_like", 6, 3), ("flat_blocks", 7, 1), ("noise", 8, 2)])
+def test_session_matches_python_restatement_with_full_width_keep_rule(oracle, gen, seed, ch):
+    w, h, n = 26, 14, 9
+    img = getattr(D, gen)(w, h, seed, channels=ch)
+    out, seams = py_session(img, n)
+    r = H.run_case(oracle, img, w - n, h, switch_freq=0)
+    assert r["ret"] == L.LQR_OK
+    assert np.array_equal(r["image"], out)
+    # seam k of the session carries the k-th distinct non-zero level of the visibility map
+    vm = r["vmap"]["data"]
+    levels = sorted(set(int(v) for v in np.unique(vm) if v != 0))
+    assert len(levels) == n
+    for k, seam in enumerate(seams):
+        ys, xs = np.nonzero(vm == levels[k])
+        assert sorted(zip(ys.tolist(), xs.tolist())) == sorted(seam)
