@@ -19,6 +19,13 @@
 // contraction, IEEE division and sqrt) so that results are bit-identical to the
 // C arithmetic of the CPU path.  No MFMA: this is stencil + scan + shift work
 // bounded by HBM bandwidth and by the H-step dependency chains.
+//
+// Order of this file: descriptors; energy kernels; generic DP sweep (k_dp_sweep) and backtrack
+// (k_vpath, k_vpath1); carve (k_carve); energy update (k_emap_update, k_frozen_catchup); the
+// update_mmap kernels -- generic band (k_band_update), multi-wave band (k_band_update_mw), the
+// shared DP row (dp_row4), trapezoid-wave band (k_band_update_tw), tiled sweeps (k_dp_tile,
+// k_dp_tile_p); visibility map / inflate / compaction / transpose; then the host side of the
+// shim (allocation cache, batches, lqrhip_seam_step's per-seam sequence, read-out).
 #include <hip/hip_runtime.h>
 #include <utility>
 #include <type_traits>
