@@ -415,3 +415,15 @@ def test_session_matches_python_restatement_with_full_width_keep_rule(oracle, ge
     for k, seam in enumerate(seams):
         ys, xs = np.nonzero(vm == levels[k])
         assert sorted(zip(ys.tolist(), xs.tolist())) == sorted(seam)
+
+
+@pytest.mark.parametrize("gen,seed,ch", [("noise", 15, 3), ("photo_like", 16, 4)])
+def test_vertical_session_is_the_transposed_horizontal_one(oracle, gen, seed, ch):
+    """E11: a height change is the same session on the transposed image (src/render.c resizes width, then
+    height; liblqr transposes the carver in between)"""
+    w, h, n = 15, 22, 6
+    img = getattr(D, gen)(w, h, seed, channels=ch)
+    out_t, _ = py_session(np.ascontiguousarray(img.transpose(1, 0, 2)), n)
+    r = H.run_case(oracle, img, w, h - n, switch_freq=0)
+    assert r["ret"] == L.LQR_OK
+    assert np.array_equal(r["image"], out_t.transpose(1, 0, 2))
