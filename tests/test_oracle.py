@@ -337,8 +337,11 @@ def test_null_energy_with_masks_never_leaves_dangling_back_pointers(oracle):
 # gives the same memory) both must agree bit for bit, here and in the GPU kernels that rely
 # on it (k_dp_tile_p<UPDATE>, k_band_update_tw)
 # ---------------------------------------------------------------------------
-def py_session(img, n_seams, leftright=0):
+def py_session(img, n_seams, leftright=0, switch_freq=0):
+    """switch_freq: number of side switches per session (spec delta 1): at a switch the
+    seam is still picked with the old tie rule, then the map is rebuilt from scratch with the new one"""
     h, w, ch = img.shape
+    interval = (n_seams - 1) // switch_freq + 1 if switch_freq else 0
     rows = [[(y, x) for x in range(w)] for y in range(h)]            # surviving pixels, by id
     m, least = {}, {}
 
@@ -346,7 +349,10 @@ def py_session(img, n_seams, leftright=0):
         cur = np.array([[img[p] for p in r] for r in rows], dtype=np.uint8).reshape(h, len(rows[0]), ch)
         return py_energy_xabs(cur)
 
+    lr = [leftright]
+
     def best_parent(y, x):
+        leftright = lr[0]
         wc = len(rows[y])
         cands = [xx for xx in (x - 1, x, x + 1) if 0 <= xx < wc]
         bx = cands[0]
@@ -370,8 +376,11 @@ def py_session(img, n_seams, leftright=0):
         best, bx = np.float32(2 ** 29), 0
         for x in range(wc):
             v = m[rows[h - 1][x]]
-            if v < best or (v == best and leftright == 1):
+            if v < best or (v == best and lr[0] == 1):
                 best, bx = v, x
+        rebuild = bool(interval) and (s + interval // 2) % interval == 0
+        if rebuild:
+            lr[0] ^= 1
         p = rows[h - 1][bx]
         seam = [None] * h
         for y in range(h - 1, -1, -1):
@@ -391,7 +400,7 @@ def py_session(img, n_seams, leftright=0):
             for x, p in enumerate(rows[y]):
                 q = best_parent(y, x)
                 new_m = np.float32(e[y, x] + m[q])
-                if least[p] == q and float(abs(np.float32(m[p] - new_m))) < 1e-5:
+                if not rebuild and least[p] == q and float(abs(np.float32(m[p] - new_m))) < 1e-5:
                     pass                                   # the stale value is kept
                 else:
                     m[p] = new_m
@@ -427,3 +436,13 @@ def test_vertical_session_is_the_transposed_horizontal_one(oracle, gen, seed, ch
     r = H.run_case(oracle, img, w, h - n, switch_freq=0)
     assert r["ret"] == L.LQR_OK
     assert np.array_equal(r["image"], out_t.transpose(1, 0, 2))
+
+
+@pytest.mark.parametrize("freq", [1, 2, 3, 100])
+def test_side_switch_schedule_matches_python_restatement(oracle, freq):
+    """the tie rule flips `freq` times per session, each flip with a full rebuild (freq >= seams: every seam)"""
+    w, h, n = 24, 12, 8
+    img = D.flat_blocks(w, h, 21, channels=3)          # many ties: the tie rule matters
+    out, _ = py_session(img, n, switch_freq=freq)
+    r = H.run_case(oracle, img, w - n, h, switch_freq=freq)
+    assert np.array_equal(r["image"], out)
