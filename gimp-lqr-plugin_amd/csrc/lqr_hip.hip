@@ -120,6 +120,22 @@ struct DpK {
 static thread_local std::string g_err;
 static int g_device = -1;
 
+// Device-side failures (a spin wait that timed out because a persistent grid was not co-resident, a
+// prediction that did not hold) never trap: the kernel stores a code in this host-mapped word and
+// leaves; the host finds it at its next synchronisation and returns LQRHIP_EHIP (-> LQR_ERROR).
+#define DEVERR_TILE_TIMEOUT 1
+#define DEVERR_BAND_PREDICTION 2
+static int *g_dev_err_host = nullptr;      // hipHostMalloc'ed, mapped
+static int *g_dev_err = nullptr;           // its device address
+__device__ __forceinline__ void dev_fail(int *flag, int code)
+{
+    __hip_atomic_store(flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ int dev_failed(int *flag)
+{
+    return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 #define HIPCK_VOID(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { g_err = std::string(#expr) + ": " + hipGetErrorString(e__); (void) hipGetLastError(); } } while (0)
 #define HIPCK(expr)                                                                   \
     do {                                                                              \
@@ -733,9 +749,12 @@ __device__ __forceinline__ int block_rank_256(bool flag, int *s_wave, int &total
 // of the session; current coordinates are mapped back by undoing seams k..epoch of the
 // row (p += (log[j] <= p)), which costs O(k - epoch) per pixel for ~10 pixels per row and
 // saves moving 4 (8 with bias) of the 13 bytes per pixel that a carve would otherwise move.
-#define EU_NT 12            // brightness samples per row tile
+// Brightness samples staged per row: row y is asked for columns [min - 2, max + 1] of the seam over rows
+// y-1..y+1 by its own gradient and [min - 1, max] of the seam over rows y-2..y+2 by its neighbours', and the
+// seam moves at most delta_x per row: at most max(4*delta_x + 2, 2*delta_x + 4) columns.  EU_NT is a template
+// parameter chosen by the launch from delta_x: 12 (delta_x <= 2), 36 (<= 8), 68 (<= 16 = LQRHIP_MAX_DELTA).
 #define EU_ROWS 62          // rows per block (+2 halo rows)
-template <int NRG>
+template <int NRG, int EU_NT>
 __global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, int w, int h, int stride, int k, int epoch, int pre_shift)
 {
     const GCarver c = gview(cs[blockIdx.y]);
@@ -1352,7 +1371,7 @@ constexpr int TW_R = 16;                     // rows per batch = halo columns
 constexpr int TW_OWN = 256 - 2 * TW_R;       // own columns per slot
 
 template <int NW, bool LR, bool RIG>
-__global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs, DpK p, int w, int h, int stride)
+__global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs, DpK p, int w, int h, int stride, int *dev_err)
 {
     constexpr int R = TW_R, OWN = TW_OWN, WIN = NW * OWN, NT = 128 * NW;
     const GCarver c = gview(cs[blockIdx.x]);
@@ -1464,7 +1483,9 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
         const bool own_lane = lane >= R / 4 && lane < 64 - R / 4;
         if (par_w == kpar) {
             const bool active = force_active || (lo - R <= own_hi && hi + R >= own_lo);
-            if (active && !loads_full) __builtin_trap();      // the prediction below is a superset by construction
+            // the prediction below is a superset by construction; should it ever fail, say so instead of
+            // computing on rows that were not loaded (the host turns the flag into LQR_ERROR)
+            if (active && !loads_full && lane == 0) dev_fail(dev_err, DEVERR_BAND_PREDICTION);
             bool in[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) in[k] = (x0 + k >= 0) && (x0 + k < w);
@@ -1692,14 +1713,16 @@ constexpr int DPP_OWN = 256 - 2 * DPP_HALO;     // columns a tile owns
 constexpr int DPP_R = 16;                       // rows per batch
 constexpr int DPP_W = 2;                        // waves taking turns
 static_assert(DPP_HALO % (DPP_R * DPP_W) == 0, "a block is a whole number of rounds");
-// co-residency bound for the spin waits: a CU holds 4 of these workgroups (2 waves, <=192 VGPRs each);
-// three per CU are used (768 on the 256 CUs of an MI355X), set from the device properties in lqrhip_init
-static int g_dpp_max_wgs = 768;
+// co-residency bound for the spin waits, set from the occupancy query in lqrhip_init (dpp_resident_workgroups)
+static int g_dpp_max_wgs = 0;
 
 template <bool LR, bool RIG, bool UPDATE>
-__global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, DpK p, int w, int h, int stride, int *tile_flags)
+__global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, DpK p, int w, int h, int stride, int *tile_flags, int *dev_err)
 {
     __shared__ f32x4 s_mp[64];                   // the row above the next batch, handed from wave to wave
+    __shared__ int s_fail;                       // a neighbour never showed up: both waves leave at the next barrier
+    if (threadIdx.x == 0) s_fail = 0;
+    __syncthreads();
     const GCarver c = gview(cs[blockIdx.y]);
     gf32 *m_out = UPDATE ? c.m2 : c.m;
     gi8 *least_out = UPDATE ? c.least2 : c.least;
@@ -1782,17 +1805,24 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, D
                     mp[0] = v[0]; mp[1] = v[1]; mp[2] = v[2]; mp[3] = v[3];
                 }
                 if (bb == 0 && j > 0) {
-                    // neighbours must have published block j-1; every spin is bounded (a tile that never shows
-                    // up means the grid was not co-resident: trap, the host sees the error at its next sync)
+                    // neighbours must have published block j-1; every spin is bounded.  A tile that never shows
+                    // up means the grid was not co-resident (the host sizes it from the occupancy query, but the
+                    // GPU may be shared): record the failure in the host-visible error word and stop waiting --
+                    // every other tile sees the word in its own spin loop and leaves too, the host returns
+                    // LQR_ERROR at its next synchronisation.  Nothing traps.
+                    bool failed = false;
                     for (int side = -1; side <= 1; side += 2) {
                         const int nb = tile + side;
                         if (nb < 0 || nb >= ntiles) continue;
                         int spins = 0;
-                        while (__hip_atomic_load(flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < j) {
+                        while (!failed && __hip_atomic_load(flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < j) {
                             __builtin_amdgcn_s_sleep(2);
-                            if (++spins > (1 << 24)) __builtin_trap();
+                            ++spins;
+                            if ((spins & 1023) == 0 && dev_failed(dev_err)) failed = true;
+                            if (spins > (1 << 24)) { if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); failed = true; }
                         }
                     }
+                    if (failed) s_fail = 1;
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     if (!own_lane) {
                         // halo columns: the tile's own values there are contaminated from the tile edge inwards
@@ -1822,6 +1852,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, D
             }
             // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. every wave's prefetch
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (s_fail) return;                  // uniform: written before the barrier, read by both waves after it
         }
     }
 }
@@ -2043,6 +2074,28 @@ static uint32_t *g_zero_page = nullptr;     // 4 KB of zeros on the device (k_vp
 
 extern "C" const char *lqrhip_last_error(void) { return g_err.c_str(); }
 
+// Workgroups of k_dp_tile_p the device holds at once.  Its tiles spin on their neighbours, so the grid
+// must be co-resident: the bound comes from the occupancy query of every instantiation that can be
+// launched (the minimum over them), less one workgroup per CU of margin -- the API is known to answer
+// one block per CU too many at some SGPR counts (MI355X_MICROARCH.md, residency) -- times the CU count.
+// A grid above the bound goes to k_dp_tile (kernel boundaries instead of spin waits).
+static int dpp_resident_workgroups(int dev)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return 0;
+    int per_cu = 1 << 20;
+    auto q = [&](auto kern) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 64 * DPP_W, 0) != hipSuccess) { (void) hipGetLastError(); n = 0; }
+        per_cu = std::min(per_cu, n);
+    };
+    q(k_dp_tile_p<false, false, false>); q(k_dp_tile_p<false, true, false>); q(k_dp_tile_p<true, false, false>); q(k_dp_tile_p<true, true, false>);
+    q(k_dp_tile_p<false, false, true>); q(k_dp_tile_p<false, true, true>); q(k_dp_tile_p<true, false, true>); q(k_dp_tile_p<true, true, true>);
+    const char *e = getenv("LQRHIP_DPP_WGS_PER_CU");        // test hook: 0 forces the k_dp_tile path
+    if (e) per_cu = std::min(per_cu, atoi(e) + 1);
+    return std::max(0, per_cu - 1) * prop.multiProcessorCount;
+}
+
 extern "C" int lqrhip_init(void)
 {
     if (g_device >= 0) return g_device;
@@ -2060,12 +2113,24 @@ extern "C" int lqrhip_init(void)
     HIPCK(hipMalloc((void **) &g_zero_page, 4096));
     HIPCK(hipMemsetAsync(g_zero_page, 0, 4096, g_stream0));
     HIPCK(hipStreamSynchronize(g_stream0));
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g_dpp_max_wgs = 3 * prop.multiProcessorCount;
-    }
+    HIPCK(hipHostMalloc((void **) &g_dev_err_host, sizeof(int), hipHostMallocMapped));
+    *g_dev_err_host = 0;
+    HIPCK(hipHostGetDevicePointer((void **) &g_dev_err, g_dev_err_host, 0));
+    g_dpp_max_wgs = dpp_resident_workgroups(dev);
     g_device = dev;
     return dev;
+}
+
+// a kernel recorded a failure (dev_fail): report it once, as an error return, and clear the word
+static int check_dev_error(void)
+{
+    if (!g_dev_err_host || *g_dev_err_host == 0) return 0;
+    const int code = *g_dev_err_host;
+    *g_dev_err_host = 0;
+    g_err = code == DEVERR_TILE_TIMEOUT ? "persistent tiled DP sweep: a neighbour tile never became resident (GPU shared or partitioned?); "
+                                          "results of this resize are invalid"
+                                        : "band update: activity prediction failed; results of this resize are invalid";
+    return LQRHIP_EHIP;
 }
 
 // Device allocations go through a small size-class cache: the carve path allocates and frees
@@ -2192,19 +2257,24 @@ static int ensure_working(LqrHipCarver *c, int w, int h)
     bool need_bias = c->bias0 != nullptr, need_rig = c->rig0 != nullptr;
     if (c->pix && c->stride == stride && c->wk_h == h && (!!c->bias == need_bias) && (!!c->rig == need_rig)) return 0;
     free_working(c);
+    c->stride = 0; c->wk_h = 0;
     size_t n = (size_t) stride * (h + 1) + 1024;
     int rc;
     if ((rc = dmalloc(&c->pix, n)) || (rc = dmalloc(&c->en, n)) || (rc = dmalloc(&c->m, n)) || (rc = dmalloc(&c->least, n)) ||
-        (rc = dmalloc(&c->seam_x, (size_t) h + 8)) || (rc = dmalloc(&c->flags, FLAG_COUNT)) || (rc = dmalloc(&c->progress, (size_t) h / 64 + 2)))
+        (rc = dmalloc(&c->seam_x, (size_t) h + 8)) || (rc = dmalloc(&c->flags, FLAG_COUNT)) || (rc = dmalloc(&c->progress, (size_t) h / 64 + 2)) ||
+        (need_bias && (rc = dmalloc(&c->bias, n))) || (need_rig && (rc = dmalloc(&c->rig, n)))) {
+        free_working(c);            // never leave a half-allocated set behind: a retry must not pass the early-out above
         return rc;
-    if (need_bias && (rc = dmalloc(&c->bias, n))) return rc;
-    if (need_rig && (rc = dmalloc(&c->rig, n))) return rc;
-    HIPCK(dzero(c->least, n));
-    HIPCK(dzero(c->m, n * sizeof(float)));
-    HIPCK(dzero(c->en, n * sizeof(float)));
-    HIPCK(dzero(c->pix, n * sizeof(uint32_t)));
-    HIPCK(dzero(c->flags, FLAG_COUNT * sizeof(int32_t)));
-    HIPCK(dzero(c->progress, ((size_t) h / 64 + 2) * sizeof(int32_t)));
+    }
+    // all on the shim's stream, one synchronisation
+    hipError_t e = hipMemsetAsync(c->least, 0, n, g_stream0);
+    if (e == hipSuccess) e = hipMemsetAsync(c->m, 0, n * sizeof(float), g_stream0);
+    if (e == hipSuccess) e = hipMemsetAsync(c->en, 0, n * sizeof(float), g_stream0);
+    if (e == hipSuccess) e = hipMemsetAsync(c->pix, 0, n * sizeof(uint32_t), g_stream0);
+    if (e == hipSuccess) e = hipMemsetAsync(c->flags, 0, FLAG_COUNT * sizeof(int32_t), g_stream0);
+    if (e == hipSuccess) e = hipMemsetAsync(c->progress, 0, ((size_t) h / 64 + 2) * sizeof(int32_t), g_stream0);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream0);
+    if (e != hipSuccess) { free_working(c); HIPCK(e); }
     c->carve_epoch = 0;
     c->stride = stride; c->wk_h = h;
     if (c->batch) c->batch->dirty = true;
@@ -2314,7 +2384,7 @@ extern "C" void lqrhip_batch_destroy(LqrHipBatch *b)
 extern "C" int lqrhip_batch_sync(LqrHipBatch *b)
 {
     HIPCK(hipStreamSynchronize(b->stream));
-    return 0;
+    return check_dev_error();
 }
 extern "C" void *lqrhip_batch_stream(LqrHipBatch *b) { return (void *) b->stream; }
 
@@ -2377,6 +2447,10 @@ static int g_update_mode = -1;
 // -1: by batch size (LQRHIP_TILED_UPDATE_PX); 0: band kernel (k_band_update_tw); 1: tiled full-width update whenever its
 // grid fits; 2: the older band kernel (k_band_update_mw, overlapped with the carve for large batches)
 extern "C" void lqrhip_set_update_mode(int mode) { g_update_mode = mode; }
+static int g_dpp_limit_override = -1;
+// -1: the occupancy-derived bound (dpp_resident_workgroups); >= 0: at most that many workgroups for the persistent
+// tiled sweep -- 0 sends every full DP to k_dp_tile and every incremental update to a band kernel
+extern "C" void lqrhip_set_dp_persistent_limit(int workgroups) { g_dpp_limit_override = workgroups; }
 extern "C" void lqrhip_prof_reset(void)
 {
     for (auto &kv : g_profrec) for (auto &e : kv.second.ev) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
@@ -2448,7 +2522,8 @@ static int launch_dp_tiled(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
 // whole grid has to be resident at once.
 static bool dp_persistent_ok(const LqrHipBatch *b, int w)
 {
-    return (size_t) ((w + DPP_OWN - 1) / DPP_OWN) * b->cs.size() <= (size_t) g_dpp_max_wgs;
+    const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs) : g_dpp_max_wgs;
+    return (size_t) ((w + DPP_OWN - 1) / DPP_OWN) * b->cs.size() <= (size_t) limit;
 }
 
 // E5 (UPDATE = false) or the full-width form of E9 (UPDATE = true) as one persistent launch
@@ -2465,19 +2540,25 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
         if ((rc = dmalloc(&b->tile_flags, (size_t) ntiles * n + 64))) return rc;
         b->tile_flags_elems = (size_t) ntiles * n + 64;
     }
-    if (UPDATE && !c0->m2) {
-        // second planes, allocated on first use
-        HIPCK(hipStreamSynchronize(b->stream));
+    if (UPDATE) {
+        // second planes, allocated on first use -- per carver: a batch may mix carvers that already went
+        // through a tiled update on their own with fresh ones
+        bool grew = false;
         for (auto *c : b->cs) {
+            if (c->m2 && c->least2) continue;
+            if (!grew) { HIPCK(hipStreamSynchronize(b->stream)); grew = true; }
             const size_t pe = (size_t) c->stride * (c->wk_h + 1) + 1024;
-            if ((rc = dmalloc(&c->m2, pe)) || (rc = dmalloc(&c->least2, pe))) return rc;
+            if (!c->m2 && (rc = dmalloc(&c->m2, pe))) return rc;
+            if (!c->least2 && (rc = dmalloc(&c->least2, pe))) return rc;
         }
-        b->dirty = true;
-        if ((rc = batch_upload(b))) return rc;
+        if (grew) {
+            b->dirty = true;
+            if ((rc = batch_upload(b))) return rc;
+        }
     }
     HIPCK(hipMemsetAsync(b->tile_flags, 0, (size_t) ntiles * n * sizeof(int), b->stream));
     const dim3 grid(ntiles, (unsigned) n);
-#define LAUNCH_TILE(LRV, RIGV) hipLaunchKernelGGL((k_dp_tile_p<LRV, RIGV, UPDATE>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->tile_flags)
+#define LAUNCH_TILE(LRV, RIGV) hipLaunchKernelGGL((k_dp_tile_p<LRV, RIGV, UPDATE>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->tile_flags, g_dev_err)
     if (lr) { if (k.use_rig) LAUNCH_TILE(true, true); else LAUNCH_TILE(true, false); }
     else { if (k.use_rig) LAUNCH_TILE(false, true); else LAUNCH_TILE(false, false); }
 #undef LAUNCH_TILE
@@ -2621,9 +2702,11 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
             if (rc2) return rc2;
         }
         const int epoch = c0->frozen_epoch;
-#define LAUNCH_EUPD(N) hipLaunchKernelGGL((k_emap_update<N>), dim3((h + EU_ROWS - 1) / EU_ROWS, n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, log_index, epoch, pre_shift)
+#define LAUNCH_EUPD_NT(N, NT) hipLaunchKernelGGL((k_emap_update<N, NT>), dim3((h + EU_ROWS - 1) / EU_ROWS, n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, log_index, epoch, pre_shift)
+#define LAUNCH_EUPD(N) do { if (p->delta_x <= 2) LAUNCH_EUPD_NT(N, 12); else if (p->delta_x <= 8) LAUNCH_EUPD_NT(N, 36); else LAUNCH_EUPD_NT(N, 68); } while (0)
         NRG_DISPATCH(p->nrg_func, LAUNCH_EUPD)
 #undef LAUNCH_EUPD
+#undef LAUNCH_EUPD_NT
         return 0;
     };
     auto launch_carve = [&](hipStream_t st) {
@@ -2642,7 +2725,7 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     auto launch_fast_band = [&](int gate_arg) {
         if (band_tw) {
             ProfScope ps("band_update", b->stream, 0);
-#define LAUNCH_TW(NWV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_tw<NWV, LRV, RIGV>), dim3(n), dim3(128 * NWV), (size_t) 2 * h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride)
+#define LAUNCH_TW(NWV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_tw<NWV, LRV, RIGV>), dim3(n), dim3(128 * NWV), (size_t) 2 * h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, g_dev_err)
 #define LAUNCH_TW_N(LRV, RIGV) LAUNCH_TW(4, LRV, RIGV)
             if (leftright_next) { if (p->use_rigidity) LAUNCH_TW_N(true, true); else LAUNCH_TW_N(true, false); }
             else { if (p->use_rigidity) LAUNCH_TW_N(false, true); else LAUNCH_TW_N(false, false); }
@@ -2981,7 +3064,7 @@ extern "C" void lqrhip_pool_trim(void)
 extern "C" int lqrhip_device_sync(void)
 {
     HIPCK(hipDeviceSynchronize());
-    return 0;
+    return check_dev_error();
 }
 
 extern "C" int lqrhip_read_vmap(LqrHipCarver *c, int w0, int h0, int w, int level, int depth, int *out)
@@ -3022,5 +3105,128 @@ extern "C" int lqrhip_read_working(LqrHipCarver *c, int w, int h, float *en, flo
         for (int y = 0; y < h; y++)
             for (int x = 0; x < w; x++) least_dx[(size_t) y * w + x] = y == 0 ? 0 : (int) tl[(size_t) y * c->stride + x];
     }
+    return 0;
+}
+
+// ---- start over from a device-resident image ---------------------------------------------------
+extern "C" int lqrhip_carver_reset(LqrHipCarver *c, const void *device_rgb, int w, int h)
+{
+    if (!c || c->root || !c->aux.empty() || w < 1 || h < 1) return LQRHIP_EARG;
+    int rc = batch_sync_of(c);
+    if (rc) return rc;
+    const size_t n = (size_t) w * h;
+    dfree(c->rgb0); dfree(c->vs); dfree(c->bias0); dfree(c->rig0);
+    // a carver that had masks carries bias / rig working planes: the fresh carver has none
+    if (c->bias || c->rig) { free_working(c); c->stride = 0; c->wk_h = 0; }
+    c->w0 = w; c->h0 = h;
+    c->frozen_epoch = 0;
+    if ((rc = dmalloc(&c->rgb0, n * c->ch)) || (rc = dmalloc(&c->vs, n))) return rc;
+    HIPCK(hipMemcpyAsync(c->rgb0, device_rgb, n * c->ch, hipMemcpyDeviceToDevice, g_stream0));
+    HIPCK(hipMemsetAsync(c->vs, 0, n * sizeof(int32_t), g_stream0));
+    if (c->batch) c->batch->dirty = true;
+    if (c->active && (rc = ensure_working(c, w, h))) return rc;        // synchronises g_stream0 when it allocates
+    return 0;
+}
+
+// order everything the shim enqueued on its own stream (resets, mask uploads) before the caller goes on
+extern "C" int lqrhip_reset_sync(void)
+{
+    if (g_stream0) HIPCK(hipStreamSynchronize(g_stream0));
+    return 0;
+}
+
+extern "C" int lqrhip_mem_info(unsigned long long *free_bytes, unsigned long long *total_bytes, unsigned long long *cached_bytes)
+{
+    if (lqrhip_init() < 0) return LQRHIP_EHIP;
+    size_t f = 0, t = 0;
+    HIPCK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    if (cached_bytes) *cached_bytes = g_pool_cached;
+    return 0;
+}
+
+// ---- measured HBM ceiling: plain streaming copy, 16 B per lane, grid-stride, 8 loads in flight per lane
+__global__ __launch_bounds__(256) void k_copy16(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t n16)
+{
+    const size_t stride = (size_t) gridDim.x * 256;
+    size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        u32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load(src + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < 8; k++) __builtin_nontemporal_store(v[k], dst + i + k * stride);
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+extern "C" int lqrhip_copy_bandwidth(unsigned long long bytes, int iters, double *gbps)
+{
+    if (lqrhip_init() < 0) return LQRHIP_EHIP;
+    if (iters < 1 || bytes < 4096) return LQRHIP_EARG;
+    uint8_t *a = nullptr, *b = nullptr;
+    int rc;
+    if ((rc = dmalloc(&a, bytes)) || (rc = dmalloc(&b, bytes))) { dfree(a); return rc; }
+    HIPCK(hipMemsetAsync(a, 1, bytes, g_stream0));
+    hipEvent_t e0, e1;
+    HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
+    const size_t n16 = bytes / 16;
+    const dim3 grid(256 * 16);
+    hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, g_stream0, (const u32x4 *) a, (u32x4 *) b, n16);     // warm-up
+    HIPCK(hipEventRecord(e0, g_stream0));
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, g_stream0, (const u32x4 *) a, (u32x4 *) b, n16);
+    HIPCK(hipEventRecord(e1, g_stream0));
+    HIPCK(hipStreamSynchronize(g_stream0));
+    float ms = 0;
+    HIPCK(hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    dfree(a); dfree(b);
+    if (gbps) *gbps = 2.0 * (double) (n16 * 16) * iters / (ms * 1e-3) / 1e9;
+    return 0;
+}
+
+// ---- seam-map colour ramp -----------------------------------------------------
+// write_vmap_to_layer's per-pixel arithmetic, src/io_functions.c:249-279, in double with every
+// operation individually rounded; (guchar)(255 * x) truncates.  One thread per pixel, streaming.
+__global__ __launch_bounds__(256) void k_vmap_ramp(const int32_t *__restrict__ vmap, uint32_t *__restrict__ out, size_t n, int depth,
+                                                   double sr, double sg, double sb, double er, double eg, double eb)
+{
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int vs = vmap[i];
+    uint32_t px = 0;                                                     // vs == 0: all four bytes 0 (:253-259)
+    if (vs != 0) {
+        const double value = __ddiv_rn((double) (depth + 1 - vs), (double) (depth + 1));        // :263
+        const double inv = __dsub_rn(1.0, value);
+        const double rd = __dadd_rn(__dmul_rn(value, sr), __dmul_rn(inv, er));                    // :264
+        const double gr = __dadd_rn(__dmul_rn(value, sg), __dmul_rn(inv, eg));                    // :265
+        const double bl = __dadd_rn(__dmul_rn(value, sb), __dmul_rn(inv, eb));                    // :266
+        const double al = __dmul_rn(0.5, __dadd_rn(1.0, value));                                  // :267
+        // (guchar) of a double: truncation towards zero, then the low 8 bits (values are in [0, 255])
+        const uint32_t r8 = (uint32_t) (int) __dmul_rn(255.0, rd) & 0xffu, g8 = (uint32_t) (int) __dmul_rn(255.0, gr) & 0xffu;
+        const uint32_t b8 = (uint32_t) (int) __dmul_rn(255.0, bl) & 0xffu, a8 = (uint32_t) (int) __dmul_rn(255.0, al) & 0xffu;
+        px = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
+    }
+    out[i] = px;
+}
+
+extern "C" int lqrhip_vmap_to_rgba(const int *vmap, int w, int h, int depth, const double col_start[3], const double col_end[3],
+                                   unsigned char *out_rgba)
+{
+    if (lqrhip_init() < 0) return LQRHIP_EHIP;
+    if (!vmap || !out_rgba || w < 1 || h < 1) return LQRHIP_EARG;
+    const size_t n = (size_t) w * h;
+    int32_t *dv = nullptr;
+    uint32_t *dout = nullptr;
+    int rc;
+    if ((rc = dmalloc(&dv, n)) || (rc = dmalloc(&dout, n))) { dfree(dv); return rc; }
+    HIPCK(hipMemcpyAsync(dv, vmap, n * sizeof(int32_t), hipMemcpyHostToDevice, g_stream0));
+    hipLaunchKernelGGL(k_vmap_ramp, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, g_stream0, dv, dout, n, depth, col_start[0], col_start[1],
+                       col_start[2], col_end[0], col_end[1], col_end[2]);
+    HIPCK(hipGetLastError());
+    HIPCK(hipMemcpyAsync(out_rgba, dout, n * 4, hipMemcpyDeviceToHost, g_stream0));
+    HIPCK(hipStreamSynchronize(g_stream0));
+    dfree(dv); dfree(dout);
     return 0;
 }

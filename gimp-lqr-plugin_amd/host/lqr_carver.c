@@ -55,6 +55,7 @@ struct _LqrCarver {
     int w_start, h_start, w, h, w0, h0;
     int level, max_level;
     int channels;
+    int img_w, img_h;           /* the image handed to lqr_carver_new */
     int transposed;
     int active;
     LqrCarver *root;
@@ -175,6 +176,7 @@ LqrCarver *lqr_carver_new(guchar *buffer, gint width, gint height, gint channels
     r->w = r->w0 = r->w_start = width;
     r->h = r->h0 = r->h_start = height;
     r->channels = channels;
+    r->img_w = width; r->img_h = height;
     r->nrg_func = LQR_EF_GRAD_XABS;
     r->nrg_radius = 1;
     r->enl_step = 2.0f;
@@ -720,6 +722,43 @@ LqrRetVal lqrx_carver_read_image(LqrCarver *r, guchar *out)
 LqrRetVal lqrx_carver_read_image_device(LqrCarver *r, void *device_ptr)
 {
     HIP_CATCH(lqrhip_read_visible_device(r->dev, r->w0, r->h0, r->w, r->level, device_ptr));
+    return LQR_OK;
+}
+
+/* ======================= seam-map colour ramp (I5) ======================== */
+LqrRetVal lqrx_vmap_to_rgba(LqrVMap *v, const gdouble col_start[3], const gdouble col_end[3], guchar *out_rgba)
+{
+    if (!v || !v->buffer || !out_rgba) return LQR_ERROR;
+    HIP_CATCH(lqrhip_vmap_to_rgba(v->buffer, v->width, v->height, v->depth, col_start, col_end, out_rgba));
+    return LQR_OK;
+}
+
+/* ======================= reload from device memory ======================= */
+LqrRetVal lqrx_carver_reload_device_batch(LqrCarver **rs, gint n, void *const *device_rgb)
+{
+    int i, x;
+    if (n < 1) return LQR_ERROR;
+    for (i = 0; i < n; i++)
+        if (!rs[i] || rs[i]->root || rs[i]->attached || !device_rgb[i]) return LQR_ERROR;
+    for (i = 0; i < n; i++) {
+        LqrCarver *r = rs[i];
+        LqrVMapList *v, *vn;
+        HIP_CATCH(lqrhip_carver_reset(r->dev, device_rgb[i], r->img_w, r->img_h));
+        for (v = r->flushed_vs; v; v = vn) { vn = v->next; lqr_vmap_destroy(v->current); free(v); }
+        r->flushed_vs = NULL;
+        r->level = r->max_level = 1;
+        r->w = r->w0 = r->w_start = r->img_w;
+        r->h = r->h0 = r->h_start = r->img_h;
+        r->transposed = 0;
+        r->leftright = 0;
+        r->has_bias = r->has_rigmask = 0;
+        r->wk_valid = 0;
+        r->ro_valid = 0; r->ro_line = 0;
+        if (r->active)      /* as lqr_carver_init */
+            for (x = -r->delta_x; x <= r->delta_x; x++)
+                r->rigidity_map[x + r->delta_x] = r->rigidity * powf(fabsf((float) x), 1.5f) / r->h;
+    }
+    HIP_CATCH(lqrhip_reset_sync());
     return LQR_OK;
 }
 

@@ -212,6 +212,21 @@ gint lqrx_guess_new_size(const guchar *mask, gint channels, gint width, gint hei
  * batched launch sequence (the per-frame batch axis). */
 LqrRetVal lqrx_carver_resize_batch(LqrCarver **carvers, gint n, gint w1, gint h1);
 
+/* The plug-in's seam-map colour ramp, write_vmap_to_layer's per-pixel loop (src/io_functions.c:249-279),
+ * over a dumped map: out_rgba receives get_width*get_height RGBA pixels, row-major.  For vs != 0:
+ * value = (double)(depth+1-vs)/(depth+1); R,G,B = (guchar)(255*(value*col_start + (1-value)*col_end));
+ * A = (guchar)(255*0.5*(1+value)); vs == 0 -> 0,0,0,0.  col_* are GimpRGB's r,g,b doubles in [0,1]
+ * (src/io_functions.c:196,208-209).  The engine runs it as one streaming kernel. */
+LqrRetVal lqrx_vmap_to_rgba(LqrVMap *vmap, const gdouble col_start[3], const gdouble col_end[3], guchar *out_rgba);
+/* ENGINE ONLY (the oracle returns LQR_ERROR).  Start n carvers over from images that already sit in
+ * device memory: equivalent to lqr_carver_destroy + lqr_carver_new(buffer, w, h, channels) +
+ * lqr_carver_init(delta_x, rigidity) with the same geometry, channels, delta_x and rigidity, except
+ * that the pixels come from device_rgb[i] (w*h*channels interleaved bytes, image orientation) by a
+ * device-to-device copy, and that the configuration set through lqr_carver_set_* is kept.  Masks,
+ * the visibility map and dumped maps are dropped.  Carvers with attached carvers are refused.
+ * This is how a batch driver with HBM-resident inputs (bench.py) reuses one set of carvers. */
+LqrRetVal lqrx_carver_reload_device_batch(LqrCarver **carvers, gint n, void *const *device_rgb);
+
 #ifdef __cplusplus
 }
 #endif

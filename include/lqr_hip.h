@@ -50,6 +50,14 @@ const char *lqrhip_last_error(void);
  * base layout.  The host buffer is not retained. */
 LqrHipCarver *lqrhip_carver_create(const unsigned char *rgb, int w, int h, int channels);
 void lqrhip_carver_destroy(LqrHipCarver *c);
+/* Start over on an existing carver, as lqr_carver_destroy + lqr_carver_new + lqr_carver_init would
+ * (render.c:376,222,224), but from an image that is already in HBM: the base layout becomes the
+ * w x h x channels interleaved u8 image at `device_rgb` (device-to-device copy on the shim's stream),
+ * the visibility map is cleared, masks are dropped; working planes are kept when the geometry is the
+ * same.  For batch drivers that keep their inputs device-resident (bench.py). */
+int lqrhip_carver_reset(LqrHipCarver *c, const void *device_rgb, int w, int h);
+/* wait for the copies lqrhip_carver_reset enqueued */
+int lqrhip_reset_sync(void);
 /* attached carver (render.c:897): shares the root's visibility map */
 int lqrhip_carver_attach(LqrHipCarver *root, LqrHipCarver *aux);
 /* E1 lqr_carver_init (render.c:224): allocate the working planes
@@ -109,6 +117,16 @@ int lqrhip_mask_line_max(const unsigned char *mask, int channels, int width, int
 /* same, but into a caller-provided device buffer (no host round trip) */
 int lqrhip_read_visible_device(LqrHipCarver *c, int w0, int h0, int w, int level, void *device_out);
 int lqrhip_device_sync(void);
+/* free / total device memory in bytes (hipMemGetInfo) and the bytes the shim's allocation cache holds */
+int lqrhip_mem_info(unsigned long long *free_bytes, unsigned long long *total_bytes, unsigned long long *cached_bytes);
+/* Measured HBM ceiling of this device: a 16-byte-per-lane streaming copy of `bytes` bytes, `iters` times;
+ * returns read+write GB/s through *gbps (the denominator bench.py reports next to the nominal 8 TB/s). */
+int lqrhip_copy_bandwidth(unsigned long long bytes, int iters, double *gbps);
+/* the colour ramp of write_vmap_to_layer (src/io_functions.c:249-279) over a
+ * w x h visibility map: value = (depth+1-vs)/(depth+1), RGB = value*start + (1-value)*end,
+ * alpha = 0.5*(1+value), each channel (guchar)(255*x); vs == 0 -> 0,0,0,0.  Host buffers. */
+int lqrhip_vmap_to_rgba(const int *vmap, int w, int h, int depth, const double col_start[3], const double col_end[3],
+                        unsigned char *out_rgba);
 /* return the cached (freed) device blocks of the shim's allocation cache to the driver */
 void lqrhip_pool_trim(void);
 /* E12 lqr_vmap_dump (render.c:725): vs of the pixels visible at `level`
@@ -128,6 +146,10 @@ void lqrhip_set_overlap(int mode);
  * kernel k_band_update_tw above), 0 band kernel always, 1 tiled sweep whenever its grid fits the device,
  * 2 the older band kernel k_band_update_mw (overlapped with the carve for large batches) */
 void lqrhip_set_update_mode(int mode);
+/* Cap on the workgroups of the persistent tiled DP sweep (k_dp_tile_p), whose tiles spin on their neighbours and
+ * must all be resident: -1 = the bound derived from the occupancy query at lqrhip_init, n >= 0 = min(n, that bound).
+ * Grids above the cap run as k_dp_tile (one launch per 32 rows).  0 forces that path (tests). */
+void lqrhip_set_dp_persistent_limit(int workgroups);
 void lqrhip_prof_reset(void);
 int lqrhip_prof_get(const char *kernel, double *ms_total, long long *launches, double *bytes_total);
 

@@ -48,7 +48,9 @@
 
 #define MAXI(a, b) ((a) > (b) ? (a) : (b))
 #define MINI(a, b) ((a) < (b) ? (a) : (b))
-#define UPDATE_TOLERANCE (1e-5f)
+/* update_mmap's keep rule compares in double: fabsf() promoted against the double constant 1e-5
+ * (DESIGN.md spec delta 4), i.e. a float difference d is kept iff d <= 1e-5f (0x3727C5AC) */
+#define UPDATE_TOLERANCE (1e-5)
 
 struct _LqrProgress {
     gfloat update_step;
@@ -771,7 +773,7 @@ static LqrRetVal update_mmap(LqrCarver *r)
             /* shrink the band where nothing (relevant) changed: the stale
              * value is KEPT when the change is below tolerance */
             if (r->least[data] == least) {
-                if (fabsf(r->m[data] - new_m) < UPDATE_TOLERANCE) {
+                if ((double) fabsf(r->m[data] - new_m) < UPDATE_TOLERANCE) {
                     if (stop == 0) x_stop = x;
                     stop = 1;
                     new_m = r->m[data];
@@ -1147,6 +1149,49 @@ LqrRetVal lqrx_carver_read_image_device(LqrCarver *r, void *device_ptr)
     cursor_reset(r);
     while (lqr_carver_scan_line(r, &n, &line)) memcpy(out + (size_t) n * r->w * r->channels, line, (size_t) r->w * r->channels);
     return LQR_OK;
+}
+
+/* ======================= seam-map colour ramp ============================ */
+/* restates the per-pixel loop of write_vmap_to_layer, reference src/io_functions.c:249-279 (this one IS
+ * in the tree, so this part of the oracle is pinned to reference source): same expressions, same
+ * types (gdouble locals, gint vs/depth, guchar destination), compiled without FMA contraction as the
+ * reference is on its baseline x86-64 target.  GimpRGB's r, g, b are gdouble (io_functions.c:196). */
+LqrRetVal lqrx_vmap_to_rgba(LqrVMap *vmap, const gdouble col_start[3], const gdouble col_end[3], guchar *out_rgba)
+{
+    gint w, h, bpp = 4, depth, *buffer, vs, y, x, k;
+    gdouble value, rd, gr, bl, al;
+    if (!vmap || !out_rgba) return LQR_ERROR;
+    w = lqr_vmap_get_width(vmap);                                   /* :216 */
+    h = lqr_vmap_get_height(vmap);                                  /* :217 */
+    buffer = lqr_vmap_get_data(vmap);                               /* :218 */
+    depth = lqr_vmap_get_depth(vmap);                               /* :219 */
+    for (y = 0; y < h; y++) {
+        guchar *outrow = out_rgba + (size_t) y * w * bpp;
+        for (x = 0; x < w; x++) {
+            vs = buffer[y * w + x];                                  /* :253 */
+            if (vs == 0) {
+                for (k = 0; k < bpp; k++) outrow[x * bpp + k] = 0;    /* :254-259 */
+            } else {
+                value = (double) (depth + 1 - vs) / (depth + 1);      /* :263 */
+                rd = value * col_start[0] + (1 - value) * col_end[0]; /* :264 */
+                gr = value * col_start[1] + (1 - value) * col_end[1]; /* :265 */
+                bl = value * col_start[2] + (1 - value) * col_end[2]; /* :266 */
+                al = 0.5 * (1 + value);                               /* :267 */
+                outrow[x * bpp] = 255 * rd;                           /* :268 */
+                outrow[x * bpp + 1] = 255 * gr;                       /* :269 */
+                outrow[x * bpp + 2] = 255 * bl;                       /* :270 */
+                outrow[x * bpp + 3] = 255 * al;                       /* :271 */
+            }
+        }
+    }
+    return LQR_OK;
+}
+
+/* engine-only extension: the oracle has no device memory */
+LqrRetVal lqrx_carver_reload_device_batch(LqrCarver **carvers, gint n, void *const *device_rgb)
+{
+    (void) carvers; (void) n; (void) device_rgb;
+    return LQR_ERROR;
 }
 
 /* ======================= auto-size (plug-in side) ======================== */
