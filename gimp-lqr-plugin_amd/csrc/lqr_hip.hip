@@ -45,6 +45,14 @@
 // ---------------------------------------------------------------------------
 #define LEAST_INVALID (-128)
 #define FLAG_OVF_ROW 0          // first row the band kernel could not handle (h = none)
+// The carved planes (en, m, back pointers, rigidity mask) of an image start FLAG_ORG elements into each row:
+// a seam is removed by moving whichever side of it is shorter, and moving the left side
+// one to the right advances the origin by one.  k_vpath* picks the side for the seam it found and publishes
+// {origin before the seam, side, origin after it}; the carve works on physical positions with the first
+// two, every other kernel sees rows through pointers advanced by the current origin (gview).
+#define FLAG_ORG 3              // origin every kernel but the carve uses
+#define FLAG_ORG_PREV 4         // origin of the frame the seam in seam_x was found in (carve)
+#define FLAG_SIDE 5             // 0: the part right of the seam moves left; 1: the part left of it moves right
 #define FLAG_COUNT 8
 #define DP_THREADS 1024
 #define VPATH_THREADS 256
@@ -69,7 +77,6 @@ struct DevCarver {
     int32_t *seam_x;
     int32_t *seam_log;
     int32_t *flags;
-    int32_t *progress;      // [ceil(h/64)] rows carved so far, cumulative over the seams since allocation
 };
 
 // Pointers fetched from a descriptor in memory are "generic" to the compiler, which then
@@ -93,17 +100,33 @@ struct GCarver {
     gf32 *en, *m, *m2;
     gi8 *least, *least2;
     gf32 *bias, *rig;
-    gi32 *seam_x, *seam_log, *flags, *progress;
+    gi32 *seam_x, *seam_log, *flags;
 };
 
-__device__ __forceinline__ GCarver gview(const DevCarver &d)
+// physical view: plane pointers as allocated (row y starts at y * stride); what the carve and the one-off
+// kernels that lay the planes out use
+__device__ __forceinline__ GCarver gview_phys(const DevCarver &d)
 {
     GCarver g;
     g.rgb0 = (gu8 *) d.rgb0; g.vs = (gi32 *) d.vs; g.bias0 = (gf32 *) d.bias0; g.rig0 = (gf32 *) d.rig0;
     g.pix = (gu32 *) d.pix; g.en = (gf32 *) d.en; g.m = (gf32 *) d.m; g.least = (gi8 *) d.least;
     g.m2 = (gf32 *) d.m2; g.least2 = (gi8 *) d.least2;
     g.bias = (gf32 *) d.bias; g.rig = (gf32 *) d.rig;
-    g.seam_x = (gi32 *) d.seam_x; g.seam_log = (gi32 *) d.seam_log; g.flags = (gi32 *) d.flags; g.progress = (gi32 *) d.progress;
+    g.seam_x = (gi32 *) d.seam_x; g.seam_log = (gi32 *) d.seam_log; g.flags = (gi32 *) d.flags;
+    return g;
+}
+// logical view: the carved planes advanced by the image's current origin, so that x = 0 is the first pixel of
+// the carved frame in every kernel that indexes by frame coordinates.  The origin is uniform over the rows of an
+// image, so rows stay mutually aligned; vector accesses become element-aligned only (measured on gfx950:
+// correct, 12-17 % slower than 16-byte aligned ones, scripts/dbg/t_unaligned.hip).  pix / bias stay frozen in
+// their own frame (k_emap_update) and are not shifted.
+__device__ __forceinline__ GCarver gview(const DevCarver &d)
+{
+    GCarver g = gview_phys(d);
+    const int org = g.flags[FLAG_ORG];
+    g.en += org; g.m += org; g.least += org;
+    if (g.m2) { g.m2 += org; g.least2 += org; }
+    if (g.rig) g.rig += org;
     return g;
 }
 
@@ -232,8 +255,9 @@ __device__ __forceinline__ float energy_at(const GCarver &c, const DpK &p, int s
 // ---------------------------------------------------------------------------
 __global__ void k_wk_init(const DevCarver *cs, int w, int h, int stride, int ch)
 {
-    const GCarver c = gview(cs[blockIdx.z]);
+    const GCarver c = gview_phys(cs[blockIdx.z]);
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x == 0 && y == 0) { c.flags[FLAG_ORG] = 0; c.flags[FLAG_ORG_PREV] = 0; c.flags[FLAG_SIDE] = 0; }      // planes laid out afresh
     if (x >= stride) return;
     size_t o = (size_t) y * stride + x;
     uint32_t p = 0;
@@ -381,10 +405,21 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sweep(const DevCarver *cs, Dp
 // loaded into a second register set before this chunk's chase has finished.
 // ---------------------------------------------------------------------------
 #define VP_ROWS 62
+// Which side of the seam the carve moves (wave 0 of k_vpath*, after the backtrack): the part right of the
+// seam holds sum(w - 1 - x), the part left of it sum(x) elements over the rows; the shorter one moves, and
+// moving the left part right advances the image's origin by one.  `acc` = this lane's share of sum(x).
+__device__ __forceinline__ void publish_side(const GCarver &c, int org, int acc, int w, int h, int lane)
+{
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    const int side = (2ll * acc < (long long) h * (w - 1)) ? 1 : 0;
+    if (lane == 0) { c.flags[FLAG_ORG_PREV] = org; c.flags[FLAG_SIDE] = side; c.flags[FLAG_ORG] = org + side; }
+}
+
 __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, int w, int h, int stride, int lr, int delta,
                                                           int log_index)
 {
     const GCarver c = gview(cs[blockIdx.x]);
+    const int org = c.flags[FLAG_ORG];           // read before wave 0 publishes the next one
     __shared__ float s_val[VPATH_THREADS];
     __shared__ int s_idx[VPATH_THREADS];
     const int tid = threadIdx.x;
@@ -442,6 +477,7 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
     };
     int y_top = h - 1;
     int xa_cur = window_base(x);
+    int acc = 0;
     if (y_top >= 1) load_chunk(0, y_top, xa_cur);
     while (y_top >= 1) {
 #pragma unroll
@@ -462,13 +498,14 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
                         x += d;
                     }
                 }
-                if (lane < nrows) { seam[y_top - lane] = path; logp[y_top - lane] = path; }
+                if (lane < nrows) { seam[y_top - lane] = path; logp[y_top - lane] = path; acc += path; }
                 xa_cur = xa_next;
                 y_top -= nrows;
             }
         }
     }
-    if (lane == 0) { seam[0] = x; logp[0] = x; }
+    if (lane == 0) { seam[0] = x; logp[0] = x; acc += x; }
+    publish_side(c, org, acc, w, h, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -502,6 +539,7 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, i
                                                            const uint32_t *zero_page)
 {
     const GCarver c = gview(cs[blockIdx.x]);
+    const int org = c.flags[FLAG_ORG];           // read before wave 0 publishes the next one
     __shared__ float s_val[VPATH_THREADS];
     __shared__ int s_idx[VPATH_THREADS];
     const int tid = threadIdx.x;
@@ -561,6 +599,7 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, i
     };
     int y_top = h - 1;
     int xa_cur = window_base(x);
+    int acc = 0;
     load_chunk(0, y_top, xa_cur);
     while (true) {
         {
@@ -569,7 +608,7 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, i
             load_chunk(1, y_top - R, xa_next);                                     // in flight during the chase
             int path = 0;
             vp_chase(regs[0], x, xa_cur, path, std::make_integer_sequence<int, R>{});
-            if (lane < nrows) { seam[y_top - lane] = path; logp[y_top - lane] = path; }
+            if (lane < nrows) { seam[y_top - lane] = path; logp[y_top - lane] = path; acc += path; }
             xa_cur = xa_next;
             y_top -= nrows;
         }
@@ -580,138 +619,238 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, i
             load_chunk(0, y_top - R, xa_next);
             int path = 0;
             vp_chase(regs[1], x, xa_cur, path, std::make_integer_sequence<int, R>{});
-            if (lane < nrows) { seam[y_top - lane] = path; logp[y_top - lane] = path; }
+            if (lane < nrows) { seam[y_top - lane] = path; logp[y_top - lane] = path; acc += path; }
             xa_cur = xa_next;
             y_top -= nrows;
         }
         if (y_top < 1) break;
     }
-    if (lane == 0) { seam[0] = x; logp[0] = x; }
+    if (lane == 0) { seam[0] = x; logp[0] = x; acc += x; }
+    publish_side(c, org, acc, w, h, lane);
 }
 
 // ---------------------------------------------------------------------------
-// E8 carve: shift every working plane left by one from the seam on, one wave
-// per row, 16 B per lane, in place.  The dominant HBM kernel: algorithmic
-// traffic is (read + write) of the part of each row right of the seam.
-// The back-pointer plane is re-based on the fly: a stored dx stays valid unless
-// pixel and parent are on different sides of the seam.
+// E8 carve: remove the seam from every carved plane (en, m, back pointers, rigidity mask), in place, one
+// wave per row, 16 B per lane.  The dominant HBM kernel.  Only the SHORTER side of the seam moves
+// (DESIGN.md 4.9): k_vpath* compared sum(x) with sum(w - 1 - x) over the seam's rows and published
+//   side 0: the part right of the seam moves one to the left, the origin stays;
+//   side 1: the part left of it moves one to the right and the image's origin advances by one.
+// The side is uniform over an image's rows, so rows stay mutually aligned and every other kernel just sees
+// the planes through pointers advanced by the origin.  Seams are delta_x-connected, so a seam's rows differ
+// little in x and the per-image choice loses almost nothing against a per-row one; for seams spread over
+// the width the mean moved fraction of a row is 1/4 instead of 1/2.
+// This kernel works on PHYSICAL positions p = origin + x (rows start 16-byte aligned at p = 0), with aligned
+// vector accesses; the element that enters a lane's four from the neighbouring lane comes by DPP.
+// The back-pointer plane is re-based on the fly: a stored dx stays valid unless pixel and parent are on
+// different sides of the seam (then it changes by one, or becomes LEAST_INVALID if the parent was carved).
 // ---------------------------------------------------------------------------
 // write-through (sc1) stores: the data reaches memory without a release fence (buffer_wbl2), so a
 // drained wave (s_waitcnt vmcnt(0)) can publish a flag that a consumer on another XCD may trust
 __device__ __forceinline__ void store_sc1_x4(gu32 *p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void store_sc1_x1(gu32 *p, uint32_t v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 
-template <bool SC1>
-__device__ __forceinline__ void shift_row_u32(gu32 *row, int v, int wnew, int lane)
+#define DPP_WAVE_SHL1 0x130
+#define DPP_WAVE_SHR1 0x138
+
+// side 0: new[p] = old[p + 1] for p in [pv, pend); pend = physical end (exclusive) of the row after the carve
+__device__ __forceinline__ void shift_left_u32(gu32 *row, int pv, int pend, int lane)
 {
-    int base = v & ~3;
-    // 4 chunks of 256 px in flight: all loads of a group are issued before its stores (non-temporal:
-    // streaming the rows past L2 is worth 6 % of the kernel).  The element
-    // that follows a lane's 4 pixels is the next lane's first one (DPP); only lane 63 of the last
-    // chunk of a group has to fetch it from memory.
-    for (; base < wnew; base += 1024) {
+    // 4 chunks of 256 elements in flight: all loads of a group are issued before its stores (non-temporal:
+    // streaming the rows past L2 is worth 6 % of the kernel).  The element that follows a lane's four is the next
+    // lane's first one (DPP); only lane 63 of the last chunk of a group has to fetch it from memory.
+    for (int base = pv & ~3; base < pend; base += 1024) {
         u32x4 a[4];
         uint32_t tail = 0;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            int x = base + u * 256 + lane * 4;
-            // x <= wnew: the group that starts at wnew holds the old last pixel, which the lane before needs
-            a[u] = (x <= wnew) ? __builtin_nontemporal_load((const GLOBAL_AS u32x4 *) (row + x)) : (u32x4) {0u, 0u, 0u, 0u};
+            const int x = base + u * 256 + lane * 4;
+            // x <= pend: the group that starts at pend holds the old last element, which the lane before needs
+            a[u] = (x <= pend) ? __builtin_nontemporal_load((const GLOBAL_AS u32x4 *) (row + x)) : (u32x4) {0u, 0u, 0u, 0u};
         }
-        if (lane == 63 && base + 1024 <= wnew) tail = row[base + 1024];
+        if (lane == 63 && base + 1024 <= pend) tail = row[base + 1024];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            int x = base + u * 256 + lane * 4;
+            const int x = base + u * 256 + lane * 4;
             const uint32_t first_next = (u < 3) ? (uint32_t) __builtin_amdgcn_readlane((int) a[u < 3 ? u + 1 : 3].x, 0) : 0u;
             const uint32_t lane63 = (u < 3) ? first_next : tail;
-            const uint32_t nx = (uint32_t) __builtin_amdgcn_update_dpp((int) lane63, (int) a[u].x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-            if (x < wnew) {
+            const uint32_t nx = (uint32_t) __builtin_amdgcn_update_dpp((int) lane63, (int) a[u].x, DPP_WAVE_SHL1, 0xf, 0xf, false);
+            if (x < pend) {
                 u32x4 o;
-                o.x = (x >= v) ? a[u].y : a[u].x;
-                o.y = (x + 1 >= v) ? a[u].z : a[u].y;
-                o.z = (x + 2 >= v) ? a[u].w : a[u].z;
-                o.w = (x + 3 >= v) ? nx : a[u].w;
-                if (SC1) store_sc1_x4(row + x, o);
-                else __builtin_nontemporal_store(o, (GLOBAL_AS u32x4 *) (row + x));
+                o.x = (x >= pv) ? a[u].y : a[u].x;
+                o.y = (x + 1 >= pv) ? a[u].z : a[u].y;
+                o.z = (x + 2 >= pv) ? a[u].w : a[u].z;
+                o.w = (x + 3 >= pv) ? nx : a[u].w;
+                __builtin_nontemporal_store(o, (GLOBAL_AS u32x4 *) (row + x));
             }
         }
     }
 }
 
-template <bool SC1>
-__device__ __forceinline__ void shift_row_least(gi8 *row, int v, int vprev, int y, int delta, int wnew, int lane)
+// side 1: new[p] = old[p - 1] for p in (pbeg, pv]; pbeg = the origin before the carve (dead afterwards).
+// Groups run from the seam towards the origin: a group's stores reach one element past its loads on the right,
+// into a group that has been read already.
+__device__ __forceinline__ void shift_right_u32(gu32 *row, int pbeg, int pv, int lane)
+{
+    for (int top = (pv | 3) + 1; top > pbeg + 1; top -= 1024) {
+        const int gbase = top - 1024;
+        u32x4 a[4];
+        uint32_t head = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int x = gbase + u * 256 + lane * 4;
+            // chunks that hold a source (p in [pbeg, pv - 1]) or a destination; x + 3 >= pbeg >= 0 keeps x >= 0
+            a[u] = (x + 3 >= pbeg && x <= pv) ? __builtin_nontemporal_load((const GLOBAL_AS u32x4 *) (row + x)) : (u32x4) {0u, 0u, 0u, 0u};
+        }
+        if (lane == 0 && gbase - 1 >= pbeg) head = row[gbase - 1];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int x = gbase + u * 256 + lane * 4;
+            const uint32_t last_prev = (u > 0) ? (uint32_t) __builtin_amdgcn_readlane((int) a[u > 0 ? u - 1 : 0].w, 63) : 0u;
+            const uint32_t lane0 = (u > 0) ? last_prev : head;
+            const uint32_t pw = (uint32_t) __builtin_amdgcn_update_dpp((int) lane0, (int) a[u].w, DPP_WAVE_SHR1, 0xf, 0xf, false);
+            if (x <= pv && x + 3 > pbeg) {
+                u32x4 o;
+                o.x = (x > pbeg && x <= pv) ? pw : a[u].x;
+                o.y = (x + 1 > pbeg && x + 1 <= pv) ? a[u].x : a[u].y;
+                o.z = (x + 2 > pbeg && x + 2 <= pv) ? a[u].y : a[u].z;
+                o.w = (x + 3 > pbeg && x + 3 <= pv) ? a[u].z : a[u].w;
+                __builtin_nontemporal_store(o, (GLOBAL_AS u32x4 *) (row + x));
+            }
+        }
+    }
+}
+
+// one back pointer of the carved frame: the pixel that lands on new frame column xx came from old column
+// xo = xx + right with back pointer dx (parent at old column xo + dx on row y - 1, whose seam pixel was vprev)
+__device__ __forceinline__ int rebase_dx(int dx, int xx, int xo, int vprev, int y)
+{
+    if (y > 0 && dx != LEAST_INVALID) {
+        const int q = xo + dx;
+        if (q == vprev) dx = LEAST_INVALID;            // parent was the carved pixel
+        else dx = q - (q > vprev ? 1 : 0) - xx;
+    }
+    return dx;
+}
+
+// Back pointers, side 0.  New frame column xx sits at physical org + xx and takes old column xx + (xx >= v).  Pixels
+// left of the seam whose parent may lie right of the seam of the row above (xx >= vprev - delta) are re-based too.
+__device__ __forceinline__ void shift_left_least(gi8 *row, int org, int v, int vprev, int y, int delta, int wnew, int lane)
 {
     int start = (y > 0) ? min(v, vprev - delta) : v;
     if (start < 0) start = 0;
     gu32 *row32 = (gu32 *) row;
-    // as shift_row_u32: 4 chunks of 256 px (one dword per lane) in flight, all loads of a group before
+    const int pstart = org + start, pend = org + wnew;
+    // as shift_left_u32: 4 chunks of 256 px (one dword per lane) in flight, all loads of a group before
     // its stores; the dword that follows a lane's is the next lane's (DPP)
-    for (int base = start & ~3; base < wnew; base += 1024) {
+    for (int base = pstart & ~3; base < pend; base += 1024) {
         uint32_t a[4];
         uint32_t tail = 0;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int x = base + u * 256 + lane * 4;
-            a[u] = (x <= wnew) ? __builtin_nontemporal_load(row32 + (x >> 2)) : 0u;
+            a[u] = (x <= pend) ? __builtin_nontemporal_load(row32 + (x >> 2)) : 0u;
         }
-        if (lane == 63 && base + 1024 <= wnew) tail = row32[(base + 1024) >> 2];
+        if (lane == 63 && base + 1024 <= pend) tail = row32[(base + 1024) >> 2];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int x = base + u * 256 + lane * 4;
             const uint32_t first_next = (u < 3) ? (uint32_t) __builtin_amdgcn_readlane((int) a[u < 3 ? u + 1 : 3], 0) : 0u;
             const uint32_t lane63 = (u < 3) ? first_next : tail;
-            const uint32_t nx = (uint32_t) __builtin_amdgcn_update_dpp((int) lane63, (int) a[u], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-            if (x < wnew) {
+            const uint32_t nx = (uint32_t) __builtin_amdgcn_update_dpp((int) lane63, (int) a[u], DPP_WAVE_SHL1, 0xf, 0xf, false);
+            if (x < pend) {
                 const uint64_t both = ((uint64_t) nx << 32) | a[u];
                 uint32_t o = 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    int xx = x + j;
-                    bool right = (xx >= v);
-                    int dx = (int8_t) (both >> (8 * (j + (right ? 1 : 0))));
-                    int xo = right ? xx + 1 : xx;
-                    if (y > 0 && dx != LEAST_INVALID) {
-                        int q = xo + dx;
-                        if (q == vprev) dx = LEAST_INVALID;            // parent was the carved pixel
-                        else dx = q - (q > vprev ? 1 : 0) - xx;
+                    const int xx = x + j - org;
+                    int dx;
+                    if (xx < start || xx >= wnew) {
+                        dx = (int8_t) (a[u] >> (8 * j));                    // not part of the job: as loaded
+                    } else {
+                        const bool right = (xx >= v);
+                        dx = rebase_dx((int8_t) (both >> (8 * (j + (right ? 1 : 0)))), xx, right ? xx + 1 : xx, vprev, y);
                     }
                     o |= (uint32_t) (uint8_t) (int8_t) dx << (8 * j);
                 }
-                if (SC1) store_sc1_x1(row32 + (x >> 2), o);
-                else __builtin_nontemporal_store(o, row32 + (x >> 2));
+                __builtin_nontemporal_store(o, row32 + (x >> 2));
             }
         }
     }
 }
 
-template <bool SIGNAL>
+// Back pointers, side 1.  New frame column xx sits at physical org + 1 + xx; pixels left of the seam (xx < v) come
+// from physical org + xx (they move), pixels right of it stay where they are and are only re-based while their
+// parent may lie left of (or on) the seam of the row above (xx < vprev + delta).
+__device__ __forceinline__ void shift_right_least(gi8 *row, int org, int v, int vprev, int y, int delta, int wnew, int lane)
+{
+    const int end_l = (y > 0) ? min(wnew, max(v, vprev + delta)) : min(wnew, v);
+    if (end_l <= 0) return;
+    gu32 *row32 = (gu32 *) row;
+    const int pfirst = org + 1, ptop = org + 1 + end_l;       // destination range [pfirst, ptop)
+    for (int top = (ptop + 3) & ~3; top > pfirst; top -= 1024) {
+        const int gbase = top - 1024;
+        uint32_t a[4];
+        uint32_t head = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int x = gbase + u * 256 + lane * 4;
+            a[u] = (x + 3 >= org && x < ptop) ? __builtin_nontemporal_load(row32 + (x >> 2)) : 0u;      // x + 3 >= org >= 0 keeps x >= 0
+        }
+        if (lane == 0 && gbase - 1 >= org) head = row32[(gbase - 4) >> 2];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int x = gbase + u * 256 + lane * 4;
+            const uint32_t last_prev = (u > 0) ? (uint32_t) __builtin_amdgcn_readlane((int) a[u > 0 ? u - 1 : 0], 63) : 0u;
+            const uint32_t lane0 = (u > 0) ? last_prev : head;
+            const uint32_t pd = (uint32_t) __builtin_amdgcn_update_dpp((int) lane0, (int) a[u], DPP_WAVE_SHR1, 0xf, 0xf, false);
+            if (x < ptop && x + 3 >= pfirst) {
+                const uint64_t both = ((uint64_t) a[u] << 8) | (pd >> 24);      // byte k = physical x - 1 + k
+                uint32_t o = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int xx = x + j - pfirst;
+                    int dx;
+                    if (xx < 0 || xx >= end_l) {
+                        dx = (int8_t) (a[u] >> (8 * j));                    // not part of the job: as loaded
+                    } else {
+                        const bool right = (xx >= v);
+                        dx = rebase_dx((int8_t) (both >> (8 * (j + (right ? 1 : 0)))), xx, right ? xx + 1 : xx, vprev, y);
+                    }
+                    o |= (uint32_t) (uint8_t) (int8_t) dx << (8 * j);
+                }
+                __builtin_nontemporal_store(o, row32 + (x >> 2));
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h, int stride, int delta, int move_dp)
 {
-    // blockIdx.x = image (fastest): workgroups are dispatched row-block by row-block across ALL
-    // images, so every image's top rows are carved first and the band update (which walks down the
-    // image on another stream) can follow close behind
-    const GCarver c = gview(cs[blockIdx.x]);
+    // blockIdx.x = image (fastest): workgroups are dispatched row-block by row-block across ALL images
+    const GCarver c = gview_phys(cs[blockIdx.x]);
+    const int org = c.flags[FLAG_ORG_PREV], side = c.flags[FLAG_SIDE];      // published by k_vpath* for this seam
     const int lane = threadIdx.x & 63;
     const int wnew = w - 1;
     for (int y = blockIdx.y * 4 + (threadIdx.x >> 6); y < h; y += gridDim.y * 4) {
-    const int v = c.seam_x[y];
-    size_t ro = (size_t) y * stride;
-    // pix and bias are NOT moved: they stay in the frame of `frozen epoch` and the energy
-    // update maps current coordinates back through the seam log (k_emap_update)
-    shift_row_u32<SIGNAL>((gu32 *) (c.en + ro), v, wnew, lane);
-    if (c.rig) shift_row_u32<SIGNAL>((gu32 *) (c.rig + ro), v, wnew, lane);
-    if (move_dp) {
-        shift_row_u32<SIGNAL>((gu32 *) (c.m + ro), v, wnew, lane);
-        int vprev = y > 0 ? c.seam_x[y - 1] : 0;
-        shift_row_least<SIGNAL>(c.least + ro, v, vprev, y, delta, wnew, lane);
-    }
-    if (SIGNAL) {
-        // publish "row y is carved" to the band kernel running concurrently on another stream: the
-        // row was stored write-through (sc1); drain this wave's stores, then one relaxed agent-scope
-        // add on the chunk counter (no buffer_wbl2: a release fence per row costs 6x the carve)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(c.progress + (y >> 6), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+        const int v = c.seam_x[y];
+        const size_t ro = (size_t) y * stride;
+        const int vprev = y > 0 ? c.seam_x[y - 1] : 0;
+        // pix and bias are NOT moved: they stay in the frame of `frozen epoch` and the energy
+        // update maps current coordinates back through the seam log (k_emap_update)
+        if (side == 0) {
+            shift_left_u32((gu32 *) (c.en + ro), org + v, org + wnew, lane);
+            if (c.rig) shift_left_u32((gu32 *) (c.rig + ro), org + v, org + wnew, lane);
+            if (move_dp) {
+                shift_left_u32((gu32 *) (c.m + ro), org + v, org + wnew, lane);
+                shift_left_least(c.least + ro, org, v, vprev, y, delta, wnew, lane);
+            }
+        } else {
+            shift_right_u32((gu32 *) (c.en + ro), org, org + v, lane);
+            if (c.rig) shift_right_u32((gu32 *) (c.rig + ro), org, org + v, lane);
+            if (move_dp) {
+                shift_right_u32((gu32 *) (c.m + ro), org, org + v, lane);
+                shift_right_least(c.least + ro, org, v, vprev, y, delta, wnew, lane);
+            }
+        }
     }
 }
 
@@ -744,7 +883,7 @@ __device__ __forceinline__ int block_rank_256(bool flag, int *s_wave, int &total
     return r + off;
 }
 
-// E6 update_emap: recompute en next to the carved seam (w = new width).
+// E6 update_emap: recompute en next to the carved seam (w = new width); runs after the carve.
 // The packed-pixel (and bias) planes are frozen in the frame they had at seam `epoch`
 // of the session; current coordinates are mapped back by undoing seams k..epoch of the
 // row (p += (log[j] <= p)), which costs O(k - epoch) per pixel for ~10 pixels per row and
@@ -755,7 +894,7 @@ __device__ __forceinline__ int block_rank_256(bool flag, int *s_wave, int &total
 // parameter chosen by the launch from delta_x: 12 (delta_x <= 2), 36 (<= 8), 68 (<= 16 = LQRHIP_MAX_DELTA).
 #define EU_ROWS 62          // rows per block (+2 halo rows)
 template <int NRG, int EU_NT>
-__global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, int w, int h, int stride, int k, int epoch, int pre_shift)
+__global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, int w, int h, int stride, int k, int epoch)
 {
     const GCarver c = gview(cs[blockIdx.y]);
     __shared__ double bt[64][EU_NT];
@@ -797,9 +936,7 @@ __global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, 
     for (int x = xmin; x <= xmax; x++) {
         float e = grad_energy_f<NRG>([&](int xx, int yy) { const int t = tid + (yy - y); return bt[t][xx - slo[t]]; }, x, y, w, h);
         if (c.bias) e = __fadd_rn(e, __fdiv_rn(bb[tid][x - lo], (float) p.w_start));
-        // pre_shift: the carve has not run yet -- write where the carve will pick the value up
-        const int xo = (pre_shift && x >= c.seam_x[y]) ? x + 1 : x;
-        c.en[(size_t) y * stride + xo] = e;
+        c.en[(size_t) y * stride + x] = e;
     }
 }
 
@@ -1031,9 +1168,6 @@ __global__ __launch_bounds__(64) void k_band_update(const DevCarver *cs, DpK p, 
 // the window the kernel records the row in flags[FLAG_OVF_ROW] and the full-width
 // sweep (k_dp_sweep<UPDATE>) finishes from there with identical results.
 // ---------------------------------------------------------------------------
-#define DPP_WAVE_SHL1 0x130
-#define DPP_WAVE_SHR1 0x138
-
 template <int PXL> struct PxVec;
 template <> struct PxVec<1> { typedef float F __attribute__((ext_vector_type(1))); typedef uint8_t L; };
 template <> struct PxVec<2> { typedef float F __attribute__((ext_vector_type(2))); typedef uint16_t L; };
@@ -1047,7 +1181,7 @@ struct BandEdge {          // what a wave publishes about the row it just finish
 };
 
 template <int PXL, int NW, int R, bool LR, bool RIG>
-__global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs, DpK p, int w, int h, int stride, int gate, int resume)
+__global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs, DpK p, int w, int h, int stride)
 {
     typedef typename PxVec<PXL>::F FV;
     typedef typename PxVec<PXL>::L LV;
@@ -1060,46 +1194,7 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
     const float INF = __int_as_float(0x7f800000);
     constexpr int SLOT = 64 * PXL, WIN = SLOT * NW;
     const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
-    // resume: the single-wave kernel handled rows < flags[OVF_ROW] and left the extent of its last
-    // row's changes as a hint for the first window
-    const int y_start = resume ? c.flags[FLAG_OVF_ROW] : 1;
-    if (y_start >= h) return;
-    const int hint_lo = resume ? c.flags[1] : -1, hint_hi = resume ? c.flags[2] : -1;
-
-    // gate > 0: the carve of this seam runs concurrently (other stream); rows may only be touched once
-    // their 64-row chunk has been carved `gate` times (cumulative counter, agent-scope acquire)
-    int ready = 0;
-    bool acquired = true;
-    __shared__ int s_abort;
-    if (tid == 0) s_abort = 0;
-    __syncthreads();
-    // returns false if the carve did not show up within ~2 s (every spin is bounded): the caller then
-    // records the current row and leaves; the full-width sweep, which the host orders after the
-    // carve, finishes the image correctly
-    auto wait_rows = [&](int upto) -> bool {
-        if (!gate) return true;
-        const int cu = min(upto, h - 1) >> 6;
-        if (ready <= cu) {
-            // one polling wave per workgroup, long sleeps: hundreds of spinning waves would eat into
-            // the very bandwidth the carve needs; the others wait at the (LDS-only) barrier
-            if (wave == 0)
-                for (int ch = ready; ch <= cu; ch++) {
-                    const int need = gate * min(64, h - 64 * ch);
-                    int spins = 0;
-                    while (__hip_atomic_load(c.progress + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                        __builtin_amdgcn_s_sleep(64);
-                        if (++spins > (1 << 20)) { if (lane == 0) s_abort = 1; break; }
-                    }
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (s_abort) return false;
-            ready = cu + 1;
-            acquired = false;
-        }
-        if (!acquired) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
-        return true;
-    };
-    if (!wait_rows(0)) { if (tid == 0) c.flags[FLAG_OVF_ROW] = resume ? y_start : 0; return; }
+    const int y_start = 1;
 
     // pixels of row y whose inputs the carve changed: energy (liblqr's update_emap interval)
     // and parent sets next to the seam; a superset is fine
@@ -1112,7 +1207,7 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
         BandEdge e; e.first_val = INF; e.last_val = INF; e.flags = 0; e.pad = 0;
         s_edge[tid / (NW + 2)][tid % (NW + 2)] = e;
     }
-    if (!resume) {   // row 0: m = en on liblqr's interval
+    {   // row 0: m = en on liblqr's interval
         const int v0 = c.seam_x[0], vp = c.seam_x[min(1, h - 1)];
         int lo = v0, hi = v0 - 1;
         if (p.radius) { lo = min(v0, vp) - 1; hi = max(v0, vp); }
@@ -1127,14 +1222,12 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
     int dirty_lo = -1, dirty_hi = -1;      // dirty slots of the last finished row, window-relative (-1: none)
     int B = 0;
     bool have_window = false;
-    bool abort_all = false;
-    while (y < h && !abort_all) {
+    while (y < h) {
         // ---- (re)base the window (identical decision in every wave)
         {
             const int t = s_touch[y];
             int lo = t & 0xffff, hi = t >> 16;                       // absolute pixel range that must be inside
             if (have_window && dirty_lo >= 0) { lo = min(lo, B + SLOT * dirty_lo - 1); hi = max(hi, B + SLOT * (dirty_hi + 1)); }
-            if (!have_window && hint_lo >= 0) { lo = min(lo, hint_lo - 1); hi = max(hi, hint_hi + 1); }
             lo = max(lo, 0); hi = min(hi, w - 1);
             if (hi - lo + 1 > WIN - 2 * SLOT - 2 * (R + 2) - 8 && hi - lo + 1 < w) { ovf = y; break; }
             int nb = (((lo + hi) >> 1) - WIN / 2) & ~3;
@@ -1163,7 +1256,6 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
         }
 
         // previous row: rows < y were stored by this workgroup -> make them visible, then load
-        if (!wait_rows(y + R - 1)) { ovf = y; break; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1217,7 +1309,6 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
                         dirty_lo = __builtin_amdgcn_readfirstlane(lo);
                         dirty_hi = __builtin_amdgcn_readfirstlane(hi);
                     } else {
-                        if (!wait_rows(y + 2 * R - 1)) { ovf = y; abort_all = true; rebase = true; break; }
                         issue(buf ^ 1, y + R);            // next batch in flight while this one is processed
 #pragma unroll
                         for (int r = 0; r < R; r++) {
@@ -2039,8 +2130,7 @@ struct LqrHipCarver {
     uint32_t *pix = nullptr;
     float *en = nullptr, *m = nullptr, *m2 = nullptr, *bias = nullptr, *rig = nullptr;
     int8_t *least = nullptr, *least2 = nullptr;
-    int32_t *seam_x = nullptr, *seam_log = nullptr, *flags = nullptr, *progress = nullptr;
-    int carve_epoch = 0;            // carve launches since `progress` was zeroed
+    int32_t *seam_x = nullptr, *seam_log = nullptr, *flags = nullptr;
     int log_cap = 0, log_h = 0;
     int frozen_epoch = 0;           // pix / bias are in the frame before seam `frozen_epoch` of the session
     LqrHipCarver *root = nullptr;
@@ -2052,13 +2142,7 @@ struct LqrHipBatch {
     std::vector<LqrHipCarver *> cs;
     DevCarver *d_desc = nullptr;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;          // the carve of a seam runs here, concurrently with the band update
-    hipEvent_t ev_ready = nullptr, ev_carved = nullptr;
     int *tile_flags = nullptr;              // k_dp_tile_p: row blocks finished, per image and tile
-    // pipelined sub-batches (LQRHIP_PIPE): chain kernels and carves on CU-masked streams of their own
-    hipStream_t s_chain = nullptr, s_carve = nullptr;
-    hipEvent_t ev_main = nullptr, ev_done = nullptr;
-    bool pipe_now = false;
     size_t tile_flags_elems = 0;
     bool dirty = true;
 };
@@ -2224,7 +2308,7 @@ extern "C" LqrHipCarver *lqrhip_carver_create(const unsigned char *rgb, int w, i
 static void free_working(LqrHipCarver *c)
 {
     dfree(c->pix); dfree(c->en); dfree(c->m); dfree(c->least); dfree(c->m2); dfree(c->least2); dfree(c->bias); dfree(c->rig);
-    dfree(c->seam_x); dfree(c->seam_log); dfree(c->flags); dfree(c->progress);
+    dfree(c->seam_x); dfree(c->seam_log); dfree(c->flags);
     c->log_cap = 0;
 }
 
@@ -2261,7 +2345,7 @@ static int ensure_working(LqrHipCarver *c, int w, int h)
     size_t n = (size_t) stride * (h + 1) + 1024;
     int rc;
     if ((rc = dmalloc(&c->pix, n)) || (rc = dmalloc(&c->en, n)) || (rc = dmalloc(&c->m, n)) || (rc = dmalloc(&c->least, n)) ||
-        (rc = dmalloc(&c->seam_x, (size_t) h + 8)) || (rc = dmalloc(&c->flags, FLAG_COUNT)) || (rc = dmalloc(&c->progress, (size_t) h / 64 + 2)) ||
+        (rc = dmalloc(&c->seam_x, (size_t) h + 8)) || (rc = dmalloc(&c->flags, FLAG_COUNT)) ||
         (need_bias && (rc = dmalloc(&c->bias, n))) || (need_rig && (rc = dmalloc(&c->rig, n)))) {
         free_working(c);            // never leave a half-allocated set behind: a retry must not pass the early-out above
         return rc;
@@ -2272,10 +2356,8 @@ static int ensure_working(LqrHipCarver *c, int w, int h)
     if (e == hipSuccess) e = hipMemsetAsync(c->en, 0, n * sizeof(float), g_stream0);
     if (e == hipSuccess) e = hipMemsetAsync(c->pix, 0, n * sizeof(uint32_t), g_stream0);
     if (e == hipSuccess) e = hipMemsetAsync(c->flags, 0, FLAG_COUNT * sizeof(int32_t), g_stream0);
-    if (e == hipSuccess) e = hipMemsetAsync(c->progress, 0, ((size_t) h / 64 + 2) * sizeof(int32_t), g_stream0);
     if (e == hipSuccess) e = hipStreamSynchronize(g_stream0);
     if (e != hipSuccess) { free_working(c); HIPCK(e); }
-    c->carve_epoch = 0;
     c->stride = stride; c->wk_h = h;
     if (c->batch) c->batch->dirty = true;
     return 0;
@@ -2332,18 +2414,6 @@ extern "C" int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int c
 }
 
 // ---- batch -----------------------------------------------------------------
-// the carve stream: optionally with a different priority than the chain stream (LQRHIP_CARVE_PRIO:
-// 1 = highest, -1 = lowest, 0/unset = default)
-static hipError_t create_stream2(hipStream_t *s)
-{
-    const char *e = getenv("LQRHIP_CARVE_PRIO");
-    int mode = e ? atoi(e) : 0;
-    if (mode == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-    int lo = 0, hi = 0;
-    (void) hipDeviceGetStreamPriorityRange(&lo, &hi);       // lo = least, hi = greatest priority (numerically lower)
-    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, mode > 0 ? hi : lo);
-}
-
 extern "C" LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n)
 {
     if (lqrhip_init() < 0 || n <= 0) return nullptr;
@@ -2353,9 +2423,6 @@ extern "C" LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n)
         carvers[i]->batch = b;
     }
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess ||
-        create_stream2(&b->stream2) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_carved, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **) &b->d_desc, sizeof(DevCarver) * n) != hipSuccess) {
         g_err = "batch_create failed";
         delete b;
@@ -2368,14 +2435,7 @@ extern "C" void lqrhip_batch_destroy(LqrHipBatch *b)
 {
     if (!b) return;
     if (b->stream) { (void) hipStreamSynchronize(b->stream); (void) hipStreamDestroy(b->stream); }
-    if (b->stream2) { (void) hipStreamSynchronize(b->stream2); (void) hipStreamDestroy(b->stream2); }
-    if (b->ev_ready) (void) hipEventDestroy(b->ev_ready);
-    if (b->ev_carved) (void) hipEventDestroy(b->ev_carved);
     dfree(b->tile_flags);
-    if (b->s_chain) { (void) hipStreamSynchronize(b->s_chain); (void) hipStreamDestroy(b->s_chain); }
-    if (b->s_carve) { (void) hipStreamSynchronize(b->s_carve); (void) hipStreamDestroy(b->s_carve); }
-    if (b->ev_main) (void) hipEventDestroy(b->ev_main);
-    if (b->ev_done) (void) hipEventDestroy(b->ev_done);
     for (auto *c : b->cs) if (c->batch == b) c->batch = nullptr;
     if (b->d_desc) (void) hipFree(b->d_desc);
     delete b;
@@ -2393,7 +2453,7 @@ static DevCarver make_desc(const LqrHipCarver *c)
     DevCarver d;
     d.rgb0 = c->rgb0; d.vs = c->vs; d.bias0 = c->bias0; d.rig0 = c->rig0;
     d.pix = c->pix; d.en = c->en; d.m = c->m; d.least = c->least; d.m2 = c->m2; d.least2 = c->least2; d.bias = c->bias; d.rig = c->rig;
-    d.seam_x = c->seam_x; d.seam_log = c->seam_log; d.flags = c->flags; d.progress = c->progress;
+    d.seam_x = c->seam_x; d.seam_log = c->seam_log; d.flags = c->flags;
     return d;
 }
 
@@ -2440,9 +2500,6 @@ struct ProfScope {
 };
 
 extern "C" void lqrhip_prof_enable(int on) { g_prof = on; }
-static int g_overlap_override = -1;
-// -1: LQRHIP_OVERLAP / default; 0: carve and band update back to back on one stream; 1: overlapped
-extern "C" void lqrhip_set_overlap(int mode) { g_overlap_override = mode; }
 static int g_update_mode = -1;
 // -1: by batch size (LQRHIP_TILED_UPDATE_PX); 0: band kernel (k_band_update_tw); 1: tiled full-width update whenever its
 // grid fits; 2: the older band kernel (k_band_update_mw, overlapped with the carve for large batches)
@@ -2628,33 +2685,22 @@ static int frozen_catchup(LqrHipBatch *b, int to, int w_at_to, int h)
     return 0;
 }
 
-static int g_use_band = -1;
-static int g_band_variant = 0;
-static int g_carve_wgs = 0;          // > 0: cap on the carve kernel's workgroups (LQRHIP_CARVE_WGS)
-static int g_band_tw = 1;            // LQRHIP_BAND_TW=0: k_band_update_mw (+ carve overlap) instead of k_band_update_tw
-                                     // multi-wave one (a lone wave issues 1 instruction / 4 cycles: ~184 instr/row), so off
+static int g_use_band = -1;         // LQRHIP_NO_BAND (debug): 1 = full-width updates only (0), 2 = generic band kernel only
 static long long g_tiled_update_px = 12LL * 3840 * 2160;   // batches up to this many pixels use the tiled update (LQRHIP_TILED_UPDATE_PX)
-static int g_overlap = 1;            // carve || band update on two streams (LQRHIP_OVERLAP=0 disables)
 
-static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
-                          int full_rebuild, int leftright_next)
+// One seam of a lock-step batch: k_vpath* (pick + backtrack, publishes the side to move) -> k_carve ->
+// k_emap_update -> one form of update_mmap (or the full DP after a side switch), all on the batch's stream.
+extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
+                                int full_rebuild, int leftright_next)
 {
     int rc;
     LqrHipCarver *c0 = b->cs[0];
     if (g_use_band < 0) {
-        const char *e = getenv("LQRHIP_NO_BAND");       // debug switches: 1 = full-width updates only,
-        g_use_band = (e && atoi(e) == 1) ? 0 : (e && atoi(e) == 2) ? 2 : 1;   // 2 = generic band kernel only
-        const char *v = getenv("LQRHIP_BAND_VARIANT");  // tuning experiments
-        g_band_variant = v ? atoi(v) : 0;
-        const char *cw = getenv("LQRHIP_CARVE_WGS");
-        g_carve_wgs = cw ? atoi(cw) : 0;
-        const char *tw = getenv("LQRHIP_BAND_TW");
-        g_band_tw = tw ? atoi(tw) : 1;
+        const char *e = getenv("LQRHIP_NO_BAND");
+        g_use_band = (e && atoi(e) == 1) ? 0 : (e && atoi(e) == 2) ? 2 : 1;
         const char *tu = getenv("LQRHIP_TILED_UPDATE_PX");
         if (tu) g_tiled_update_px = atoll(tu);
         if (g_dp_tiled < 0) { const char *dt = getenv("LQRHIP_DP_TILED"); g_dp_tiled = dt ? atoi(dt) : 1; }
-        const char *ov = getenv("LQRHIP_OVERLAP");
-        g_overlap = ov ? atoi(ov) : 1;
     }
     for (auto *c : b->cs)
         if (log_index >= c->log_cap) return LQRHIP_EARG;
@@ -2675,183 +2721,74 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     const int move_dp = (wnew > 1 && !full_rebuild) ? 1 : 0;
     bool has_rigmask = false;
     for (auto *c : b->cs) has_rigmask |= (c->rig != nullptr);
-    // small batches: the whole chip recomputing every row (tiled full-width keep-rule sweep) beats the
-    // one-workgroup-per-image band walk, which is instruction-issue bound at ~1 ms per 4K seam; for
-    // large batches its 14 B/px of traffic would not
-    const bool tiled_update = move_dp && g_use_band == 1 && g_dp_tiled != 0 && p->delta_x == 1 && !has_rigmask &&
-                              (g_update_mode < 0 ? (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px : g_update_mode == 1) &&
-                              dp_persistent_ok(b, w);
-    const bool fast_band = !tiled_update && move_dp && g_use_band == 1 && p->delta_x == 1 && !has_rigmask && (size_t) h * sizeof(int) <= 60 * 1024;
-    // overlap: the bandwidth-bound carve (stream2) runs concurrently with the latency-bound band
-    // update (stream), which follows it down the image chunk by chunk (progress counters)
-    // (only pays when the carve is long enough to hide something: measured break-even ~8 images of 4K)
-    // the trapezoid-wave band kernel (default) is fast enough that hiding it under a slower, signalling
-    // carve no longer pays: it runs after the plain carve.  LQRHIP_BAND_TW=0 brings back
-    // k_band_update_mw and the overlap.
-    // (rows wider than ~4200 px: the changes outgrow its 896-column window too often, and the 8-slot build
-    // spills registers -- 3.9 ms per 8K seam against k_band_update_mw's ~2.5)
-    const bool band_tw = fast_band && g_band_tw && g_update_mode != 2 && wnew <= 4200 && (size_t) 2 * h * sizeof(int) <= 64 * 1024 &&
-                         (g_overlap_override < 1);
-    const bool overlap = fast_band && !band_tw && !b->pipe_now && (g_overlap_override >= 0 ? g_overlap_override : g_overlap) && (size_t) n * (size_t) w * (size_t) h >= (size_t) 12 * 3840 * 2160;
-    const int gate = c0->carve_epoch + 1;
-
-    auto launch_emap_update = [&](int pre_shift) -> int {
+    {
+        // algorithmic bytes of one carve launch (SURVEY 8(d)): read + write of one 4-byte
+        // plane over the half of each row right of the seam = 8 B * w*h/2 per image
+        ProfScope ps("carve", b->stream, 4.0 * (double) w * h * n);
+        hipLaunchKernelGGL(k_carve, dim3(n, (h + 3) / 4), dim3(256), 0, b->stream, b->d_desc, w, h, stride, p->delta_x, move_dp);
+    }
+    if (wnew <= 1) {            // liblqr's finish_vsmap case: nothing left to update
+        HIPCK(hipGetLastError());
+        return 0;
+    }
+    {
         ProfScope ps("emap_update", b->stream, 0);
-        if (log_index + 1 - c0->frozen_epoch > FROZEN_LAG_MAX) {
-            int rc2 = frozen_catchup(b, log_index + 1, wnew, h);
-            if (rc2) return rc2;
-        }
+        if (log_index + 1 - c0->frozen_epoch > FROZEN_LAG_MAX && (rc = frozen_catchup(b, log_index + 1, wnew, h))) return rc;
         const int epoch = c0->frozen_epoch;
-#define LAUNCH_EUPD_NT(N, NT) hipLaunchKernelGGL((k_emap_update<N, NT>), dim3((h + EU_ROWS - 1) / EU_ROWS, n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, log_index, epoch, pre_shift)
+#define LAUNCH_EUPD_NT(N, NT) hipLaunchKernelGGL((k_emap_update<N, NT>), dim3((h + EU_ROWS - 1) / EU_ROWS, n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, log_index, epoch)
 #define LAUNCH_EUPD(N) do { if (p->delta_x <= 2) LAUNCH_EUPD_NT(N, 12); else if (p->delta_x <= 8) LAUNCH_EUPD_NT(N, 36); else LAUNCH_EUPD_NT(N, 68); } while (0)
         NRG_DISPATCH(p->nrg_func, LAUNCH_EUPD)
 #undef LAUNCH_EUPD
 #undef LAUNCH_EUPD_NT
-        return 0;
-    };
-    auto launch_carve = [&](hipStream_t st) {
-        // algorithmic bytes of one carve launch (SURVEY 8(d)): read + write of one 4-byte
-        // plane over the half of each row right of the seam = 8 B * w*h/2 per image
-        ProfScope ps("carve", st, 4.0 * (double) w * h * n);
-        int gx = (h + 3) / 4;
-        if (g_carve_wgs > 0) gx = std::max(1, std::min(gx, g_carve_wgs / (int) n));
-        if (overlap) {
-            hipLaunchKernelGGL(k_carve<true>, dim3(n, gx), dim3(256), 0, st, b->d_desc, w, h, stride, p->delta_x, move_dp);
-            for (auto *c : b->cs) c->carve_epoch = gate;      // counts the signalling carves only
-        } else {
-            hipLaunchKernelGGL(k_carve<false>, dim3(n, gx), dim3(256), 0, st, b->d_desc, w, h, stride, p->delta_x, move_dp);
-        }
-    };
-    auto launch_fast_band = [&](int gate_arg) {
-        if (band_tw) {
-            ProfScope ps("band_update", b->stream, 0);
-#define LAUNCH_TW(NWV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_tw<NWV, LRV, RIGV>), dim3(n), dim3(128 * NWV), (size_t) 2 * h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, g_dev_err)
-#define LAUNCH_TW_N(LRV, RIGV) LAUNCH_TW(4, LRV, RIGV)
-            if (leftright_next) { if (p->use_rigidity) LAUNCH_TW_N(true, true); else LAUNCH_TW_N(true, false); }
-            else { if (p->use_rigidity) LAUNCH_TW_N(false, true); else LAUNCH_TW_N(false, false); }
-#undef LAUNCH_TW_N
-#undef LAUNCH_TW
-            return;
-        }
-        const int resume = 0;
-        ProfScope ps("band_update", b->stream, 0);
-#define LAUNCH_BAND_V(PX, NWV, RV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_mw<PX, NWV, RV, LRV, RIGV>), dim3(n), dim3(64 * NWV), (size_t) h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, gate_arg, resume)
-#define LAUNCH_BAND(LRV, RIGV)                                                          \
-    do {                                                                                \
-        if (g_band_variant == 1) LAUNCH_BAND_V(4, 4, 8, LRV, RIGV);                     \
-        else if (g_band_variant == 4) LAUNCH_BAND_V(2, 4, 8, LRV, RIGV);                \
-        else if (g_band_variant == 5) LAUNCH_BAND_V(2, 16, 8, LRV, RIGV);               \
-        else if (g_band_variant == 6) LAUNCH_BAND_V(4, 8, 8, LRV, RIGV);                \
-        else if (wnew > 4200) LAUNCH_BAND_V(2, 16, 8, LRV, RIGV);   /* 8K: dirty regions up to ~900 px */ \
-        else LAUNCH_BAND_V(2, 8, 8, LRV, RIGV);                                         \
-    } while (0)
-        if (leftright_next) { if (p->use_rigidity) LAUNCH_BAND(true, true); else LAUNCH_BAND(true, false); }
-        else { if (p->use_rigidity) LAUNCH_BAND(false, true); else LAUNCH_BAND(false, false); }
-#undef LAUNCH_BAND_V
-#undef LAUNCH_BAND
-    };
-
-    if (overlap) {
-        // the energy update does not read any plane the carve moves (pix/bias are frozen): it runs
-        // first and writes en where the carve will pick it up
-        if ((rc = launch_emap_update(1))) return rc;
-        HIPCK(hipEventRecord(b->ev_ready, b->stream));
-        HIPCK(hipStreamWaitEvent(b->stream2, b->ev_ready, 0));
-        launch_carve(b->stream2);
-        HIPCK(hipEventRecord(b->ev_carved, b->stream2));
-        launch_fast_band(gate);
-        HIPCK(hipStreamWaitEvent(b->stream, b->ev_carved, 0));       // everything after needs the whole carve
-        {
-            ProfScope ps("dp_update", b->stream, 0);
-            if ((rc = launch_dp<true>(b, k, wnew, h, leftright_next))) return rc;
-        }
+    }
+    if (full_rebuild) {
+        ProfScope ps("dp_sweep", b->stream, 9.0 * wnew * h * n);
+        if ((rc = launch_dp<false>(b, k, wnew, h, leftright_next))) return rc;
         HIPCK(hipGetLastError());
         return 0;
     }
-
-    if (b->pipe_now) {
-        // pipelined sub-batches: this batch's carve goes to the carve stream (its own CUs), so that it
-        // runs under the other sub-batch's chain kernels; the energy update runs first (pre-shifted)
-        if (wnew > 1 && (rc = launch_emap_update(1))) return rc;
-        HIPCK(hipEventRecord(b->ev_ready, b->stream));
-        HIPCK(hipStreamWaitEvent(b->s_carve, b->ev_ready, 0));
-        launch_carve(b->s_carve);
-        HIPCK(hipEventRecord(b->ev_carved, b->s_carve));
-        HIPCK(hipStreamWaitEvent(b->stream, b->ev_carved, 0));
-    } else {
-        launch_carve(b->stream);
-        if (wnew > 1 && (rc = launch_emap_update(0))) return rc;
+    // How E9 (update_mmap) runs.  Small batches: the whole chip recomputing every row (tiled full-width keep-rule
+    // sweep) beats the one-workgroup-per-image band walk; for large batches its 14 B/px of traffic would not.
+    const bool fast_ok = g_use_band == 1 && p->delta_x == 1 && !has_rigmask;
+    const bool tiled_update = fast_ok && g_dp_tiled != 0 &&
+                              (g_update_mode < 0 ? (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px : g_update_mode == 1) &&
+                              dp_persistent_ok(b, w);
+    if (tiled_update) {
+        ProfScope ps("dp_update_tiled", b->stream, 0);
+        if ((rc = launch_dp_persistent<true>(b, k, wnew, h, leftright_next))) return rc;
+        HIPCK(hipGetLastError());
+        return 0;
     }
-    if (wnew > 1) {
-        if (full_rebuild) {
-            ProfScope ps("dp_sweep", b->stream, 9.0 * wnew * h * n);
-            if ((rc = launch_dp<false>(b, k, wnew, h, leftright_next))) return rc;
-        } else {
-            if (tiled_update) {
-                ProfScope ps("dp_update_tiled", b->stream, 0);
-                if ((rc = launch_dp_persistent<true>(b, k, wnew, h, leftright_next))) return rc;
-                HIPCK(hipGetLastError());
-                return 0;
-            }
-            if (g_use_band) {
-                if (fast_band) {
-                    launch_fast_band(0);
-                } else {
-                    ProfScope ps("band_update", b->stream, 0);
-                    hipLaunchKernelGGL(k_band_update, dim3(n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, leftright_next);
-                }
-            } else {
-                for (auto *c : b->cs) HIPCK(hipMemsetAsync(c->flags, 0, sizeof(int32_t), b->stream));
-            }
-            ProfScope ps("dp_update", b->stream, 0);
-            if ((rc = launch_dp<true>(b, k, wnew, h, leftright_next))) return rc;
-        }
+    const bool fast_band = fast_ok && (size_t) h * sizeof(int) <= 60 * 1024;
+    // the trapezoid-wave band kernel takes rows up to ~4200 px (wider rows: the changes outgrow its 896-column window
+    // too often, and an 8-slot build spills registers); beyond that, and in update mode 2, k_band_update_mw
+    const bool band_tw = fast_band && g_update_mode != 2 && wnew <= 4200 && (size_t) 2 * h * sizeof(int) <= 64 * 1024;
+    if (!g_use_band) {
+        for (auto *c : b->cs) HIPCK(hipMemsetAsync(c->flags, 0, sizeof(int32_t), b->stream));      // FLAG_OVF_ROW = 0: everything to the sweep
+    } else if (band_tw) {
+        ProfScope ps("band_update", b->stream, 0);
+#define LAUNCH_TW(LRV, RIGV) hipLaunchKernelGGL((k_band_update_tw<4, LRV, RIGV>), dim3(n), dim3(128 * 4), (size_t) 2 * h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, g_dev_err)
+        if (leftright_next) { if (p->use_rigidity) LAUNCH_TW(true, true); else LAUNCH_TW(true, false); }
+        else { if (p->use_rigidity) LAUNCH_TW(false, true); else LAUNCH_TW(false, false); }
+#undef LAUNCH_TW
+    } else if (fast_band) {
+        ProfScope ps("band_update", b->stream, 0);
+#define LAUNCH_MW(NWV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_mw<2, NWV, 8, LRV, RIGV>), dim3(n), dim3(64 * NWV), (size_t) h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride)
+#define LAUNCH_MW_N(LRV, RIGV) do { if (wnew > 4200) LAUNCH_MW(16, LRV, RIGV); /* 8K: dirty regions up to ~900 px */ else LAUNCH_MW(8, LRV, RIGV); } while (0)
+        if (leftright_next) { if (p->use_rigidity) LAUNCH_MW_N(true, true); else LAUNCH_MW_N(true, false); }
+        else { if (p->use_rigidity) LAUNCH_MW_N(false, true); else LAUNCH_MW_N(false, false); }
+#undef LAUNCH_MW_N
+#undef LAUNCH_MW
+    } else {
+        ProfScope ps("band_update", b->stream, 0);
+        hipLaunchKernelGGL(k_band_update, dim3(n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, leftright_next);
+    }
+    {
+        // rows the band kernel handed over (flags[FLAG_OVF_ROW] .. h): the keep rule over the full width
+        ProfScope ps("dp_update", b->stream, 0);
+        if ((rc = launch_dp<true>(b, k, wnew, h, leftright_next))) return rc;
     }
     HIPCK(hipGetLastError());
-    return 0;
-}
-
-// LQRHIP_PIPE=1 (with LQRHIP_SUBBATCHES=2): the chain kernels (backtrack, energy update, band update) of a
-// batch run on a stream confined to a few CUs and its carve on a stream confined to the others, so
-// that one sub-batch's HBM-bound carve runs under the other's latency-bound chain.  Without the CU
-// masks the carve's grid takes every wave slot and the other stream's kernels just queue behind it.
-static int g_pipe = -1, g_pipe_chain_cus = 64;
-static hipError_t make_masked_stream(hipStream_t *s, int lo, int hi)
-{
-    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = lo; i < hi && i < 256; i++) mask[i >> 5] |= 1u << (i & 31);
-    return hipExtStreamCreateWithCUMask(s, 8, mask);
-}
-
-extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
-                                int full_rebuild, int leftright_next)
-{
-    if (g_pipe < 0) {
-        const char *e = getenv("LQRHIP_PIPE");
-        g_pipe = e ? atoi(e) : 0;
-        const char *cc = getenv("LQRHIP_PIPE_CHAIN_CUS");
-        if (cc) g_pipe_chain_cus = std::max(8, std::min(atoi(cc), 248));
-    }
-    if (!g_pipe || b->cs.size() < 4) return seam_step_impl(b, p, w, h, log_index, leftright_pick, full_rebuild, leftright_next);
-    if (!b->s_chain) {
-        if (make_masked_stream(&b->s_chain, 0, g_pipe_chain_cus) != hipSuccess || make_masked_stream(&b->s_carve, g_pipe_chain_cus, 256) != hipSuccess ||
-            hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming) != hipSuccess) {
-            g_err = "cannot create CU-masked streams";
-            return LQRHIP_EHIP;
-        }
-    }
-    HIPCK(hipEventRecord(b->ev_main, b->stream));
-    HIPCK(hipStreamWaitEvent(b->s_chain, b->ev_main, 0));
-    hipStream_t main_stream = b->stream;
-    b->stream = b->s_chain;
-    b->pipe_now = true;
-    const int rc = seam_step_impl(b, p, w, h, log_index, leftright_pick, full_rebuild, leftright_next);
-    b->pipe_now = false;
-    b->stream = main_stream;
-    if (rc) return rc;
-    HIPCK(hipEventRecord(b->ev_done, b->s_chain));
-    HIPCK(hipStreamWaitEvent(b->stream, b->ev_done, 0));
     return 0;
 }
 
@@ -3089,21 +3026,24 @@ extern "C" int lqrhip_read_working(LqrHipCarver *c, int w, int h, float *en, flo
     int rc = batch_sync_of(c);
     if (rc) return rc;
     if (!c->pix) return LQRHIP_EARG;
+    int32_t fl[FLAG_COUNT];
+    HIPCK(hipMemcpy(fl, c->flags, sizeof fl, hipMemcpyDeviceToHost));
+    const int org = fl[FLAG_ORG];                 // the carved planes start `org` elements into each row
     size_t n = (size_t) c->stride * h;
     std::vector<float> t(n);
     std::vector<int8_t> tl(n);
     if (en) {
         HIPCK(hipMemcpy(t.data(), c->en, n * sizeof(float), hipMemcpyDeviceToHost));
-        for (int y = 0; y < h; y++) memcpy(en + (size_t) y * w, t.data() + (size_t) y * c->stride, (size_t) w * sizeof(float));
+        for (int y = 0; y < h; y++) memcpy(en + (size_t) y * w, t.data() + (size_t) y * c->stride + org, (size_t) w * sizeof(float));
     }
     if (m) {
         HIPCK(hipMemcpy(t.data(), c->m, n * sizeof(float), hipMemcpyDeviceToHost));
-        for (int y = 0; y < h; y++) memcpy(m + (size_t) y * w, t.data() + (size_t) y * c->stride, (size_t) w * sizeof(float));
+        for (int y = 0; y < h; y++) memcpy(m + (size_t) y * w, t.data() + (size_t) y * c->stride + org, (size_t) w * sizeof(float));
     }
     if (least_dx) {
         HIPCK(hipMemcpy(tl.data(), c->least, n, hipMemcpyDeviceToHost));
         for (int y = 0; y < h; y++)
-            for (int x = 0; x < w; x++) least_dx[(size_t) y * w + x] = y == 0 ? 0 : (int) tl[(size_t) y * c->stride + x];
+            for (int x = 0; x < w; x++) least_dx[(size_t) y * w + x] = y == 0 ? 0 : (int) tl[(size_t) y * c->stride + org + x];
     }
     return 0;
 }

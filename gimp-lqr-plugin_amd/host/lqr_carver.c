@@ -90,13 +90,11 @@ struct _LqrCarver {
     int *dbg_least, dbg_w, dbg_h;
 };
 
-#define MAX_SUB 8
+#define MAX_SUB 1
 typedef struct {
     LqrCarver **r;
     int n;
-    /* the group's carvers are split over nb device batches (one HIP stream each): the per-image
-     * dependency chains of one sub-batch overlap with the bandwidth-bound carve of another */
-    LqrHipBatch *b[MAX_SUB];
+    LqrHipBatch *b[MAX_SUB];    /* the group's device batch (one HIP stream) */
     int nb;
 } Group;
 
@@ -285,19 +283,6 @@ static void set_width_tree(LqrCarver *r, int w1)
     for (l = r->attached; l; l = l->next) set_width_tree(l->current, w1);
 }
 
-static int sub_batches_for(int n)
-{
-    /* measured on MI355X (64 x 4K): 1 stream 157-175k, 2 streams 177k, 4 streams 130k Mseams*px/s --
-     * the chain kernels slow down under the carve's HBM load as much as the overlap gains, so the
-     * default is one batch; LQRHIP_SUBBATCHES overrides */
-    const char *e = getenv("LQRHIP_SUBBATCHES");
-    int nb = e ? atoi(e) : 1;
-    if (nb < 1) nb = 1;
-    if (nb > MAX_SUB) nb = MAX_SUB;
-    if (nb > n) nb = n;
-    return nb;
-}
-
 static LqrRetVal group_open(Group *g, LqrCarver **rs, int n)
 {
     int i, k;
@@ -313,7 +298,7 @@ static LqrRetVal group_open(Group *g, LqrCarver **rs, int n)
         g->nb = 1;
     } else {
         LqrHipCarver **ds = (LqrHipCarver **) malloc((size_t) n * sizeof *ds);
-        int nb = sub_batches_for(n);
+        const int nb = 1;       /* one device batch (one HIP stream) per group: measured faster than 2 or 4 sub-batches */
         if (!ds) return LQR_NOMEM;
         for (i = 0; i < n; i++) {
             if (rs[i]->own_batch) { lqrhip_batch_destroy(rs[i]->own_batch); rs[i]->own_batch = NULL; }

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 def update_mode(request, engine):
     """Every test runs three times: with the engine's default choice of update_mmap kernel (the tiled
     full-width sweep at these sizes), with the band kernel the large batches use, and with the
-    older band kernel kept behind LQRHIP_BAND_TW=0."""
+    per-row-barrier band kernel k_band_update_mw (the default for rows wider than 4200 px)."""
     import ctypes
     lib = engine.lib
     lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]

@@ -228,3 +228,35 @@ def test_vmap_colour_ramp_on_the_device(oracle, engine):
                 assert len(res) == len(want) and len(res) >= 2
                 for a, b in zip(want, res):
                     assert a.shape == b.shape and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("where", ["left", "right", "both"])
+def test_both_carve_sides_and_origin(oracle, engine, where):
+    """the carve moves the shorter side of the seam: a discard band at the left edge sends every seam there (the left
+    part moves right, the planes' origin advances seam by seam), one at the right edge keeps the origin at 0, two
+    bands alternate.  Seam maps, pixels AND the DP planes after the last incremental update must match the oracle
+    (lqrx debug snapshot reads the planes through the origin)."""
+    w, h = 420, 150
+    img = D.photo_like(w, h, 900)
+    disc = np.zeros((h, w, 4), np.uint8)
+    if where in ("left", "both"):
+        disc[:, 6:60] = 255
+    if where in ("right", "both"):
+        disc[:, w - 70:w - 9] = 255
+    for mode in (-1, 0, 2):
+        engine.lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]
+        engine.lib.lqrhip_set_update_mode(mode)
+        try:
+            both(oracle, engine, img, w - 90, h - 20, disc=disc, output_seams=True)
+            snaps = []
+            for api in (oracle, engine):
+                api.lqrx_set_debug(1)
+                c, _ = H.init_carver(api, img, w - 45, h, disc=disc, switch_freq=0)
+                assert c.resize(w - 45, h) == L.LQR_OK
+                snaps.append(c.debug_snapshot())
+                api.lqrx_set_debug(0)
+                c.destroy()
+            (ea, ma, da), (eb, mb, db) = snaps
+            assert np.array_equal(ea, eb) and np.array_equal(ma, mb) and np.array_equal(da[1:], db[1:])
+        finally:
+            engine.lib.lqrhip_set_update_mode(-1)
