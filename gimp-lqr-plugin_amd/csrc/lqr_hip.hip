@@ -71,7 +71,7 @@ struct DevCarver {
     float *m;
     int8_t *least;
     float *m2;              // second m / back-pointer planes: output of the out-of-place tiled update,
-    int8_t *least2;         // swapped with m / least afterwards (k_swap_planes)
+    int8_t *least2;         // swapped with m / least afterwards (by the last tile of k_dp_tile_p<UPDATE>)
     float *bias;
     float *rig;
     int32_t *seam_x;
@@ -509,34 +509,36 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
 }
 
 // ---------------------------------------------------------------------------
-// k_vpath1: k_vpath for delta_x == 1 with the chase made branch-free and the loads
-// made unconditional, so that the compiler can count them: in k_vpath every row
-// of the chase is guarded (`r < nrows`, two taken branches per step) and the
-// predicated chunk loads make the compiler fall back to s_waitcnt vmcnt(0) before
-// the first step of a chunk, which serialises load latency and chase.  Here rows
-// above the image read a zero dword (dx = 0) instead of being skipped, the lane
-// that records the path is written with v_writelane, and a chunk's loads stay in
-// flight under the previous chunk's chase.
+// k_vpath1: k_vpath for delta_x == 1.  The chase is a chain of H dependent steps on one wave, so what counts
+// is the length of one step.  In k_vpath a step is v_readlane + 7 scalar instructions (find the lane, pull the
+// dword, extract and sign-extend the byte) and ~55 ns.  Here the rows are taken in chunks of 31:
+//   * as before, lane L holds the 4 back-pointer bytes of columns xa + 4L .. +3 of a 256-column window, one
+//     coalesced load per row, loaded THREE chunks ahead (the chunk's start column is then known to within
+//     3 * 31 columns, and it moves at most 31 more inside the chunk: 124 <= 126 columns of margin);
+//   * when a chunk's turn comes its start column xc is known exactly, and the 64 columns xc - 32 .. xc + 31
+//     are spread out one per lane, sign-extended (one ds_bpermute + one v_bfe_i32 per row, all rows
+//     independent: throughput, not latency);
+//   * the chase step is then v_readlane (the lane IS the column) + s_add, plus a v_writelane that records the
+//     path: ~3 instructions.
+// No load is guarded or predicated (rows above the image re-read row 1 and their steps are discarded).
+// No LEAST_INVALID test: the carve marks a back pointer invalid only next to the seam, inside the interval
+// every form of update_mmap recomputes before the next backtrack, so none survives to this point.
 // ---------------------------------------------------------------------------
+#define VP1_ROWS 31
+#define VP1_AHEAD 3
 template <int r>
-__device__ __forceinline__ void vp_step(const uint32_t reg, int &x, const int xa, int &path)
+__device__ __forceinline__ void vp1_step(const int e, int &o, int &path)
 {
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(path) : "s"(x), "n"(r));      // lane r <- column at row y_top - r
-    const int o = x - xa;
-    const uint32_t dw = (uint32_t) __builtin_amdgcn_readlane((int) reg, o >> 2);
-    // no LEAST_INVALID test here (3 of 10 instructions on the chain): the carve marks a back pointer
-    // invalid only next to the seam, inside the interval every form of update_mmap recomputes before
-    // the next backtrack, so none survives to this point
-    x += (int) (int8_t) (dw >> (8 * (o & 3)));
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(path) : "s"(o), "n"(r));      // lane r <- window offset at row y_top - r
+    o += __builtin_amdgcn_readlane(e, o);
 }
 template <int... Rs>
-__device__ __forceinline__ void vp_chase(const uint32_t (&regs)[VP_ROWS], int &x, const int xa, int &path, std::integer_sequence<int, Rs...>)
+__device__ __forceinline__ void vp1_chase(const int (&e)[VP1_ROWS], int &o, int &path, std::integer_sequence<int, Rs...>)
 {
-    (vp_step<Rs>(regs[Rs], x, xa, path), ...);
+    (vp1_step<Rs>(e[Rs], o, path), ...);
 }
 
-__global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, int w, int h, int stride, int lr, int log_index,
-                                                           const uint32_t *zero_page)
+__global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, int w, int h, int stride, int lr, int log_index)
 {
     const GCarver c = gview(cs[blockIdx.x]);
     const int org = c.flags[FLAG_ORG];           // read before wave 0 publishes the next one
@@ -582,46 +584,55 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, i
     const int lane = tid;
     gi32 *seam = c.seam_x;
     gi32 *logp = c.seam_log + (size_t) log_index * h;
-    const gu32 *zero = (const gu32 *) zero_page;
-    constexpr int R = VP_ROWS;
-    uint32_t regs[2][VP_ROWS];
+    constexpr int R = VP1_ROWS, NB = VP1_AHEAD + 1;
+    uint32_t regs[NB][R];                        // ring of packed windows: chunk k lives in regs[k % NB]
+    int xa[NB];                                  // their base columns
     auto window_base = [&](int cx) { return (cx - 126) & ~3; };
-    auto load_chunk = [&](int b, int y_top, int xa) {
-        const int xl = xa + 4 * lane;
-        const bool ok = (xl >= 0) && (xl + 3 < stride);
+    // Nothing is predicated (a select per load cost more instructions than the chase itself): columns outside
+    // the plane are clamped into it -- the path never goes there -- and rows above row 1 re-read row 1; the steps
+    // taken on those are discarded (see run_chunk).  Uniform row base + 32-bit lane offset: one VALU per load.
+    auto load_chunk = [&](int b, int y_top, int cx) {
+        const int base = window_base(cx);
+        xa[b] = base;
+        const unsigned voff = (unsigned) min(max(base + 4 * lane, 0), stride - 4);
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const int y = y_top - r;
-            // rows above row 1 and columns outside the plane read a zero dword: dx = 0
-            const gu32 *src = (ok && y >= 1) ? (const gu32 *) (c.least + (size_t) y * stride + xl) : zero;
-            regs[b][r] = *src;
+            const unsigned srow = (unsigned) max(y_top - r, 1) * (unsigned) stride;
+            regs[b][r] = *(const gu32 *) (c.least + (srow + voff));
         }
     };
-    int y_top = h - 1;
-    int xa_cur = window_base(x);
+    // one chunk: spread the 64 columns around the start column out over the lanes, chase, record
     int acc = 0;
-    load_chunk(0, y_top, xa_cur);
-    while (true) {
-        {
-            const int nrows = min(R, y_top);
-            const int xa_next = window_base(x);
-            load_chunk(1, y_top - R, xa_next);                                     // in flight during the chase
-            int path = 0;
-            vp_chase(regs[0], x, xa_cur, path, std::make_integer_sequence<int, R>{});
-            if (lane < nrows) { seam[y_top - lane] = path; logp[y_top - lane] = path; acc += path; }
-            xa_cur = xa_next;
-            y_top -= nrows;
+    auto run_chunk = [&](int b, int y_top) {
+        const int col = x - 32 + lane;                       // this lane's column
+        const int rel = col - xa[b];                         // 0 .. 255 inside the window
+        const int src = (rel >> 2) << 2;                     // ds_bpermute takes a byte address
+        const int sh = (rel & 3) << 3;
+        int e[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int dw = __builtin_amdgcn_ds_bpermute(src, (int) regs[b][r]);
+            e[r] = __builtin_amdgcn_sbfe(dw, sh, 8);
         }
-        if (y_top < 1) break;
-        {
-            const int nrows = min(R, y_top);
-            const int xa_next = window_base(x);
-            load_chunk(0, y_top - R, xa_next);
-            int path = 0;
-            vp_chase(regs[1], x, xa_cur, path, std::make_integer_sequence<int, R>{});
-            if (lane < nrows) { seam[y_top - lane] = path; logp[y_top - lane] = path; acc += path; }
-            xa_cur = xa_next;
-            y_top -= nrows;
+        int o = 32, path = 0;
+        vp1_chase(e, o, path, std::make_integer_sequence<int, R>{});
+        path += x - 32;                                      // lane r: column at row y_top - r (before step r)
+        const int nrows = min(R, y_top);
+        if (lane < nrows) { seam[y_top - lane] = path; logp[y_top - lane] = path; acc += path; }
+        // the column after `nrows` steps: the last chunk may hold fewer real rows than R (the rest re-read row 1)
+        x = (nrows == R) ? x + o - 32 : __builtin_amdgcn_readlane(path, nrows);
+    };
+    int y_top = h - 1;
+    // chunks are issued VP1_AHEAD ahead; the first ones all around the argmin
+#pragma unroll
+    for (int k = 0; k < VP1_AHEAD; k++) load_chunk(k, y_top - k * R, x);
+    while (true) {
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            load_chunk((k + VP1_AHEAD) % NB, y_top - VP1_AHEAD * R, x);      // in flight during this and the next two chases
+            run_chunk(k, y_top);
+            y_top -= R;
+            if (y_top < 1) break;
         }
         if (y_top < 1) break;
     }
@@ -1797,18 +1808,19 @@ __global__ __launch_bounds__(64) void k_dp_tile(const DevCarver *cs, DpK p, int 
 // UPDATE = liblqr's update_mmap keep-rule applied to every pixel (a superset of the band,
 // section 4.4), reading m / least and writing m2 / least2 (tiles overlap in their halos, so an
 // in-place update would let a tile read a neighbour's half-updated (m, least) pair); the host
-// swaps the plane pointers afterwards (k_swap_planes).
+// tile that finishes last swaps the plane pointers in the device descriptor.
 // ---------------------------------------------------------------------------
 constexpr int DPP_HALO = 64;                    // halo columns on each side = rows per block
 constexpr int DPP_OWN = 256 - 2 * DPP_HALO;     // columns a tile owns
 constexpr int DPP_R = 16;                       // rows per batch
 constexpr int DPP_W = 2;                        // waves taking turns
+constexpr int DPP_EX_TILE = 2 * 2 * DPP_HALO;   // granules a tile publishes: [block parity][side: 0 to the left, 1 to the right][column]
 static_assert(DPP_HALO % (DPP_R * DPP_W) == 0, "a block is a whole number of rounds");
 // co-residency bound for the spin waits, set from the occupancy query in lqrhip_init (dpp_resident_workgroups)
 static int g_dpp_max_wgs = 0;
 
 template <bool LR, bool RIG, bool UPDATE>
-__global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, DpK p, int w, int h, int stride, int *tile_flags, int *dev_err)
+__global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err)
 {
     __shared__ f32x4 s_mp[64];                   // the row above the next batch, handed from wave to wave
     __shared__ int s_fail;                       // a neighbour never showed up: both waves leave at the next barrier
@@ -1818,7 +1830,11 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, D
     gf32 *m_out = UPDATE ? c.m2 : c.m;
     gi8 *least_out = UPDATE ? c.least2 : c.least;
     const int ntiles = gridDim.x, tile = blockIdx.x;
-    gi32 *flags = (gi32 *) (tile_flags + (size_t) blockIdx.y * ntiles);
+    // exchange area of this image: per tile DPP_EX_TILE granules ({m bits, tag}, 8 bytes, one store each), then one
+    // word that counts finished tiles
+    typedef GLOBAL_AS unsigned long long gu64;
+    gu64 *ex_img = (gu64 *) exch + (size_t) blockIdx.y * ((size_t) ntiles * DPP_EX_TILE + 8);
+    gi32 *done_ctr = (gi32 *) (ex_img + (size_t) ntiles * DPP_EX_TILE);
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float INF = __int_as_float(0x7f800000);
@@ -1896,31 +1912,40 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, D
                     mp[0] = v[0]; mp[1] = v[1]; mp[2] = v[2]; mp[3] = v[3];
                 }
                 if (bb == 0 && j > 0) {
-                    // neighbours must have published block j-1; every spin is bounded.  A tile that never shows
-                    // up means the grid was not co-resident (the host sizes it from the occupancy query, but the
-                    // GPU may be shared): record the failure in the host-visible error word and stop waiting --
-                    // every other tile sees the word in its own spin loop and leaves too, the host returns
-                    // LQR_ERROR at its next synchronisation.  Nothing traps.
+                    // Halo columns of the row above the block: the tile's own values there are contaminated from the
+                    // tile edge inwards, the neighbours hold the true ones and published them as data-tagged granules
+                    // (one 8-byte {m, tag} per column, each written by ONE write-through store: no flag, no fence, no
+                    // drain -- MI355X_MICROARCH.md, hand-off price list).  tag = (launch epoch, block), so nothing has
+                    // to be cleared between launches; two slots by block parity, because a neighbour that is a
+                    // whole block ahead publishes block j before this tile has read block j - 1.
+                    // Every spin is bounded.  A neighbour that never shows up means the grid was not co-resident (the
+                    // host sizes it from the occupancy query, but the GPU may be shared): record the failure in the
+                    // host-visible error word and stop waiting -- every other tile sees the word in its own spin loop
+                    // and leaves too, the host returns LQR_ERROR at its next synchronisation.  Nothing traps.
+                    const bool need = !own_lane && (in[0] || in[1] || in[2] || in[3]);
+                    const int nb = (lane < 32) ? tile - 1 : tile + 1;                     // left halo <- left neighbour's right-going granules
+                    const int col = !need ? 0 : (lane < 32) ? 4 * lane : 4 * (lane - 64 + DPP_HALO / 4);        // lanes that need nothing poll a dummy
+                    gu64 *src = ex_img + (size_t) (need ? nb : tile) * DPP_EX_TILE + (size_t) (((j - 1) & 1) * 2 + (lane < 32 ? 1 : 0)) * DPP_HALO + col;
+                    const unsigned want = ((unsigned) epoch << 8) | (unsigned) j;
+                    unsigned long long g[4];
+                    int spins = 0;
                     bool failed = false;
-                    for (int side = -1; side <= 1; side += 2) {
-                        const int nb = tile + side;
-                        if (nb < 0 || nb >= ntiles) continue;
-                        int spins = 0;
-                        while (!failed && __hip_atomic_load(flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < j) {
-                            __builtin_amdgcn_s_sleep(2);
-                            ++spins;
-                            if ((spins & 1023) == 0 && dev_failed(dev_err)) failed = true;
-                            if (spins > (1 << 24)) { if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); failed = true; }
-                        }
+                    while (true) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) g[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        bool ok = true;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) ok &= ((unsigned) (g[k] >> 32) == want);
+                        if (__all(ok || !need)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        ++spins;
+                        if ((spins & 1023) == 0 && dev_failed(dev_err)) { failed = true; break; }
+                        if (spins > (1 << 22)) { if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); failed = true; break; }
                     }
                     if (failed) s_fail = 1;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    if (!own_lane) {
-                        // halo columns: the tile's own values there are contaminated from the tile edge inwards
-                        const gf32 *mrow = m_out + (size_t) (y0 - 1) * stride;
+                    if (need) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++)
-                            mp[k] = in[k] ? __hip_atomic_load(mrow + x0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
+                        for (int k = 0; k < 4; k++) mp[k] = in[k] ? __uint_as_float((unsigned) g[k]) : INF;
                     }
                 }
                 if (yb > 0 && yb + R <= h) { if (interior) batch(yb, std::false_type{}, std::false_type{}); else batch(yb, std::false_type{}, std::true_type{}); }
@@ -1929,15 +1954,16 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, D
                     f32x4 v = {mp[0], mp[1], mp[2], mp[3]};
                     s_mp[lane] = v;
                 }
-                if (yb + R > ylast) {
-                    // publish: the block's last row (still in mp) goes out again write-through, for the
-                    // neighbours' halo reload; drain this wave's stores, then one relaxed add
-                    if (own) {
-                        u32x4 t = {__float_as_uint(mp[0]), __float_as_uint(mp[1]), __float_as_uint(mp[2]), __float_as_uint(mp[3])};
-                        store_sc1_x4((gu32 *) (m_out + (unsigned) ylast * (unsigned) stride + (unsigned) x0), t);
+                if (yb + R > ylast && j + 1 < nblk) {
+                    // publish the block's last row (still in mp): the outer DPP_HALO own columns on each side are the
+                    // neighbours' halo; lanes 16..31 write the left-going granules, lanes 32..47 the right-going ones
+                    if (own_lane) {
+                        const int side = lane < 32 ? 0 : 1;
+                        gu64 *dst = ex_img + (size_t) tile * DPP_EX_TILE + (size_t) ((j & 1) * 2 + side) * DPP_HALO + 4 * (lane - (side ? 32 : DPP_HALO / 4));
+                        const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 8) | (unsigned) (j + 1)) << 32;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) __hip_atomic_store(dst + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_fetch_add(flags + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 issue(yb + DPP_W * R);
             }
@@ -1946,14 +1972,16 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(const DevCarver *cs, D
             if (s_fail) return;                  // uniform: written before the barrier, read by both waves after it
         }
     }
-}
-
-__global__ void k_swap_planes(DevCarver *cs, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float *m = cs[i].m; cs[i].m = cs[i].m2; cs[i].m2 = m;
-    int8_t *l = cs[i].least; cs[i].least = cs[i].least2; cs[i].least2 = l;
+    if (UPDATE && threadIdx.x == 0) {
+        // the update wrote m2 / least2: the tile that finishes last swaps the image's plane pointers in the device
+        // descriptor (every tile read the descriptor before it could finish) and re-arms the counter
+        if (__hip_atomic_fetch_add(done_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ntiles - 1) {
+            DevCarver *d = cs + blockIdx.y;
+            float *m = d->m; d->m = d->m2; d->m2 = m;
+            int8_t *l = d->least; d->least = d->least2; d->least2 = l;
+            __hip_atomic_store(done_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2142,9 +2170,13 @@ struct LqrHipBatch {
     std::vector<LqrHipCarver *> cs;
     DevCarver *d_desc = nullptr;
     hipStream_t stream = nullptr;
-    int *tile_flags = nullptr;              // k_dp_tile_p: row blocks finished, per image and tile
-    size_t tile_flags_elems = 0;
+    unsigned long long *exch = nullptr;     // k_dp_tile_p: halo granules per image and tile + finished-tile counters
+    size_t exch_elems = 0;
+    int exch_ntiles = 0, exch_n = 0;        // geometry the exchange area was last laid out for
+    int tile_epoch = 0;                     // launches of k_dp_tile_p on this batch (part of the granule tags)
     bool dirty = true;
+    bool shared = false;                    // other batches of the same group run concurrently on their own streams:
+                                            // no persistent (spin-waiting, co-residency-dependent) kernels
 };
 
 struct ProfRec {
@@ -2154,7 +2186,6 @@ struct ProfRec {
 static int g_prof = 0;                 // 0 off, 1 every kernel, 2 the roofline kernel (k_carve) only
 static std::map<std::string, ProfRec> g_profrec;
 static hipStream_t g_stream0 = nullptr;
-static uint32_t *g_zero_page = nullptr;     // 4 KB of zeros on the device (k_vpath1 reads it for rows above the image)
 
 extern "C" const char *lqrhip_last_error(void) { return g_err.c_str(); }
 
@@ -2194,9 +2225,6 @@ extern "C" int lqrhip_init(void)
     if (lr) dev = atoi(lr) % n;
     HIPCK(hipSetDevice(dev));
     HIPCK(hipStreamCreateWithFlags(&g_stream0, hipStreamNonBlocking));
-    HIPCK(hipMalloc((void **) &g_zero_page, 4096));
-    HIPCK(hipMemsetAsync(g_zero_page, 0, 4096, g_stream0));
-    HIPCK(hipStreamSynchronize(g_stream0));
     HIPCK(hipHostMalloc((void **) &g_dev_err_host, sizeof(int), hipHostMallocMapped));
     *g_dev_err_host = 0;
     HIPCK(hipHostGetDevicePointer((void **) &g_dev_err, g_dev_err_host, 0));
@@ -2414,6 +2442,15 @@ extern "C" int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int c
 }
 
 // ---- batch -----------------------------------------------------------------
+static int g_sub_batches = -1, g_carve_wgs_per_cu = -1, g_num_cus = 256;
+extern "C" int lqrhip_sub_batches(int n)
+{
+    if (g_sub_batches < 0) { const char *e = getenv("LQRHIP_SUBBATCHES"); g_sub_batches = e ? atoi(e) : 1; }
+    return n >= 8 ? g_sub_batches : 1;
+}
+
+extern "C" void lqrhip_batch_set_shared(LqrHipBatch *b, int shared) { b->shared = shared != 0; }
+
 extern "C" LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n)
 {
     if (lqrhip_init() < 0 || n <= 0) return nullptr;
@@ -2435,7 +2472,7 @@ extern "C" void lqrhip_batch_destroy(LqrHipBatch *b)
 {
     if (!b) return;
     if (b->stream) { (void) hipStreamSynchronize(b->stream); (void) hipStreamDestroy(b->stream); }
-    dfree(b->tile_flags);
+    dfree(b->exch);
     for (auto *c : b->cs) if (c->batch == b) c->batch = nullptr;
     if (b->d_desc) (void) hipFree(b->d_desc);
     delete b;
@@ -2444,7 +2481,14 @@ extern "C" void lqrhip_batch_destroy(LqrHipBatch *b)
 extern "C" int lqrhip_batch_sync(LqrHipBatch *b)
 {
     HIPCK(hipStreamSynchronize(b->stream));
-    return check_dev_error();
+    const int rc = check_dev_error();
+    if (rc) {
+        // a persistent sweep gave up half way: its exchange area and the device descriptors (plane swap) are in an
+        // unknown state -- lay both out again before anything else runs on this batch
+        b->exch_ntiles = 0;
+        b->dirty = true;
+    }
+    return rc;
 }
 extern "C" void *lqrhip_batch_stream(LqrHipBatch *b) { return (void *) b->stream; }
 
@@ -2579,6 +2623,8 @@ static int launch_dp_tiled(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
 // whole grid has to be resident at once.
 static bool dp_persistent_ok(const LqrHipBatch *b, int w)
 {
+    if (b->shared) return false;
+    if (b->cs[0]->wk_h > 255 * DPP_HALO) return false;       // the block index is 8 bits of the granule tag
     const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs) : g_dpp_max_wgs;
     return (size_t) ((w + DPP_OWN - 1) / DPP_OWN) * b->cs.size() <= (size_t) limit;
 }
@@ -2591,11 +2637,20 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
     const size_t n = b->cs.size();
     const int ntiles = (w + DPP_OWN - 1) / DPP_OWN;
     int rc;
-    if (b->tile_flags_elems < (size_t) ntiles * n) {
+    const size_t need_elems = ((size_t) ntiles * DPP_EX_TILE + 8) * n;
+    if (b->exch_elems < need_elems) {
         HIPCK(hipStreamSynchronize(b->stream));
-        dfree(b->tile_flags);
-        if ((rc = dmalloc(&b->tile_flags, (size_t) ntiles * n + 64))) return rc;
-        b->tile_flags_elems = (size_t) ntiles * n + 64;
+        dfree(b->exch);
+        b->exch_elems = 0;
+        if ((rc = dmalloc(&b->exch, need_elems))) return rc;
+        b->exch_elems = need_elems;
+        b->exch_ntiles = 0;
+    }
+    if (b->exch_ntiles != ntiles || b->exch_n != (int) n) {
+        // (re)lay the exchange area out: tags and finished-tile counters start at 0 (afterwards nothing is ever
+        // cleared: tags carry the launch epoch, the last tile re-arms the counter)
+        HIPCK(hipMemsetAsync(b->exch, 0, need_elems * sizeof(unsigned long long), b->stream));
+        b->exch_ntiles = ntiles; b->exch_n = (int) n;
     }
     if (UPDATE) {
         // second planes, allocated on first use -- per carver: a batch may mix carvers that already went
@@ -2613,18 +2668,15 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
             if ((rc = batch_upload(b))) return rc;
         }
     }
-    HIPCK(hipMemsetAsync(b->tile_flags, 0, (size_t) ntiles * n * sizeof(int), b->stream));
+    const int epoch = 1 + ((b->tile_epoch++) % 0x7ffffe);          // never 0; 23 bits above the 8-bit block index
     const dim3 grid(ntiles, (unsigned) n);
-#define LAUNCH_TILE(LRV, RIGV) hipLaunchKernelGGL((k_dp_tile_p<LRV, RIGV, UPDATE>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->tile_flags, g_dev_err)
+#define LAUNCH_TILE(LRV, RIGV) hipLaunchKernelGGL((k_dp_tile_p<LRV, RIGV, UPDATE>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
     if (lr) { if (k.use_rig) LAUNCH_TILE(true, true); else LAUNCH_TILE(true, false); }
     else { if (k.use_rig) LAUNCH_TILE(false, true); else LAUNCH_TILE(false, false); }
 #undef LAUNCH_TILE
     HIPCK(hipGetLastError());
-    if (UPDATE) {
-        hipLaunchKernelGGL(k_swap_planes, dim3((unsigned) (n + 63) / 64), dim3(64), 0, b->stream, b->d_desc, (int) n);
-        HIPCK(hipGetLastError());
+    if (UPDATE)       // the kernel's last tile swapped the pointers in the device descriptors: mirror it
         for (auto *c : b->cs) { std::swap(c->m, c->m2); std::swap(c->least, c->least2); }
-    }
     return 0;
 }
 
@@ -2711,8 +2763,7 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     {
         ProfScope ps("vpath", b->stream, 0);
         if (p->delta_x == 1)
-            hipLaunchKernelGGL(k_vpath1, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index,
-                               g_zero_page);
+            hipLaunchKernelGGL(k_vpath1, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index);
         else
             hipLaunchKernelGGL(k_vpath, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, p->delta_x,
                                log_index);
@@ -2725,7 +2776,10 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         // algorithmic bytes of one carve launch: read + write of one 4-byte
         // plane over the half of each row right of the seam = 8 B * w*h/2 per image
         ProfScope ps("carve", b->stream, 4.0 * (double) w * h * n);
-        hipLaunchKernelGGL(k_carve, dim3(n, (h + 3) / 4), dim3(256), 0, b->stream, b->d_desc, w, h, stride, p->delta_x, move_dp);
+        if (g_carve_wgs_per_cu < 0) { const char *e = getenv("LQRHIP_CARVE_WGS_PER_CU"); g_carve_wgs_per_cu = e ? atoi(e) : 0; }
+        int gy = (h + 3) / 4;
+        if (g_carve_wgs_per_cu > 0) gy = std::max(1, std::min(gy, g_carve_wgs_per_cu * g_num_cus / (int) n));
+        hipLaunchKernelGGL(k_carve, dim3(n, gy), dim3(256), 0, b->stream, b->d_desc, w, h, stride, p->delta_x, move_dp);
     }
     if (wnew <= 1) {            // liblqr's finish_vsmap case: nothing left to update
         HIPCK(hipGetLastError());

@@ -90,11 +90,13 @@ struct _LqrCarver {
     int *dbg_least, dbg_w, dbg_h;
 };
 
-#define MAX_SUB 1
+#define MAX_SUB 8
 typedef struct {
     LqrCarver **r;
     int n;
-    LqrHipBatch *b[MAX_SUB];    /* the group's device batch (one HIP stream) */
+    /* the group's carvers are split over nb device batches (one HIP stream each), all advancing seam by seam:
+     * the latency-bound chain kernels of one sub-batch run under the bandwidth-bound carve of another */
+    LqrHipBatch *b[MAX_SUB];
     int nb;
 } Group;
 
@@ -298,7 +300,10 @@ static LqrRetVal group_open(Group *g, LqrCarver **rs, int n)
         g->nb = 1;
     } else {
         LqrHipCarver **ds = (LqrHipCarver **) malloc((size_t) n * sizeof *ds);
-        const int nb = 1;       /* one device batch (one HIP stream) per group: measured faster than 2 or 4 sub-batches */
+        int nb = lqrhip_sub_batches(n);
+        if (nb < 1) nb = 1;
+        if (nb > MAX_SUB) nb = MAX_SUB;
+        if (nb > n) nb = n;
         if (!ds) return LQR_NOMEM;
         for (i = 0; i < n; i++) {
             if (rs[i]->own_batch) { lqrhip_batch_destroy(rs[i]->own_batch); rs[i]->own_batch = NULL; }
@@ -308,6 +313,7 @@ static LqrRetVal group_open(Group *g, LqrCarver **rs, int n)
             int lo = (int) ((long long) n * k / nb), hi = (int) ((long long) n * (k + 1) / nb);
             g->b[k] = lqrhip_batch_create(ds + lo, hi - lo);
             if (!g->b[k]) { free(ds); return LQR_NOMEM; }
+            lqrhip_batch_set_shared(g->b[k], nb > 1);
             g->nb = k + 1;
         }
         free(ds);

@@ -71,7 +71,12 @@ int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int channels, in
                     int x_off, int y_off, int transposed, int is_rigmask, int bias_factor);
 
 /* -- batch ------------------------------------------------------------------ */
+/* into how many device batches (HIP streams) the host should split a lock-step group of n carvers */
+int lqrhip_sub_batches(int n);
 LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n);
+/* tell a batch that sibling batches of the same group run concurrently on other streams: kernels whose grid must be
+ * co-resident (k_dp_tile_p spins on neighbour tiles) are then never chosen */
+void lqrhip_batch_set_shared(LqrHipBatch *b, int shared);
 void lqrhip_batch_destroy(LqrHipBatch *b);
 int lqrhip_batch_sync(LqrHipBatch *b);
 void *lqrhip_batch_stream(LqrHipBatch *b);      /* hipStream_t, for event timing in bench.py */
