@@ -1906,7 +1906,8 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
 #pragma unroll 1
         for (int bb = 0; bb < DPP_HALO / R; bb++) {
             const int yb = y0 + bb * R;
-            if ((bb & (DPP_W - 1)) == q && yb < h) {
+            const bool mine = (bb & (DPP_W - 1)) == q && yb < h;
+            if (mine) {
                 if (yb > 0) {
                     const f32x4 v = s_mp[lane];
                     mp[0] = v[0]; mp[1] = v[1]; mp[2] = v[2]; mp[3] = v[3];
@@ -1965,11 +1966,13 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                         for (int k = 0; k < 4; k++) __hip_atomic_store(dst + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                issue(yb + DPP_W * R);
             }
             // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. every wave's prefetch
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (s_fail) return;                  // uniform: written before the barrier, read by both waves after it
+            // this wave's next batch, issued AFTER the barrier: the ~50 load instructions (~1500 cycles of issue) then
+            // run under the partner's compute instead of in front of it
+            if (mine) issue(yb + DPP_W * R);
         }
     }
     if (UPDATE && threadIdx.x == 0) {
