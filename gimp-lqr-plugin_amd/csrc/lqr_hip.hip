@@ -1408,6 +1408,10 @@ __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs,
 // the back pointer is produced directly as a byte in place ((dx & 0xff) << 8k: two selects of
 // constants), the four are OR-ed, and "same parent as before" is a byte compare of old ^ new.
 // MASK: some of the lane's pixels may lie outside the image (they become +inf).
+// left / right come by DPP wave shifts with bound_ctrl: lane 0's left and lane 63's right neighbour read as 0.  In the
+// halo kernels those two lanes are the outermost halo columns, whose values are allowed to be wrong from the first row
+// of a block on (the error moves inwards one column per row, which is what the halo width pays for), so no register has
+// to be preset with +inf for them; the image's own borders are handled by MASK, not by the shift.
 // ch[k] (UPDATE): the pixel's (m, back pointer) pair changed.
 // ---------------------------------------------------------------------------
 template <bool LR, bool RIG, bool UPDATE, bool MASK>
@@ -1606,22 +1610,21 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
             auto rows = [&](auto guard, auto mask) {
                 constexpr bool GUARD = decltype(guard)::value, MASK = decltype(mask)::value;
                 const bool own = own_lane && x0 < w;
+                // running store offsets (see k_dp_tile_p)
+                unsigned so = (unsigned) y * (unsigned) stride + (unsigned) x0, so4 = so * 4u;
 #pragma unroll
-                for (int r = 0; r < R; r++) {
+                for (int r = 0; r < R; r++, so += (unsigned) stride, so4 += 4u * (unsigned) stride) {
+                    asm volatile("" : "+v"(so), "+v"(so4));
                     if (!GUARD || r < nrows) {
-                        const int yy = y + r;
                         float mc[4];
                         uint32_t lnew = 0;
                         bool ch[4];
-                        const float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[3]), DPP_WAVE_SHR1,
-                                                                                  0xf, 0xf, false));
-                        const float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[0]), DPP_WAVE_SHL1,
-                                                                                   0xf, 0xf, false));
+                        const float left = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[3]), DPP_WAVE_SHR1, 0xf, 0xf, true));
+                        const float right = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[0]), DPP_WAVE_SHL1, 0xf, 0xf, true));
                         dp_row4<LR, RIG, true, MASK>(mp, left, right, q_e[r], q_mo[r], q_lo[r], in, rig_l, rig_r, mc, lnew, ch);
                         if (own) {
-                            const unsigned so = (unsigned) yy * (unsigned) stride + (unsigned) x0;
                             u32x4 tv = {__float_as_uint(mc[0]), __float_as_uint(mc[1]), __float_as_uint(mc[2]), __float_as_uint(mc[3])};
-                            *(GLOBAL_AS u32x4 *) (c.m + so) = tv;
+                            *(GLOBAL_AS u32x4 *) ((gu8 *) c.m + so4) = tv;
                             *(gu32 *) (c.least + so) = lnew;
                         }
 #pragma unroll
@@ -1758,10 +1761,8 @@ __global__ __launch_bounds__(64) void k_dp_tile(const DevCarver *cs, DpK p, int 
 #pragma unroll
                         for (int k = 0; k < 4; k++) mc[k] = (lane_in && x0 + k < w) ? e[k] : INF;     // row 0: m = en
                     } else {
-                        float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[3]), DPP_WAVE_SHR1,
-                                                                            0xf, 0xf, false));
-                        float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[0]), DPP_WAVE_SHL1,
-                                                                             0xf, 0xf, false));
+                        float left = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[3]), DPP_WAVE_SHR1, 0xf, 0xf, true));
+                        float right = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[0]), DPP_WAVE_SHL1, 0xf, 0xf, true));
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
@@ -1867,9 +1868,13 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
     // MASK: the tile reaches over the image's left or right border
     auto batch = [&](int ybase, auto guard, auto mask) {
         constexpr bool GUARD = decltype(guard)::value, MASK = decltype(mask)::value;
+        // store offsets run down the rows in two VGPRs (elements for the byte plane, bytes for m): one v_add each per
+        // row instead of a scalar multiply + two adds; opaque to the compiler so that it keeps them that way
+        unsigned so = (unsigned) ybase * (unsigned) stride + (unsigned) x0, so4 = so * 4u;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
+        for (int r = 0; r < R; r++, so += (unsigned) stride, so4 += 4u * (unsigned) stride) {
             const int y = ybase + r;
+            asm volatile("" : "+v"(so), "+v"(so4));
             if (!GUARD || y < h) {
                 float mc[4];
                 uint32_t lnew = 0;
@@ -1878,17 +1883,14 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
 #pragma unroll
                     for (int k = 0; k < 4; k++) mc[k] = in[k] ? e[k] : INF;     // row 0: m = en
                 } else {
-                    const float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[3]), DPP_WAVE_SHR1,
-                                                                              0xf, 0xf, false));
-                    const float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(mp[0]), DPP_WAVE_SHL1,
-                                                                               0xf, 0xf, false));
+                    const float left = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[3]), DPP_WAVE_SHR1, 0xf, 0xf, true));
+                    const float right = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[0]), DPP_WAVE_SHL1, 0xf, 0xf, true));
                     bool ch[4];
                     dp_row4<LR, RIG, UPDATE, MASK>(mp, left, right, e, q_mo[r], q_lo[r], in, rig_l, rig_r, mc, lnew, ch);
                 }
                 if (own) {
-                    const unsigned so = (unsigned) y * (unsigned) stride + (unsigned) x0;
                     u32x4 t = {__float_as_uint(mc[0]), __float_as_uint(mc[1]), __float_as_uint(mc[2]), __float_as_uint(mc[3])};
-                    *(GLOBAL_AS u32x4 *) (m_out + so) = t;
+                    *(GLOBAL_AS u32x4 *) ((gu8 *) m_out + so4) = t;
                     *(gu32 *) (least_out + so) = lnew;
                 }
 #pragma unroll
