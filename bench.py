@@ -48,6 +48,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# --sub-batches N (opt-in) runs the batch on N HIP streams; each needs a hardware queue of its own and the HIP runtime's
+# default is 4 per process, shared with torch's streams.  The variable must be in the environment before the first HIP
+# call of the process, i.e. before torch is imported; it changes nothing for the default single-stream run.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def parse():
@@ -60,6 +64,9 @@ def parse():
     ap.add_argument("--seams", type=int, default=None)
     ap.add_argument("--kernel-times", action="store_true",
                     help="HIP-event time every kernel of the seam loop (kernels_ms), not only k_carve; costs ~2.5 %% of the step")
+    ap.add_argument("--sub-batches", type=int, default=1,
+                    help="split the batch over this many HIP streams (chain kernels of one under the carve of another): more "
+                         "throughput, but every kernel then shares the chip and the per-launch roofline figure drops")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--switch-freq", type=int, default=2, help="lqr side switch frequency (plug-in: 2, render.c:237)")
@@ -156,6 +163,8 @@ def main():
         raise SystemExit("bench.py: no usable HIP device: %s" % lib.lqrhip_last_error().decode())
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: torch sees no GPU")
+    lib.lqrhip_set_sub_batches.argtypes = [C.c_int]
+    lib.lqrhip_set_sub_batches(args.sub_batches)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -289,7 +298,7 @@ def main():
                        args.workload, nimg, W, H, NW, NH, W - NW, (" + %d horizontal" % (H - NH)) if NH != H else "",
                        args.switch_freq),
                    "images_per_gpu": nimg, "width": W, "height": H, "new_width": NW, "new_height": NH,
-                   "parallelism": "images sharded i mod N, no data-path collective"},
+                   "parallelism": "images sharded i mod N, no data-path collective", "streams_per_gpu": args.sub_batches},
         "roofline": roofline,
         "kernels_ms": {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in kern.items() if v[1]},
         "gather_ms": None if gather_ms is None else round(gather_ms, 2),

@@ -2447,12 +2447,17 @@ extern "C" int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int c
 }
 
 // ---- batch -----------------------------------------------------------------
-static int g_sub_batches = -1, g_carve_wgs_per_cu = -1, g_num_cus = 256;
-extern "C" int lqrhip_sub_batches(int n)
-{
-    if (g_sub_batches < 0) { const char *e = getenv("LQRHIP_SUBBATCHES"); g_sub_batches = e ? atoi(e) : 1; }
-    return n >= 8 ? g_sub_batches : 1;
-}
+// A lock-step group can be split over several HIP streams (sub-batches) that advance seam by seam side by side: a seam
+// round is a latency-bound chain (backtrack, energy update, band update: ~0.7 ms at 4K whatever the batch size, on a
+// few CUs) followed by the bandwidth-bound carve, so one sub-batch's chain runs under another's carve.  Measured at
+// 64 x 4K with 4 streams: +12 % throughput (424k vs 377k Mseams*px/s), but every kernel then shares the chip -- a carve
+// launch of 16 images takes 0.20 ms next to the others' kernels (2.6 TB/s algorithmic) instead of 0.13 ms alone -- and
+// it needs a hardware queue per stream: with the HIP runtime's default of 4 queues per process (GPU_MAX_HW_QUEUES) the
+// streams share queues and the same split is 30 % SLOWER.  So it is opt-in: lqrhip_set_sub_batches (bench.py
+// --sub-batches), default one stream.  DESIGN.md 4.11.
+static int g_sub_batches = 1;
+extern "C" void lqrhip_set_sub_batches(int n) { g_sub_batches = n > 0 ? n : 1; }
+extern "C" int lqrhip_sub_batches(int n) { return n >= 2 * g_sub_batches ? g_sub_batches : 1; }
 
 extern "C" void lqrhip_batch_set_shared(LqrHipBatch *b, int shared) { b->shared = shared != 0; }
 
@@ -2781,10 +2786,7 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         // algorithmic bytes of one carve launch: read + write of one 4-byte
         // plane over the half of each row right of the seam = 8 B * w*h/2 per image
         ProfScope ps("carve", b->stream, 4.0 * (double) w * h * n);
-        if (g_carve_wgs_per_cu < 0) { const char *e = getenv("LQRHIP_CARVE_WGS_PER_CU"); g_carve_wgs_per_cu = e ? atoi(e) : 0; }
-        int gy = (h + 3) / 4;
-        if (g_carve_wgs_per_cu > 0) gy = std::max(1, std::min(gy, g_carve_wgs_per_cu * g_num_cus / (int) n));
-        hipLaunchKernelGGL(k_carve, dim3(n, gy), dim3(256), 0, b->stream, b->d_desc, w, h, stride, p->delta_x, move_dp);
+        hipLaunchKernelGGL(k_carve, dim3(n, (h + 3) / 4), dim3(256), 0, b->stream, b->d_desc, w, h, stride, p->delta_x, move_dp);
     }
     if (wnew <= 1) {            // liblqr's finish_vsmap case: nothing left to update
         HIPCK(hipGetLastError());

@@ -71,8 +71,10 @@ int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int channels, in
                     int x_off, int y_off, int transposed, int is_rigmask, int bias_factor);
 
 /* -- batch ------------------------------------------------------------------ */
-/* into how many device batches (HIP streams) the host should split a lock-step group of n carvers */
+/* into how many device batches (HIP streams) the host should split a lock-step group of n carvers: 1 unless
+ * lqrhip_set_sub_batches asked for more (opt-in: needs a hardware queue per stream, GPU_MAX_HW_QUEUES >= streams + 2) */
 int lqrhip_sub_batches(int n);
+void lqrhip_set_sub_batches(int n);
 LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n);
 /* tell a batch that sibling batches of the same group run concurrently on other streams: kernels whose grid must be
  * co-resident (k_dp_tile_p spins on neighbour tiles) are then never chosen */

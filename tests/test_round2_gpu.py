@@ -260,3 +260,23 @@ def test_both_carve_sides_and_origin(oracle, engine, where):
             assert np.array_equal(ea, eb) and np.array_equal(ma, mb) and np.array_equal(da[1:], db[1:])
         finally:
             engine.lib.lqrhip_set_update_mode(-1)
+
+
+@pytest.mark.parametrize("nsub", [2, 4])
+def test_sub_batches_on_separate_streams(oracle, engine, nsub):
+    """a lock-step group split over several HIP streams (opt-in, bench.py --sub-batches): every image must still come
+    out as the oracle's, whatever the interleaving; persistent (co-residency-dependent) kernels are never chosen for
+    such batches"""
+    engine.lib.lqrhip_set_sub_batches.argtypes = [ctypes.c_int]
+    imgs = [D.photo_like(900, 260, 950 + i) if i % 2 else D.noise(900, 260, 950 + i) for i in range(9)]
+    engine.lib.lqrhip_set_sub_batches(nsub)
+    try:
+        cs = [L.Carver(engine, im).configure() for im in imgs]
+        assert L.resize_batch(engine, cs, 840, 230) == L.LQR_OK           # both directions: transposes and flattens per sub-batch
+    finally:
+        engine.lib.lqrhip_set_sub_batches(1)
+    for im, c in zip(imgs, cs):
+        ref = H.run_case(oracle, im, 840, 230)
+        assert np.array_equal(c.read_image(), ref["image"])
+        assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"])
+        c.destroy()
