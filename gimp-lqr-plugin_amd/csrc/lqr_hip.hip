@@ -1526,19 +1526,23 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
     // full = false: the slot cannot become active in that batch (see the prediction at the issue site);
     // only the row it hands over is needed.  The CU's vector-memory path takes ~16 cycles per 64-lane
     // 16-byte access, so four slots' 3 loads + 2 stores per row (320 cycles) would be the bound.
+    // Addresses as uniform plane base + 32-bit lane offset (global_load ... v_off, s[base]): per row one scalar
+    // multiply and two VALU adds for the three loads.  With 64-bit per-lane addresses the 48 loads of a batch cost
+    // ~2600 cycles of issue (measured), on the SIMD the partner wave is computing on.
     auto issue = [&](int ybase, bool full) {
         const int x0 = B + OWN * slot - R + 4 * lane;
         const unsigned lo_off = (unsigned) min(max(x0, 0), stride - 4);
         if (full) {
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const unsigned ro = (unsigned) min(ybase + r, h - 1) * (unsigned) stride + lo_off;
-                q_e[r] = *(const GLOBAL_AS f32x4 *) (c.en + ro);
-                q_mo[r] = *(const GLOBAL_AS f32x4 *) (c.m + ro);
+                const unsigned row = (unsigned) min(ybase + r, h - 1) * (unsigned) stride;
+                const unsigned ro = row + lo_off, ro4 = (row << 2) + (lo_off << 2);
+                q_e[r] = *(const GLOBAL_AS f32x4 *) ((const gu8 *) c.en + ro4);
+                q_mo[r] = *(const GLOBAL_AS f32x4 *) ((const gu8 *) c.m + ro4);
                 q_lo[r] = *(const gu32 *) (c.least + ro);
             }
         } else {
-            q_mo[R - 1] = *(const GLOBAL_AS f32x4 *) (c.m + (unsigned) min(ybase + R - 1, h - 1) * (unsigned) stride + lo_off);
+            q_mo[R - 1] = *(const GLOBAL_AS f32x4 *) ((const gu8 *) c.m + ((((unsigned) min(ybase + R - 1, h - 1) * (unsigned) stride) + lo_off) << 2));
         }
     };
     // make the compiler wait for this wave's prefetched batch here
@@ -1852,13 +1856,14 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
     constexpr int R = DPP_R;
     f32x4 q_e[R], q_mo[R];
     uint32_t q_lo[R];
-    auto issue = [&](int ybase) {
+    auto issue = [&](int ybase) {      // uniform plane base + 32-bit lane offset, as in k_band_update_tw
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const unsigned ro = (unsigned) min(ybase + r, h - 1) * (unsigned) stride + lo_off;
-            q_e[r] = *(const GLOBAL_AS f32x4 *) (c.en + ro);
+            const unsigned row = (unsigned) min(ybase + r, h - 1) * (unsigned) stride;
+            const unsigned ro = row + lo_off, ro4 = (row << 2) + (lo_off << 2);
+            q_e[r] = *(const GLOBAL_AS f32x4 *) ((const gu8 *) c.en + ro4);
             if (UPDATE) {
-                q_mo[r] = *(const GLOBAL_AS f32x4 *) (c.m + ro);
+                q_mo[r] = *(const GLOBAL_AS f32x4 *) ((const gu8 *) c.m + ro4);
                 q_lo[r] = *(const gu32 *) (c.least + ro);
             }
         }
@@ -3147,19 +3152,13 @@ extern "C" int lqrhip_mem_info(unsigned long long *free_bytes, unsigned long lon
     return 0;
 }
 
-// ---- measured HBM ceiling: plain streaming copy, 16 B per lane, grid-stride, 8 loads in flight per lane
+// ---- measured HBM ceiling: plain streaming copy, 16 B per lane, non-temporal, grid-stride over 8192 workgroups (the
+// form that measured fastest here: 5.0-5.1 TB/s read + write; scripts/dbg/t_unaligned.hip)
 __global__ __launch_bounds__(256) void k_copy16(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t n16)
 {
     const size_t stride = (size_t) gridDim.x * 256;
-    size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
-    for (; i + 7 * stride < n16; i += 8 * stride) {
-        u32x4 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load(src + i + k * stride);
-#pragma unroll
-        for (int k = 0; k < 8; k++) __builtin_nontemporal_store(v[k], dst + i + k * stride);
-    }
-    for (; i < n16; i += stride) dst[i] = src[i];
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load((const GLOBAL_AS u32x4 *) src + i), (GLOBAL_AS u32x4 *) dst + i);
 }
 
 extern "C" int lqrhip_copy_bandwidth(unsigned long long bytes, int iters, double *gbps)
@@ -3173,7 +3172,7 @@ extern "C" int lqrhip_copy_bandwidth(unsigned long long bytes, int iters, double
     hipEvent_t e0, e1;
     HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
     const size_t n16 = bytes / 16;
-    const dim3 grid(256 * 16);
+    const dim3 grid(8192);
     hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, g_stream0, (const u32x4 *) a, (u32x4 *) b, n16);     // warm-up
     HIPCK(hipEventRecord(e0, g_stream0));
     for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, g_stream0, (const u32x4 *) a, (u32x4 *) b, n16);
