@@ -510,21 +510,23 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
 
 // ---------------------------------------------------------------------------
 // k_vpath1: k_vpath for delta_x == 1.  The chase is a chain of H dependent steps on one wave, so what counts
-// is the length of one step.  In k_vpath a step is v_readlane + 7 scalar instructions (find the lane, pull the
-// dword, extract and sign-extend the byte) and ~55 ns.  Here the rows are taken in chunks of 31:
-//   * as before, lane L holds the 4 back-pointer bytes of columns xa + 4L .. +3 of a 256-column window, one
-//     coalesced load per row, loaded THREE chunks ahead (the chunk's start column is then known to within
-//     3 * 31 columns, and it moves at most 31 more inside the chunk: 124 <= 126 columns of margin);
-//   * when a chunk's turn comes its start column xc is known exactly, and the 64 columns xc - 32 .. xc + 31
-//     are spread out one per lane, sign-extended (one ds_bpermute + one v_bfe_i32 per row, all rows
-//     independent: throughput, not latency);
+// is the length of one step and that the back pointers are there when the chase reaches them.  In k_vpath a step
+// is v_readlane + 7 scalar instructions (find the lane, pull the dword, extract and sign-extend the byte), ~55 ns.
+// Here the rows are taken in chunks of 30:
+//   * a 256-column window of back-pointer bytes per row is prefetched THREE chunks ahead (the chunk's start
+//     column is then known to within 3 * 30 columns, and it moves at most 30 more inside the chunk: 120 <= 126
+//     columns of margin).  One load instruction fetches TWO rows (8 bytes per lane, 32 lanes per row): a wave can
+//     have 63 vector-memory operations outstanding, and with one row per load the third chunk ahead did not fit;
+//   * when a chunk's turn comes its start column xc is known exactly: the staged rows go through an LDS scratch
+//     (row-major, 256 bytes per row: exactly what the loads hold lane by lane) and the 64 columns xc - 32 .. xc + 31
+//     come back one per lane, sign-extended (ds_write_b64 x 15, ds_read_i8 x 30, all independent);
 //   * the chase step is then v_readlane (the lane IS the column) + s_add, plus a v_writelane that records the
-//     path: ~3 instructions.
+//     path: ~3 instructions, ~17 ns measured.
 // No load is guarded or predicated (rows above the image re-read row 1 and their steps are discarded).
 // No LEAST_INVALID test: the carve marks a back pointer invalid only next to the seam, inside the interval
 // every form of update_mmap recomputes before the next backtrack, so none survives to this point.
 // ---------------------------------------------------------------------------
-#define VP1_ROWS 31
+#define VP1_ROWS 30
 #define VP1_AHEAD 3
 template <int r>
 __device__ __forceinline__ void vp1_step(const int e, int &o, int &path)
@@ -544,6 +546,7 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, i
     const int org = c.flags[FLAG_ORG];           // read before wave 0 publishes the next one
     __shared__ float s_val[VPATH_THREADS];
     __shared__ int s_idx[VPATH_THREADS];
+    __shared__ __attribute__((aligned(16))) int8_t s_win[VP1_ROWS * 256];     // the current chunk's rows, 256 columns each
     const int tid = threadIdx.x;
 
     // ---- argmin over the last row: leftmost (lr=0) / rightmost (lr=1) of equals
@@ -584,36 +587,40 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, i
     const int lane = tid;
     gi32 *seam = c.seam_x;
     gi32 *logp = c.seam_log + (size_t) log_index * h;
-    constexpr int R = VP1_ROWS, NB = VP1_AHEAD + 1;
-    uint32_t regs[NB][R];                        // ring of packed windows: chunk k lives in regs[k % NB]
+    constexpr int R = VP1_ROWS, NB = VP1_AHEAD + 1, RL = VP1_ROWS / 2;      // RL loads per chunk, two rows each
+    static_assert(VP1_ROWS % 2 == 0 && (VP1_AHEAD + 1) * VP1_ROWS <= 126, "window margin");
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 regs[NB][RL];                          // ring of packed windows: chunk k lives in regs[k % NB]
     int xa[NB];                                  // their base columns
-    auto window_base = [&](int cx) { return (cx - 126) & ~3; };
+    auto window_base = [&](int cx) { return (cx - 126) & ~7; };      // multiple of 8: a lane's 8 columns never straddle column 0
     // Nothing is predicated (a select per load cost more instructions than the chase itself): columns outside
     // the plane are clamped into it -- the path never goes there -- and rows above row 1 re-read row 1; the steps
     // taken on those are discarded (see run_chunk).  Uniform row base + 32-bit lane offset: one VALU per load.
     auto load_chunk = [&](int b, int y_top, int cx) {
         const int base = window_base(cx);
         xa[b] = base;
-        const unsigned voff = (unsigned) min(max(base + 4 * lane, 0), stride - 4);
+        // lanes 0..31: row y_top - 2q, lanes 32..63: row y_top - 2q - 1; 8 columns per lane
+        const unsigned voff = (unsigned) min(max(base + 8 * (lane & 31), 0), stride - 8);
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const unsigned srow = (unsigned) max(y_top - r, 1) * (unsigned) stride;
-            regs[b][r] = *(const gu32 *) (c.least + (srow + voff));
+        for (int q = 0; q < RL; q++) {
+            const unsigned rowa = (unsigned) max(y_top - 2 * q, 1) * (unsigned) stride;
+            const unsigned rowb = (unsigned) max(y_top - 2 * q - 1, 1) * (unsigned) stride;
+            regs[b][q] = *(const GLOBAL_AS u32x2 *) (c.least + ((lane < 32 ? rowa : rowb) + voff));
         }
     };
     // one chunk: spread the 64 columns around the start column out over the lanes, chase, record
     int acc = 0;
     auto run_chunk = [&](int b, int y_top) {
-        const int col = x - 32 + lane;                       // this lane's column
-        const int rel = col - xa[b];                         // 0 .. 255 inside the window
-        const int src = (rel >> 2) << 2;                     // ds_bpermute takes a byte address
-        const int sh = (rel & 3) << 3;
+        const int rel = x - 32 + lane - xa[b];               // this lane's column, 0 .. 255 inside the window
         int e[R];
+        // through LDS: what the loads hold lane by lane IS row-major [row][256 columns]; same wave writes and reads, LDS
+        // operations of a wave execute in order
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int dw = __builtin_amdgcn_ds_bpermute(src, (int) regs[b][r]);
-            e[r] = __builtin_amdgcn_sbfe(dw, sh, 8);
-        }
+        for (int q = 0; q < RL; q++) *(u32x2 *) (s_win + q * 512 + lane * 8) = regs[b][q];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < R; r++) e[r] = s_win[r * 256 + rel];
+        __builtin_amdgcn_wave_barrier();
         int o = 32, path = 0;
         vp1_chase(e, o, path, std::make_integer_sequence<int, R>{});
         path += x - 32;                                      // lane r: column at row y_top - r (before step r)
@@ -2216,8 +2223,6 @@ static int dpp_resident_workgroups(int dev)
     };
     q(k_dp_tile_p<false, false, false>); q(k_dp_tile_p<false, true, false>); q(k_dp_tile_p<true, false, false>); q(k_dp_tile_p<true, true, false>);
     q(k_dp_tile_p<false, false, true>); q(k_dp_tile_p<false, true, true>); q(k_dp_tile_p<true, false, true>); q(k_dp_tile_p<true, true, true>);
-    const char *e = getenv("LQRHIP_DPP_WGS_PER_CU");        // test hook: 0 forces the k_dp_tile path
-    if (e) per_cu = std::min(per_cu, atoi(e) + 1);
     return std::max(0, per_cu - 1) * prop.multiProcessorCount;
 }
 
@@ -2617,7 +2622,6 @@ extern "C" int lqrhip_emap_build(LqrHipBatch *b, const LqrHipDpParams *p, int w,
     return 0;
 }
 
-static int g_dp_tiled = -1;
 
 // E5 as H/32 dependent launches of one wave per 192-column tile (any batch size)
 static int launch_dp_tiled(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
@@ -2700,10 +2704,9 @@ static int launch_dp(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
 {
     LqrHipCarver *c0 = b->cs[0];
     if (!UPDATE) {
-        if (g_dp_tiled < 0) { const char *e = getenv("LQRHIP_DP_TILED"); g_dp_tiled = e ? atoi(e) : 1; }
         bool has_rigmask = false;
         for (auto *c : b->cs) has_rigmask |= (c->rig != nullptr);
-        if (g_dp_tiled && k.delta == 1 && !has_rigmask) return dp_persistent_ok(b, w) ? launch_dp_persistent<false>(b, k, w, h, lr) : launch_dp_tiled(b, k, w, h, lr);
+        if (k.delta == 1 && !has_rigmask) return dp_persistent_ok(b, w) ? launch_dp_persistent<false>(b, k, w, h, lr) : launch_dp_tiled(b, k, w, h, lr);
     }
     int pxt = (w + DP_THREADS - 1) / DP_THREADS;
     size_t lds = (size_t) 2 * ((w + 3) & ~3) * sizeof(float);
@@ -2752,8 +2755,8 @@ static int frozen_catchup(LqrHipBatch *b, int to, int w_at_to, int h)
     return 0;
 }
 
-static int g_use_band = -1;         // LQRHIP_NO_BAND (debug): 1 = full-width updates only (0), 2 = generic band kernel only
-static long long g_tiled_update_px = 12LL * 3840 * 2160;   // batches up to this many pixels use the tiled update (LQRHIP_TILED_UPDATE_PX)
+// batches up to this many pixels use the tiled full-width update (measured break-even with the band kernel: ~15 4K images)
+static const long long g_tiled_update_px = 12LL * 3840 * 2160;
 
 // One seam of a lock-step batch: k_vpath* (pick + backtrack, publishes the side to move) -> k_carve ->
 // k_emap_update -> one form of update_mmap (or the full DP after a side switch), all on the batch's stream.
@@ -2762,13 +2765,6 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
 {
     int rc;
     LqrHipCarver *c0 = b->cs[0];
-    if (g_use_band < 0) {
-        const char *e = getenv("LQRHIP_NO_BAND");
-        g_use_band = (e && atoi(e) == 1) ? 0 : (e && atoi(e) == 2) ? 2 : 1;
-        const char *tu = getenv("LQRHIP_TILED_UPDATE_PX");
-        if (tu) g_tiled_update_px = atoll(tu);
-        if (g_dp_tiled < 0) { const char *dt = getenv("LQRHIP_DP_TILED"); g_dp_tiled = dt ? atoi(dt) : 1; }
-    }
     for (auto *c : b->cs)
         if (log_index >= c->log_cap) return LQRHIP_EARG;
     if ((rc = batch_upload(b))) return rc;
@@ -2799,7 +2795,10 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     }
     {
         ProfScope ps("emap_update", b->stream, 0);
-        if (log_index + 1 - c0->frozen_epoch > FROZEN_LAG_MAX && (rc = frozen_catchup(b, log_index + 1, wnew, h))) return rc;
+        // the energy update walks the seam log back to the frozen frame (O(lag) per sample); compacting the frozen planes
+        // costs a pass over them.  Few images: the walk is on the critical path and the pass is cheap -> short lag
+        const int lag_max = n <= 4 ? FROZEN_LAG_MAX / 4 : FROZEN_LAG_MAX;
+        if (log_index + 1 - c0->frozen_epoch > lag_max && (rc = frozen_catchup(b, log_index + 1, wnew, h))) return rc;
         const int epoch = c0->frozen_epoch;
 #define LAUNCH_EUPD_NT(N, NT) hipLaunchKernelGGL((k_emap_update<N, NT>), dim3((h + EU_ROWS - 1) / EU_ROWS, n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, log_index, epoch)
 #define LAUNCH_EUPD(N) do { if (p->delta_x <= 2) LAUNCH_EUPD_NT(N, 12); else if (p->delta_x <= 8) LAUNCH_EUPD_NT(N, 36); else LAUNCH_EUPD_NT(N, 68); } while (0)
@@ -2815,8 +2814,8 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     }
     // How E9 (update_mmap) runs.  Small batches: the whole chip recomputing every row (tiled full-width keep-rule
     // sweep) beats the one-workgroup-per-image band walk; for large batches its 14 B/px of traffic would not.
-    const bool fast_ok = g_use_band == 1 && p->delta_x == 1 && !has_rigmask;
-    const bool tiled_update = fast_ok && g_dp_tiled != 0 &&
+    const bool fast_ok = p->delta_x == 1 && !has_rigmask;
+    const bool tiled_update = fast_ok &&
                               (g_update_mode < 0 ? (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px : g_update_mode == 1) &&
                               dp_persistent_ok(b, w);
     if (tiled_update) {
@@ -2829,9 +2828,7 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     // the trapezoid-wave band kernel takes rows up to ~4200 px (wider rows: the changes outgrow its 896-column window
     // too often, and an 8-slot build spills registers); beyond that, and in update mode 2, k_band_update_mw
     const bool band_tw = fast_band && g_update_mode != 2 && wnew <= 4200 && (size_t) 2 * h * sizeof(int) <= 64 * 1024;
-    if (!g_use_band) {
-        for (auto *c : b->cs) HIPCK(hipMemsetAsync(c->flags, 0, sizeof(int32_t), b->stream));      // FLAG_OVF_ROW = 0: everything to the sweep
-    } else if (band_tw) {
+    if (band_tw) {
         ProfScope ps("band_update", b->stream, 0);
 #define LAUNCH_TW(LRV, RIGV) hipLaunchKernelGGL((k_band_update_tw<4, LRV, RIGV>), dim3(n), dim3(128 * 4), (size_t) 2 * h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, g_dev_err)
         if (leftright_next) { if (p->use_rigidity) LAUNCH_TW(true, true); else LAUNCH_TW(true, false); }
