@@ -264,7 +264,8 @@ __global__ void k_wk_init(const DevCarver *cs, int w, int h, int stride, int ch)
     float b = 0.0f, r = 0.0f;
     if (x < w) {
         const gu8 *s = c.rgb0 + ((size_t) y * w + x) * ch;
-        for (int k = 0; k < ch; k++) p |= (uint32_t) s[k] << (8 * k);
+        if (ch == 4) p = *(const gu32 *) s;
+        else for (int k = 0; k < ch; k++) p |= (uint32_t) s[k] << (8 * k);
         if (c.bias0) b = c.bias0[(size_t) y * w + x];
         if (c.rig0) r = c.rig0[(size_t) y * w + x];
     }
@@ -2041,6 +2042,23 @@ __global__ __launch_bounds__(256) void k_vs_commit(const DevCarver *cs, int w0, 
     }
 }
 
+// one interleaved pixel of `ch` bytes, base layout: RGBA pixels are dword-aligned (rows start at y * w * 4) and move as
+// one 32-bit access instead of four byte accesses
+__device__ __forceinline__ void px_copy(uint8_t *dst, const uint8_t *src, int ch)
+{
+    if (ch == 4) *(uint32_t *) dst = *(const uint32_t *) src;
+    else for (int k = 0; k < ch; k++) dst[k] = src[k];
+}
+__device__ __forceinline__ void px_avg(uint8_t *dst, const uint8_t *a, const uint8_t *b, int ch)       // (a + b) / 2 per channel, as integers
+{
+    if (ch == 4) {
+        const uint32_t x = *(const uint32_t *) a, y = *(const uint32_t *) b;
+        *(uint32_t *) dst = (x & y) + (((x ^ y) & 0xfefefefeu) >> 1);          // per byte floor((x + y) / 2), no carries across bytes
+    } else {
+        for (int k = 0; k < ch; k++) dst[k] = (uint8_t) (((int) a[k] + (int) b[k]) / 2);
+    }
+}
+
 // E14: one block per row.  dup(c) = the seam was computed in this session.
 __global__ __launch_bounds__(256) void k_inflate(const uint8_t *rgb, const int32_t *vs, const float *bias, const float *rig,
                                                   uint8_t *nrgb, int32_t *nvs, float *nbias, float *nrig, int w0, int w1, int ch,
@@ -2061,14 +2079,13 @@ __global__ __launch_bounds__(256) void k_inflate(const uint8_t *rgb, const int32
             int z = col + rank;
             int left = col > 0 ? col - 1 : col;
             if (dup) {
-                for (int k = 0; k < ch; k++)
-                    nrgb[(ro + z) * ch + k] = (uint8_t) (((int) rgb[(ri + left) * ch + k] + (int) rgb[(ri + col) * ch + k]) / 2);
+                px_avg(nrgb + (ro + z) * ch, rgb + (ri + left) * ch, rgb + (ri + col) * ch, ch);
                 if (nbias) nbias[ro + z] = __fmul_rn(__fadd_rn(bias[ri + left], bias[ri + col]), 0.5f);
                 if (nrig) nrig[ro + z] = __fmul_rn(__fadd_rn(rig[ri + left], rig[ri + col]), 0.5f);
                 if (nvs) nvs[ro + z] = l - v + max_level;
                 z++;
             }
-            for (int k = 0; k < ch; k++) nrgb[(ro + z) * ch + k] = rgb[(ri + col) * ch + k];
+            px_copy(nrgb + (ro + z) * ch, rgb + (ri + col) * ch, ch);
             if (nbias) nbias[ro + z] = bias[ri + col];
             if (nrig) nrig[ro + z] = rig[ri + col];
             if (nvs) nvs[ro + z] = v ? v + l - max_level + 1 : 0;
@@ -2094,7 +2111,7 @@ __global__ __launch_bounds__(256) void k_compact(const uint8_t *rgb, const int32
         int total;
         int rank = carry + block_rank_256(keep, s_wave, total);
         if (keep && rank < w) {
-            if (nrgb) for (int k = 0; k < ch; k++) nrgb[(ro + rank) * ch + k] = rgb[(ri + col) * ch + k];
+            if (nrgb) px_copy(nrgb + (ro + rank) * ch, rgb + (ri + col) * ch, ch);
             if (nbias) nbias[ro + rank] = bias[ri + col];
             if (nrig) nrig[ro + rank] = rig[ri + col];
             if (nvmap) nvmap[ro + rank] = v ? v - depth : 0;
