@@ -12,7 +12,16 @@
  * image.  A single carver is a batch of one.  All work of a batch is enqueued
  * on the batch's HIP stream; only lqrhip_batch_sync and the read-back calls
  * block.  Every function returns 0 on success, LQRHIP_ENOMEM on device OOM and
- * another negative value on any other HIP error; none of them aborts.
+ * another negative value on any other HIP error; none of them aborts, and no kernel
+ * traps: a device-side failure (a persistent grid that was not co-resident) is
+ * recorded in a host-visible word and returned by the next lqrhip_batch_sync /
+ * lqrhip_device_sync as LQRHIP_EHIP.
+ *
+ * Threading: like the plug-in's use of liblqr (GTK main loop / PDB run), the library
+ * is single-threaded by contract -- the allocation cache, the error word and the
+ * profiling records are process globals without locks, and the device is selected
+ * (hipSetDevice) for the thread that first calls in.  No environment variable is read
+ * except LOCAL_RANK.
  */
 #ifndef LQR_HIP_H
 #define LQR_HIP_H
