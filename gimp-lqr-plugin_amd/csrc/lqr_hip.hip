@@ -670,70 +670,79 @@ __device__ __forceinline__ void store_sc1_x4(gu32 *p, u32x4 v) { asm volatile("g
 #define DPP_WAVE_SHL1 0x130
 #define DPP_WAVE_SHR1 0x138
 
-// side 0: new[p] = old[p + 1] for p in [pv, pend); pend = physical end (exclusive) of the row after the carve
-__device__ __forceinline__ void shift_left_u32(gu32 *row, int pv, int pend, int lane)
+// A group = CG chunks of 256 elements of one plane, as loaded, plus the one element beyond the group that
+// its edge lane needs.  All planes of a row are LOADED for a group before any of them is stored: a row wave then has
+// three planes' loads in flight at once instead of three load -> store round trips one after the other (non-temporal:
+// streaming the rows past L2 is worth 6 % of the kernel).  The element that follows (side 0) / precedes (side 1) a
+// lane's four is the neighbouring lane's (DPP); only the edge lane of the group fetches it from memory.
+// Chunks per group.  Measured at 64 x 4K (one box, us per launch): planes one after the other at 8 waves per SIMD 510-518;
+// all planes of a group loaded first with CG = 1 (77 VGPRs, 6 waves) 495, 2 (100, 4) 486, 3 (120, 4) 509, 4 (142 VGPRs,
+// 3 waves per SIMD) 470-485, 6 552; CG = 4 squeezed into 128 VGPRs (11 spilled) 531.  Bytes in flight per wave beat
+// occupancy: a row's mean moved part (a quarter of 3840) fits one group of 1024.
+#define CG 4
+#define CGPX (CG * 256)
+struct G32 { u32x4 a[CG]; uint32_t edge; };     // 4-byte planes: en, m, rigidity mask
+struct G8 { uint32_t a[CG]; uint32_t edge; };   // the back-pointer bytes, 4 px per dword
+
+// ---- side 0: new[p] = old[p + 1] for p in [pv, pend); pend = physical end (exclusive) of the row after the carve.
+// Groups run left to right from `base`.
+__device__ __forceinline__ void ld_left_u32(const gu32 *row, int base, int pend, int lane, G32 &g)
 {
-    // 4 chunks of 256 elements in flight: all loads of a group are issued before its stores (non-temporal:
-    // streaming the rows past L2 is worth 6 % of the kernel).  The element that follows a lane's four is the next
-    // lane's first one (DPP); only lane 63 of the last chunk of a group has to fetch it from memory.
-    for (int base = pv & ~3; base < pend; base += 1024) {
-        u32x4 a[4];
-        uint32_t tail = 0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int x = base + u * 256 + lane * 4;
-            // x <= pend: the group that starts at pend holds the old last element, which the lane before needs
-            a[u] = (x <= pend) ? __builtin_nontemporal_load((const GLOBAL_AS u32x4 *) (row + x)) : (u32x4) {0u, 0u, 0u, 0u};
-        }
-        if (lane == 63 && base + 1024 <= pend) tail = row[base + 1024];
+    for (int u = 0; u < CG; u++) {
+        const int x = base + u * 256 + lane * 4;
+        // x <= pend: the chunk that starts at pend holds the old last element, which the lane before needs
+        g.a[u] = (x <= pend) ? __builtin_nontemporal_load((const GLOBAL_AS u32x4 *) (row + x)) : (u32x4) {0u, 0u, 0u, 0u};
+    }
+    g.edge = (lane == 63 && base + CGPX <= pend) ? row[base + CGPX] : 0u;
+}
+__device__ __forceinline__ void st_left_u32(gu32 *row, int base, int pv, int pend, int lane, const G32 &g)
+{
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int x = base + u * 256 + lane * 4;
-            const uint32_t first_next = (u < 3) ? (uint32_t) __builtin_amdgcn_readlane((int) a[u < 3 ? u + 1 : 3].x, 0) : 0u;
-            const uint32_t lane63 = (u < 3) ? first_next : tail;
-            const uint32_t nx = (uint32_t) __builtin_amdgcn_update_dpp((int) lane63, (int) a[u].x, DPP_WAVE_SHL1, 0xf, 0xf, false);
-            if (x < pend) {
-                u32x4 o;
-                o.x = (x >= pv) ? a[u].y : a[u].x;
-                o.y = (x + 1 >= pv) ? a[u].z : a[u].y;
-                o.z = (x + 2 >= pv) ? a[u].w : a[u].z;
-                o.w = (x + 3 >= pv) ? nx : a[u].w;
-                __builtin_nontemporal_store(o, (GLOBAL_AS u32x4 *) (row + x));
-            }
+    for (int u = 0; u < CG; u++) {
+        const int x = base + u * 256 + lane * 4;
+        const uint32_t first_next = (u < CG - 1) ? (uint32_t) __builtin_amdgcn_readlane((int) g.a[u < CG - 1 ? u + 1 : CG - 1].x, 0) : 0u;
+        const uint32_t lane63 = (u < CG - 1) ? first_next : g.edge;
+        const uint32_t nx = (uint32_t) __builtin_amdgcn_update_dpp((int) lane63, (int) g.a[u].x, DPP_WAVE_SHL1, 0xf, 0xf, false);
+        if (x < pend) {
+            u32x4 o;
+            o.x = (x >= pv) ? g.a[u].y : g.a[u].x;
+            o.y = (x + 1 >= pv) ? g.a[u].z : g.a[u].y;
+            o.z = (x + 2 >= pv) ? g.a[u].w : g.a[u].z;
+            o.w = (x + 3 >= pv) ? nx : g.a[u].w;
+            __builtin_nontemporal_store(o, (GLOBAL_AS u32x4 *) (row + x));
         }
     }
 }
 
-// side 1: new[p] = old[p - 1] for p in (pbeg, pv]; pbeg = the origin before the carve (dead afterwards).
-// Groups run from the seam towards the origin: a group's stores reach one element past its loads on the right,
-// into a group that has been read already.
-__device__ __forceinline__ void shift_right_u32(gu32 *row, int pbeg, int pv, int lane)
+// ---- side 1: new[p] = old[p - 1] for p in (pbeg, pv]; pbeg = the origin before the carve (dead afterwards).
+// Groups [gbase, gbase + CGPX) run from the seam towards the origin: a group's stores reach one element past its loads
+// on the right, into a group that has been read already.
+__device__ __forceinline__ void ld_right_u32(const gu32 *row, int gbase, int pbeg, int pv, int lane, G32 &g)
 {
-    for (int top = (pv | 3) + 1; top > pbeg + 1; top -= 1024) {
-        const int gbase = top - 1024;
-        u32x4 a[4];
-        uint32_t head = 0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int x = gbase + u * 256 + lane * 4;
-            // chunks that hold a source (p in [pbeg, pv - 1]) or a destination; x + 3 >= pbeg >= 0 keeps x >= 0
-            a[u] = (x + 3 >= pbeg && x <= pv) ? __builtin_nontemporal_load((const GLOBAL_AS u32x4 *) (row + x)) : (u32x4) {0u, 0u, 0u, 0u};
-        }
-        if (lane == 0 && gbase - 1 >= pbeg) head = row[gbase - 1];
+    for (int u = 0; u < CG; u++) {
+        const int x = gbase + u * 256 + lane * 4;
+        // chunks that hold a source (p in [pbeg, pv - 1]) or a destination; x + 3 >= pbeg >= 0 keeps x >= 0
+        g.a[u] = (x + 3 >= pbeg && x <= pv) ? __builtin_nontemporal_load((const GLOBAL_AS u32x4 *) (row + x)) : (u32x4) {0u, 0u, 0u, 0u};
+    }
+    g.edge = (lane == 0 && gbase - 1 >= pbeg) ? row[gbase - 1] : 0u;
+}
+__device__ __forceinline__ void st_right_u32(gu32 *row, int gbase, int pbeg, int pv, int lane, const G32 &g)
+{
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int x = gbase + u * 256 + lane * 4;
-            const uint32_t last_prev = (u > 0) ? (uint32_t) __builtin_amdgcn_readlane((int) a[u > 0 ? u - 1 : 0].w, 63) : 0u;
-            const uint32_t lane0 = (u > 0) ? last_prev : head;
-            const uint32_t pw = (uint32_t) __builtin_amdgcn_update_dpp((int) lane0, (int) a[u].w, DPP_WAVE_SHR1, 0xf, 0xf, false);
-            if (x <= pv && x + 3 > pbeg) {
-                u32x4 o;
-                o.x = (x > pbeg && x <= pv) ? pw : a[u].x;
-                o.y = (x + 1 > pbeg && x + 1 <= pv) ? a[u].x : a[u].y;
-                o.z = (x + 2 > pbeg && x + 2 <= pv) ? a[u].y : a[u].z;
-                o.w = (x + 3 > pbeg && x + 3 <= pv) ? a[u].z : a[u].w;
-                __builtin_nontemporal_store(o, (GLOBAL_AS u32x4 *) (row + x));
-            }
+    for (int u = 0; u < CG; u++) {
+        const int x = gbase + u * 256 + lane * 4;
+        const uint32_t last_prev = (u > 0) ? (uint32_t) __builtin_amdgcn_readlane((int) g.a[u > 0 ? u - 1 : 0].w, 63) : 0u;
+        const uint32_t lane0 = (u > 0) ? last_prev : g.edge;
+        const uint32_t pw = (uint32_t) __builtin_amdgcn_update_dpp((int) lane0, (int) g.a[u].w, DPP_WAVE_SHR1, 0xf, 0xf, false);
+        if (x <= pv && x + 3 > pbeg) {
+            u32x4 o;
+            o.x = (x > pbeg && x <= pv) ? pw : g.a[u].x;
+            o.y = (x + 1 > pbeg && x + 1 <= pv) ? g.a[u].x : g.a[u].y;
+            o.z = (x + 2 > pbeg && x + 2 <= pv) ? g.a[u].y : g.a[u].z;
+            o.w = (x + 3 > pbeg && x + 3 <= pv) ? g.a[u].z : g.a[u].w;
+            __builtin_nontemporal_store(o, (GLOBAL_AS u32x4 *) (row + x));
         }
     }
 }
@@ -750,125 +759,135 @@ __device__ __forceinline__ int rebase_dx(int dx, int xx, int xo, int vprev, int 
     return dx;
 }
 
-// Back pointers, side 0.  New frame column xx sits at physical org + xx and takes old column xx + (xx >= v).  Pixels
-// left of the seam whose parent may lie right of the seam of the row above (xx >= vprev - delta) are re-based too.
-__device__ __forceinline__ void shift_left_least(gi8 *row, int org, int v, int vprev, int y, int delta, int wnew, int lane)
+// ---- back pointers, side 0.  New frame column xx sits at physical org + xx and takes old column xx + (xx >= v).
+// Pixels left of the seam whose parent may lie right of the seam of the row above (xx >= start = min(v, vprev - delta))
+// are re-based too; bytes outside [start, wnew) are written back as loaded.
+__device__ __forceinline__ void ld_left_8(const gu32 *row32, int base, int pend, int lane, G8 &g)
 {
-    int start = (y > 0) ? min(v, vprev - delta) : v;
-    if (start < 0) start = 0;
-    gu32 *row32 = (gu32 *) row;
-    const int pstart = org + start, pend = org + wnew;
-    // as shift_left_u32: 4 chunks of 256 px (one dword per lane) in flight, all loads of a group before
-    // its stores; the dword that follows a lane's is the next lane's (DPP)
-    for (int base = pstart & ~3; base < pend; base += 1024) {
-        uint32_t a[4];
-        uint32_t tail = 0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int x = base + u * 256 + lane * 4;
-            a[u] = (x <= pend) ? __builtin_nontemporal_load(row32 + (x >> 2)) : 0u;
-        }
-        if (lane == 63 && base + 1024 <= pend) tail = row32[(base + 1024) >> 2];
+    for (int u = 0; u < CG; u++) {
+        const int x = base + u * 256 + lane * 4;
+        g.a[u] = (x <= pend) ? __builtin_nontemporal_load(row32 + (x >> 2)) : 0u;
+    }
+    g.edge = (lane == 63 && base + CGPX <= pend) ? row32[(base + CGPX) >> 2] : 0u;
+}
+__device__ __forceinline__ void st_left_8(gu32 *row32, int base, int org, int start, int v, int vprev, int y, int wnew, int lane, const G8 &g)
+{
+    const int pend = org + wnew;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int x = base + u * 256 + lane * 4;
-            const uint32_t first_next = (u < 3) ? (uint32_t) __builtin_amdgcn_readlane((int) a[u < 3 ? u + 1 : 3], 0) : 0u;
-            const uint32_t lane63 = (u < 3) ? first_next : tail;
-            const uint32_t nx = (uint32_t) __builtin_amdgcn_update_dpp((int) lane63, (int) a[u], DPP_WAVE_SHL1, 0xf, 0xf, false);
-            if (x < pend) {
-                const uint64_t both = ((uint64_t) nx << 32) | a[u];
-                uint32_t o = 0;
+    for (int u = 0; u < CG; u++) {
+        const int x = base + u * 256 + lane * 4;
+        const uint32_t first_next = (u < CG - 1) ? (uint32_t) __builtin_amdgcn_readlane((int) g.a[u < CG - 1 ? u + 1 : CG - 1], 0) : 0u;
+        const uint32_t lane63 = (u < CG - 1) ? first_next : g.edge;
+        const uint32_t nx = (uint32_t) __builtin_amdgcn_update_dpp((int) lane63, (int) g.a[u], DPP_WAVE_SHL1, 0xf, 0xf, false);
+        if (x < pend) {
+            const uint64_t both = ((uint64_t) nx << 32) | g.a[u];
+            uint32_t o = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int xx = x + j - org;
-                    int dx;
-                    if (xx < start || xx >= wnew) {
-                        dx = (int8_t) (a[u] >> (8 * j));                    // not part of the job: as loaded
-                    } else {
-                        const bool right = (xx >= v);
-                        dx = rebase_dx((int8_t) (both >> (8 * (j + (right ? 1 : 0)))), xx, right ? xx + 1 : xx, vprev, y);
-                    }
-                    o |= (uint32_t) (uint8_t) (int8_t) dx << (8 * j);
+            for (int j = 0; j < 4; j++) {
+                const int xx = x + j - org;
+                int dx;
+                if (xx < start || xx >= wnew) {
+                    dx = (int8_t) (g.a[u] >> (8 * j));                  // not part of the job: as loaded
+                } else {
+                    const bool right = (xx >= v);
+                    dx = rebase_dx((int8_t) (both >> (8 * (j + (right ? 1 : 0)))), xx, right ? xx + 1 : xx, vprev, y);
                 }
-                __builtin_nontemporal_store(o, row32 + (x >> 2));
+                o |= (uint32_t) (uint8_t) (int8_t) dx << (8 * j);
             }
+            __builtin_nontemporal_store(o, row32 + (x >> 2));
         }
     }
 }
 
-// Back pointers, side 1.  New frame column xx sits at physical org + 1 + xx; pixels left of the seam (xx < v) come
-// from physical org + xx (they move), pixels right of it stay where they are and are only re-based while their
-// parent may lie left of (or on) the seam of the row above (xx < vprev + delta).
-__device__ __forceinline__ void shift_right_least(gi8 *row, int org, int v, int vprev, int y, int delta, int wnew, int lane)
+// ---- back pointers, side 1.  New frame column xx sits at physical org + 1 + xx; pixels left of the seam (xx < v) come
+// from physical org + xx (they move), pixels right of it stay where they are and are only re-based while their parent
+// may lie left of (or on) the seam of the row above (xx < end_l = max(v, vprev + delta)).  Destination range
+// [org + 1, org + 1 + end_l).
+__device__ __forceinline__ void ld_right_8(const gu32 *row32, int gbase, int org, int ptop, int lane, G8 &g)
 {
-    const int end_l = (y > 0) ? min(wnew, max(v, vprev + delta)) : min(wnew, v);
-    if (end_l <= 0) return;
-    gu32 *row32 = (gu32 *) row;
-    const int pfirst = org + 1, ptop = org + 1 + end_l;       // destination range [pfirst, ptop)
-    for (int top = (ptop + 3) & ~3; top > pfirst; top -= 1024) {
-        const int gbase = top - 1024;
-        uint32_t a[4];
-        uint32_t head = 0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int x = gbase + u * 256 + lane * 4;
-            a[u] = (x + 3 >= org && x < ptop) ? __builtin_nontemporal_load(row32 + (x >> 2)) : 0u;      // x + 3 >= org >= 0 keeps x >= 0
-        }
-        if (lane == 0 && gbase - 1 >= org) head = row32[(gbase - 4) >> 2];
+    for (int u = 0; u < CG; u++) {
+        const int x = gbase + u * 256 + lane * 4;
+        g.a[u] = (x + 3 >= org && x < ptop) ? __builtin_nontemporal_load(row32 + (x >> 2)) : 0u;      // x + 3 >= org >= 0 keeps x >= 0
+    }
+    g.edge = (lane == 0 && gbase - 1 >= org) ? row32[(gbase - 4) >> 2] : 0u;
+}
+__device__ __forceinline__ void st_right_8(gu32 *row32, int gbase, int org, int end_l, int v, int vprev, int y, int lane, const G8 &g)
+{
+    const int pfirst = org + 1, ptop = org + 1 + end_l;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int x = gbase + u * 256 + lane * 4;
-            const uint32_t last_prev = (u > 0) ? (uint32_t) __builtin_amdgcn_readlane((int) a[u > 0 ? u - 1 : 0], 63) : 0u;
-            const uint32_t lane0 = (u > 0) ? last_prev : head;
-            const uint32_t pd = (uint32_t) __builtin_amdgcn_update_dpp((int) lane0, (int) a[u], DPP_WAVE_SHR1, 0xf, 0xf, false);
-            if (x < ptop && x + 3 >= pfirst) {
-                const uint64_t both = ((uint64_t) a[u] << 8) | (pd >> 24);      // byte k = physical x - 1 + k
-                uint32_t o = 0;
+    for (int u = 0; u < CG; u++) {
+        const int x = gbase + u * 256 + lane * 4;
+        const uint32_t last_prev = (u > 0) ? (uint32_t) __builtin_amdgcn_readlane((int) g.a[u > 0 ? u - 1 : 0], 63) : 0u;
+        const uint32_t lane0 = (u > 0) ? last_prev : g.edge;
+        const uint32_t pd = (uint32_t) __builtin_amdgcn_update_dpp((int) lane0, (int) g.a[u], DPP_WAVE_SHR1, 0xf, 0xf, false);
+        if (x < ptop && x + 3 >= pfirst) {
+            const uint64_t both = ((uint64_t) g.a[u] << 8) | (pd >> 24);      // byte k = physical x - 1 + k
+            uint32_t o = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int xx = x + j - pfirst;
-                    int dx;
-                    if (xx < 0 || xx >= end_l) {
-                        dx = (int8_t) (a[u] >> (8 * j));                    // not part of the job: as loaded
-                    } else {
-                        const bool right = (xx >= v);
-                        dx = rebase_dx((int8_t) (both >> (8 * (j + (right ? 1 : 0)))), xx, right ? xx + 1 : xx, vprev, y);
-                    }
-                    o |= (uint32_t) (uint8_t) (int8_t) dx << (8 * j);
+            for (int j = 0; j < 4; j++) {
+                const int xx = x + j - pfirst;
+                int dx;
+                if (xx < 0 || xx >= end_l) {
+                    dx = (int8_t) (g.a[u] >> (8 * j));                  // not part of the job: as loaded
+                } else {
+                    const bool right = (xx >= v);
+                    dx = rebase_dx((int8_t) (both >> (8 * (j + (right ? 1 : 0)))), xx, right ? xx + 1 : xx, vprev, y);
                 }
-                __builtin_nontemporal_store(o, row32 + (x >> 2));
+                o |= (uint32_t) (uint8_t) (int8_t) dx << (8 * j);
             }
+            __builtin_nontemporal_store(o, row32 + (x >> 2));
         }
     }
 }
 
 __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h, int stride, int delta, int move_dp)
 {
-    // blockIdx.x = image (fastest): workgroups are dispatched row-block by row-block across ALL images
-    const GCarver c = gview_phys(cs[blockIdx.x]);
+    // blockIdx.x = row block (fastest): consecutive workgroups take consecutive rows of one image (2.5 % faster than
+    // image-fastest, which round 1 used so that a concurrent band update could follow all images' top rows)
+    const GCarver c = gview_phys(cs[blockIdx.y]);
     const int org = c.flags[FLAG_ORG_PREV], side = c.flags[FLAG_SIDE];      // published by k_vpath* for this seam
     const int lane = threadIdx.x & 63;
     const int wnew = w - 1;
-    for (int y = blockIdx.y * 4 + (threadIdx.x >> 6); y < h; y += gridDim.y * 4) {
+    for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < h; y += gridDim.x * 4) {
         const int v = c.seam_x[y];
         const size_t ro = (size_t) y * stride;
         const int vprev = y > 0 ? c.seam_x[y - 1] : 0;
+        gu32 *en = (gu32 *) (c.en + ro), *mm = (gu32 *) (c.m + ro), *l32 = (gu32 *) (c.least + ro);
+        gu32 *rg = c.rig ? (gu32 *) (c.rig + ro) : (gu32 *) nullptr;
         // pix and bias are NOT moved: they stay in the frame of `frozen epoch` and the energy
         // update maps current coordinates back through the seam log (k_emap_update)
         if (side == 0) {
-            shift_left_u32((gu32 *) (c.en + ro), org + v, org + wnew, lane);
-            if (c.rig) shift_left_u32((gu32 *) (c.rig + ro), org + v, org + wnew, lane);
-            if (move_dp) {
-                shift_left_u32((gu32 *) (c.m + ro), org + v, org + wnew, lane);
-                shift_left_least(c.least + ro, org, v, vprev, y, delta, wnew, lane);
+            const int pv = org + v, pend = org + wnew;
+            int start = (y > 0) ? min(v, vprev - delta) : v;       // where the back pointers' job starts (<= v)
+            if (start < 0) start = 0;
+            for (int base = (org + (move_dp ? start : v)) & ~3; base < pend; base += CGPX) {
+                G32 E, M;
+                G8 L;
+                ld_left_u32(en, base, pend, lane, E);
+                if (move_dp) { ld_left_u32(mm, base, pend, lane, M); ld_left_8(l32, base, pend, lane, L); }
+                st_left_u32(en, base, pv, pend, lane, E);
+                if (move_dp) { st_left_u32(mm, base, pv, pend, lane, M); st_left_8(l32, base, org, start, v, vprev, y, wnew, lane, L); }
             }
+            if (rg)
+                for (int base = pv & ~3; base < pend; base += CGPX) { G32 R; ld_left_u32(rg, base, pend, lane, R); st_left_u32(rg, base, pv, pend, lane, R); }
         } else {
-            shift_right_u32((gu32 *) (c.en + ro), org, org + v, lane);
-            if (c.rig) shift_right_u32((gu32 *) (c.rig + ro), org, org + v, lane);
-            if (move_dp) {
-                shift_right_u32((gu32 *) (c.m + ro), org, org + v, lane);
-                shift_right_least(c.least + ro, org, v, vprev, y, delta, wnew, lane);
+            const int pv = org + v;
+            const int end_l = (y > 0) ? min(wnew, max(v, vprev + delta)) : min(wnew, v);      // back pointers' job: new columns [0, end_l)
+            const int ptop = org + 1 + max(end_l, 0);
+            const int top_u = (pv | 3) + 1;
+            for (int top = move_dp ? max(top_u, (ptop + 3) & ~3) : top_u; top > org + 1; top -= CGPX) {
+                const int gbase = top - CGPX;
+                G32 E, M;
+                G8 L;
+                ld_right_u32(en, gbase, org, pv, lane, E);
+                if (move_dp) { ld_right_u32(mm, gbase, org, pv, lane, M); ld_right_8(l32, gbase, org, ptop, lane, L); }
+                st_right_u32(en, gbase, org, pv, lane, E);
+                if (move_dp) { st_right_u32(mm, gbase, org, pv, lane, M); st_right_8(l32, gbase, org, max(end_l, 0), v, vprev, y, lane, L); }
             }
+            if (rg)
+                for (int top = top_u; top > org + 1; top -= CGPX) { G32 R; ld_right_u32(rg, top - CGPX, org, pv, lane, R); st_right_u32(rg, top - CGPX, org, pv, lane, R); }
         }
     }
 }
@@ -2804,7 +2823,7 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
         // algorithmic bytes of one carve launch: read + write of one 4-byte
         // plane over the half of each row right of the seam = 8 B * w*h/2 per image
         ProfScope ps("carve", b->stream, 4.0 * (double) w * h * n);
-        hipLaunchKernelGGL(k_carve, dim3(n, (h + 3) / 4), dim3(256), 0, b->stream, b->d_desc, w, h, stride, p->delta_x, move_dp);
+        hipLaunchKernelGGL(k_carve, dim3((h + 3) / 4, n), dim3(256), 0, b->stream, b->d_desc, w, h, stride, p->delta_x, move_dp);
     }
     if (wnew <= 1) {            // liblqr's finish_vsmap case: nothing left to update
         HIPCK(hipGetLastError());
