@@ -3185,13 +3185,13 @@ extern "C" int lqrhip_mem_info(unsigned long long *free_bytes, unsigned long lon
     return 0;
 }
 
-// ---- measured HBM ceiling: plain streaming copy, 16 B per lane, non-temporal, grid-stride over 8192 workgroups (the
-// form that measured fastest here: 5.0-5.1 TB/s read + write; scripts/dbg/t_unaligned.hip)
+// ---- measured HBM ceiling: streaming copy, ONE 16-byte element per thread, non-temporal -- the form that measured
+// fastest on this device (6.5 TB/s read + write at 2 GiB; grid-stride loops with 1-8 loads in flight per thread and
+// 1k-64k workgroups: 4.4-5.8 TB/s; scripts/dbg/t_copy.hip)
 __global__ __launch_bounds__(256) void k_copy16(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t n16)
 {
-    const size_t stride = (size_t) gridDim.x * 256;
-    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
-        __builtin_nontemporal_store(__builtin_nontemporal_load((const GLOBAL_AS u32x4 *) src + i), (GLOBAL_AS u32x4 *) dst + i);
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load((const GLOBAL_AS u32x4 *) src + i), (GLOBAL_AS u32x4 *) dst + i);
 }
 
 extern "C" int lqrhip_copy_bandwidth(unsigned long long bytes, int iters, double *gbps)
@@ -3205,7 +3205,7 @@ extern "C" int lqrhip_copy_bandwidth(unsigned long long bytes, int iters, double
     hipEvent_t e0, e1;
     HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
     const size_t n16 = bytes / 16;
-    const dim3 grid(8192);
+    const dim3 grid((unsigned) ((n16 + 255) / 256));
     hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, g_stream0, (const u32x4 *) a, (u32x4 *) b, n16);     // warm-up
     HIPCK(hipEventRecord(e0, g_stream0));
     for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, g_stream0, (const u32x4 *) a, (u32x4 *) b, n16);
