@@ -42,6 +42,11 @@ def cases():
     # (spec delta 6)
     c["null_energy_masks_276x80"] = (D.noise(276, 80, 790234955, channels=1), 260, 80,
                                      dict(pres=D.ellipse_mask(276, 80), disc=D.band_mask(276, 80, 55, 92), nrg_func=L.LQR_EF_NULL))
+    # update_mmap's keep rule exactly at its boundary, |m_old - m_new| == 1e-5f (tests/tolerance_case.py; DESIGN.md
+    # section 2, spec delta 4): the stale value is kept, seam 2 runs through it
+    import tolerance_case as T
+    timg, tmask = T.build()
+    c["tolerance_boundary_2000x3"] = (timg, T.W - 2, T.H, dict(pres=tmask, pres_coeff=T.FACTOR, nrg_func=L.LQR_EF_NULL, switch_freq=0))
     return c
 
 
