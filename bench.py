@@ -118,14 +118,19 @@ def make_images(n, w, h, seed, device):
     return out_all
 
 
-def self_spawn(args):
-    """--gpus N without a launcher: become N ranks under torch.distributed.run (one per GPU)"""
+def spawn_command(gpus, argv):
+    """the launcher line the driver uses for N > 1: one rank per GPU of one node, rendezvous on 127.0.0.1"""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_spawn(args):
+    """--gpus N without a launcher: become N ranks under torch.distributed.run (one per GPU)"""
+    cmd = spawn_command(args.gpus, sys.argv[1:])
     os.execvp(cmd[0], cmd)
 
 

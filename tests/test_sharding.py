@@ -78,3 +78,18 @@ def test_two_rank_batch_equals_single_process():
         assert c.resize(32, 24) == L.LQR_OK
         assert np.array_equal(c.read_image(), full[i])
         c.destroy()
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run with N ranks
+    (round 1's bench parsed --gpus and ignored it); under the driver's launcher RANK is set and nothing is spawned"""
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.spawn_command(4, ["--gpus", "4", "--steps", "2"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'if "RANK" not in os.environ and args.gpus > 1:' in src and "self_spawn(args)" in src
