@@ -12,20 +12,22 @@
 // keeps two representations:
 //   * base layout  (w0 x h0): rgb0 u8*ch, vs i32, bias0/rig0 f32 -- the
 //     multi-size image; touched only by the one-off passes;
-//   * working planes (row stride S, h rows): pix u32 (packed channels), en f32,
-//     m f32, least i8 (back-pointer as dx), optional bias/rig f32 -- physically
-//     COMPACTED: carving a seam shifts the right part of every row left by one.
+//   * carved planes (row stride S, h rows): en f32, m f32, least i8 (back pointer
+//     as dx), optional rig f32 -- physically COMPACTED: carving a seam moves the
+//     shorter side of it by one, and the image's origin with it (FLAG_ORG);
+//     pix u32 (packed channels) and bias f32 stay frozen in an older frame.
 // All floating point is done with explicitly rounded operations (no FMA
 // contraction, IEEE division and sqrt) so that results are bit-identical to the
 // C arithmetic of the CPU path.  No MFMA: this is stencil + scan + shift work
 // bounded by HBM bandwidth and by the H-step dependency chains.
 //
-// Order of this file: descriptors; energy kernels; generic DP sweep (k_dp_sweep) and backtrack
-// (k_vpath, k_vpath1); carve (k_carve); energy update (k_emap_update, k_frozen_catchup); the
-// update_mmap kernels -- generic band (k_band_update), multi-wave band (k_band_update_mw), the
-// shared DP row (dp_row4), trapezoid-wave band (k_band_update_tw), tiled sweeps (k_dp_tile,
-// k_dp_tile_p); visibility map / inflate / compaction / transpose; then the host side of the
-// shim (allocation cache, batches, lqrhip_seam_step's per-seam sequence, read-out).
+// Order of this file: descriptors and the origin-advanced plane view; energy kernels; generic DP sweep
+// (k_dp_sweep) and backtrack (k_vpath, k_vpath1, which also pick the side the carve moves); carve
+// (k_carve); energy update (k_emap_update, k_frozen_catchup); the update_mmap kernels -- generic band
+// (k_band_update), multi-wave band (k_band_update_mw), the shared DP row (dp_row4), trapezoid-wave band
+// (k_band_update_tw), tiled sweeps (k_dp_tile, k_dp_tile_p); visibility map / inflate / compaction /
+// transpose; then the host side of the shim (allocation cache, batches, lqrhip_seam_step's per-seam
+// sequence, read-out, reset from device memory, copy ceiling, seam-map colour ramp).
 #include <hip/hip_runtime.h>
 #include <utility>
 #include <type_traits>
@@ -2601,8 +2603,8 @@ struct ProfScope {
 
 extern "C" void lqrhip_prof_enable(int on) { g_prof = on; }
 static int g_update_mode = -1;
-// -1: by batch size (LQRHIP_TILED_UPDATE_PX); 0: band kernel (k_band_update_tw); 1: tiled full-width update whenever its
-// grid fits; 2: the older band kernel (k_band_update_mw, overlapped with the carve for large batches)
+// -1: by batch size (g_tiled_update_px); 0: band kernel (k_band_update_tw); 1: tiled full-width update whenever its
+// grid fits; 2: the per-row-barrier band kernel (k_band_update_mw)
 extern "C" void lqrhip_set_update_mode(int mode) { g_update_mode = mode; }
 static int g_dpp_limit_override = -1;
 // -1: the occupancy-derived bound (dpp_resident_workgroups); >= 0: at most that many workgroups for the persistent
