@@ -1479,6 +1479,50 @@ __device__ __forceinline__ void dp_row4(const float (&mp)[4], const float left, 
     }
 }
 
+// dp_row4's arithmetic for PX (2 or 4) consecutive pixels per lane; lo / lnew hold PX back-pointer bytes.  With 2 pixels
+// per lane a row is ~33 instructions per wave instead of ~58, and twice as many waves cover the columns.
+template <int PX, bool LR, bool RIG, bool UPDATE, bool MASK>
+__device__ __forceinline__ void dp_row(const float (&mp)[PX], const float left, const float right, const float (&e)[PX], const float (&mo)[PX],
+                                       const uint32_t lo, const bool (&in)[PX], const float rig_l, const float rig_r, float (&mc)[PX],
+                                       uint32_t &lnew, bool (&ch)[PX])
+{
+    const float INF = __int_as_float(0x7f800000);
+    float nm[PX];
+    uint32_t sel[PX];
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+        float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
+        const float cc = mp[k];
+        float rr = (k == PX - 1) ? right : mp[k < PX - 1 ? k + 1 : 0];
+        if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
+        const float best = fminf(fminf(l, cc), rr);
+        const uint32_t minus = 0xffu << (8 * k), plus = 0x01u << (8 * k);
+        if (LR) { sel[k] = (cc == best) ? 0u : minus; sel[k] = (rr == best) ? plus : sel[k]; }
+        else { sel[k] = (cc == best) ? 0u : plus; sel[k] = (l == best) ? minus : sel[k]; }
+        nm[k] = __fadd_rn(e[k], best);
+    }
+    lnew = sel[0];
+#pragma unroll
+    for (int k = 1; k < PX; k++) lnew |= sel[k];
+    const uint32_t diff = lo ^ lnew;
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+        float v = nm[k];
+        if (UPDATE) {
+            // keep the stale value iff same parent and (double) fabsf(d) < 1e-5, i.e. fabsf(d) <= 1e-5f
+            float d = fabsf(__fsub_rn(mo[k], v));
+            d = ((diff >> (8 * k)) & 0xffu) ? INF : d;
+            ch[k] = d > 1e-5f;
+            v = ch[k] ? v : mo[k];
+        }
+        mc[k] = (!MASK || in[k]) ? v : INF;
+    }
+}
+// PX floats / PX back-pointer bytes of one lane, as one load or store
+template <int PX> struct LaneVec;
+template <> struct LaneVec<2> { typedef float F __attribute__((ext_vector_type(2))); typedef uint16_t L; };
+template <> struct LaneVec<4> { typedef f32x4 F; typedef uint32_t L; };
+
 // ---------------------------------------------------------------------------
 // E9 update_mmap, band form, "trapezoid waves" (delta_x == 1, no rigidity mask).
 //
@@ -1844,19 +1888,27 @@ __global__ __launch_bounds__(64) void k_dp_tile(const DevCarver *cs, DpK p, int 
 // in-place update would let a tile read a neighbour's half-updated (m, least) pair); the host
 // tile that finishes last swaps the plane pointers in the device descriptor.
 // ---------------------------------------------------------------------------
-constexpr int DPP_HALO = 64;                    // halo columns on each side = rows per block
-constexpr int DPP_OWN = 256 - 2 * DPP_HALO;     // columns a tile owns
+// PX pixels per lane (4, or 2 when the device has room for twice the tiles: half the instructions per wave and row):
+// a tile is 64 * PX columns of which the 16 outer lanes on each side are halo
+constexpr int dpp_halo(int px) { return 16 * px; }              // halo columns on each side = rows per block
+constexpr int dpp_own(int px) { return 64 * px - 2 * dpp_halo(px); }     // columns a tile owns
+constexpr int dpp_ex_tile(int px) { return 2 * 2 * dpp_halo(px); }       // granules a tile publishes: [block parity][side: 0 to the left, 1 to the right][column]
 constexpr int DPP_R = 16;                       // rows per batch
 constexpr int DPP_W = 2;                        // waves taking turns
-constexpr int DPP_EX_TILE = 2 * 2 * DPP_HALO;   // granules a tile publishes: [block parity][side: 0 to the left, 1 to the right][column]
-static_assert(DPP_HALO % (DPP_R * DPP_W) == 0, "a block is a whole number of rounds");
+static_assert(dpp_halo(2) % (DPP_R * DPP_W) == 0 && dpp_halo(4) % (DPP_R * DPP_W) == 0, "a block is a whole number of rounds");
 // co-residency bound for the spin waits, set from the occupancy query in lqrhip_init (dpp_resident_workgroups)
 static int g_dpp_max_wgs = 0;
 
-template <bool LR, bool RIG, bool UPDATE>
+
+template <int PX, bool LR, bool RIG, bool UPDATE>
 __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err)
 {
-    __shared__ f32x4 s_mp[64];                   // the row above the next batch, handed from wave to wave
+    typedef typename LaneVec<PX>::F FV;
+    typedef typename LaneVec<PX>::L LV;
+    typedef GLOBAL_AS FV GFV;
+    typedef GLOBAL_AS LV GLV;
+    constexpr int HALO = dpp_halo(PX), OWN = dpp_own(PX), EX_TILE = dpp_ex_tile(PX), TILE = 64 * PX, HL = 16;      // HL: halo lanes per side
+    __shared__ FV s_mp[64];                      // the row above the next batch, handed from wave to wave
     __shared__ int s_fail;                       // a neighbour never showed up: both waves leave at the next barrier
     if (threadIdx.x == 0) s_fail = 0;
     __syncthreads();
@@ -1864,40 +1916,42 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
     gf32 *m_out = UPDATE ? c.m2 : c.m;
     gi8 *least_out = UPDATE ? c.least2 : c.least;
     const int ntiles = gridDim.x, tile = blockIdx.x;
-    // exchange area of this image: per tile DPP_EX_TILE granules ({m bits, tag}, 8 bytes, one store each), then one
+    // exchange area of this image: per tile EX_TILE granules ({m bits, tag}, 8 bytes, one store each), then one
     // word that counts finished tiles
     typedef GLOBAL_AS unsigned long long gu64;
-    gu64 *ex_img = (gu64 *) exch + (size_t) blockIdx.y * ((size_t) ntiles * DPP_EX_TILE + 8);
-    gi32 *done_ctr = (gi32 *) (ex_img + (size_t) ntiles * DPP_EX_TILE);
+    gu64 *ex_img = (gu64 *) exch + (size_t) blockIdx.y * ((size_t) ntiles * EX_TILE + 8);
+    gi32 *done_ctr = (gi32 *) (ex_img + (size_t) ntiles * EX_TILE);
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float INF = __int_as_float(0x7f800000);
     const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
-    const int x0 = tile * DPP_OWN - DPP_HALO + 4 * lane;    // first pixel of this lane (may be < 0 or >= w)
-    const bool own_lane = lane >= DPP_HALO / 4 && lane < 64 - DPP_HALO / 4;
+    const int x0 = tile * OWN - HALO + PX * lane;           // first pixel of this lane (may be < 0 or >= w)
+    const bool own_lane = lane >= HL && lane < 64 - HL;
     const bool own = own_lane && x0 < w;
-    const unsigned lo_off = (unsigned) min(max(x0, 0), stride - 4);
+    const unsigned lo_off = (unsigned) min(max(x0, 0), stride - PX);
     const bool lane_in = (x0 >= 0);
-    bool in[4];
+    bool in[PX];
 #pragma unroll
-    for (int k = 0; k < 4; k++) in[k] = lane_in && x0 + k < w;
+    for (int k = 0; k < PX; k++) in[k] = lane_in && x0 + k < w;
 
     constexpr int R = DPP_R;
-    f32x4 q_e[R], q_mo[R];
-    uint32_t q_lo[R];
+    FV q_e[R], q_mo[R];
+    LV q_lo[R];
     auto issue = [&](int ybase) {      // uniform plane base + 32-bit lane offset, as in k_band_update_tw
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const unsigned row = (unsigned) min(ybase + r, h - 1) * (unsigned) stride;
             const unsigned ro = row + lo_off, ro4 = (row << 2) + (lo_off << 2);
-            q_e[r] = *(const GLOBAL_AS f32x4 *) ((const gu8 *) c.en + ro4);
+            q_e[r] = *(const GFV *) ((const gu8 *) c.en + ro4);
             if (UPDATE) {
-                q_mo[r] = *(const GLOBAL_AS f32x4 *) ((const gu8 *) c.m + ro4);
-                q_lo[r] = *(const gu32 *) (c.least + ro);
+                q_mo[r] = *(const GFV *) ((const gu8 *) c.m + ro4);
+                q_lo[r] = *(const GLV *) (c.least + ro);
             }
         }
     };
-    float mp[4] = {INF, INF, INF, INF};
+    float mp[PX];
+#pragma unroll
+    for (int k = 0; k < PX; k++) mp[k] = INF;
     // GUARD: the batch may contain row 0 or rows past the image (first and last batch of a sweep);
     // MASK: the tile reaches over the image's left or right border
     auto batch = [&](int ybase, auto guard, auto mask) {
@@ -1910,43 +1964,47 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
             const int y = ybase + r;
             asm volatile("" : "+v"(so), "+v"(so4));
             if (!GUARD || y < h) {
-                float mc[4];
+                float mc[PX], e[PX], mo[PX];
                 uint32_t lnew = 0;
-                const f32x4 e = q_e[r];
+#pragma unroll
+                for (int k = 0; k < PX; k++) { e[k] = q_e[r][k]; mo[k] = UPDATE ? q_mo[r][k] : 0.0f; }
                 if (GUARD && y == 0) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) mc[k] = in[k] ? e[k] : INF;     // row 0: m = en
+                    for (int k = 0; k < PX; k++) mc[k] = in[k] ? e[k] : INF;     // row 0: m = en
                 } else {
-                    const float left = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[3]), DPP_WAVE_SHR1, 0xf, 0xf, true));
+                    const float left = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1]), DPP_WAVE_SHR1, 0xf, 0xf, true));
                     const float right = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[0]), DPP_WAVE_SHL1, 0xf, 0xf, true));
-                    bool ch[4];
-                    dp_row4<LR, RIG, UPDATE, MASK>(mp, left, right, e, q_mo[r], q_lo[r], in, rig_l, rig_r, mc, lnew, ch);
+                    bool ch[PX];
+                    dp_row<PX, LR, RIG, UPDATE, MASK>(mp, left, right, e, mo, UPDATE ? (uint32_t) q_lo[r] : 0u, in, rig_l, rig_r, mc, lnew, ch);
                 }
                 if (own) {
-                    u32x4 t = {__float_as_uint(mc[0]), __float_as_uint(mc[1]), __float_as_uint(mc[2]), __float_as_uint(mc[3])};
-                    *(GLOBAL_AS u32x4 *) ((gu8 *) m_out + so4) = t;
-                    *(gu32 *) (least_out + so) = lnew;
+                    FV t;
+#pragma unroll
+                    for (int k = 0; k < PX; k++) t[k] = mc[k];
+                    *(GFV *) ((gu8 *) m_out + so4) = t;
+                    *(GLV *) (least_out + so) = (LV) lnew;
                 }
 #pragma unroll
-                for (int k = 0; k < 4; k++) mp[k] = mc[k];
+                for (int k = 0; k < PX; k++) mp[k] = mc[k];
             }
         }
     };
-    const bool interior = (x0 - 4 * lane >= 0) && (x0 - 4 * lane + 256 <= w);      // uniform: the whole tile window is inside the image
+    const bool interior = (x0 - PX * lane >= 0) && (x0 - PX * lane + TILE <= w);      // uniform: the whole tile window is inside the image
 
-    const int nblk = (h + DPP_HALO - 1) / DPP_HALO;
+    const int nblk = (h + HALO - 1) / HALO;
     issue(q * R);
     for (int j = 0; j < nblk; j++) {
-        const int y0 = j * DPP_HALO;
-        const int ylast = min(y0 + DPP_HALO, h) - 1;
+        const int y0 = j * HALO;
+        const int ylast = min(y0 + HALO, h) - 1;
 #pragma unroll 1
-        for (int bb = 0; bb < DPP_HALO / R; bb++) {
+        for (int bb = 0; bb < HALO / R; bb++) {
             const int yb = y0 + bb * R;
             const bool mine = (bb & (DPP_W - 1)) == q && yb < h;
             if (mine) {
                 if (yb > 0) {
-                    const f32x4 v = s_mp[lane];
-                    mp[0] = v[0]; mp[1] = v[1]; mp[2] = v[2]; mp[3] = v[3];
+                    const FV v = s_mp[lane];
+#pragma unroll
+                    for (int k = 0; k < PX; k++) mp[k] = v[k];
                 }
                 if (bb == 0 && j > 0) {
                     // Halo columns of the row above the block: the tile's own values there are contaminated from the
@@ -1959,20 +2017,23 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     // host sizes it from the occupancy query, but the GPU may be shared): record the failure in the
                     // host-visible error word and stop waiting -- every other tile sees the word in its own spin loop
                     // and leaves too, the host returns LQR_ERROR at its next synchronisation.  Nothing traps.
-                    const bool need = !own_lane && (in[0] || in[1] || in[2] || in[3]);
+                    bool any_in = false;
+#pragma unroll
+                    for (int k = 0; k < PX; k++) any_in |= in[k];
+                    const bool need = !own_lane && any_in;
                     const int nb = (lane < 32) ? tile - 1 : tile + 1;                     // left halo <- left neighbour's right-going granules
-                    const int col = !need ? 0 : (lane < 32) ? 4 * lane : 4 * (lane - 64 + DPP_HALO / 4);        // lanes that need nothing poll a dummy
-                    gu64 *src = ex_img + (size_t) (need ? nb : tile) * DPP_EX_TILE + (size_t) (((j - 1) & 1) * 2 + (lane < 32 ? 1 : 0)) * DPP_HALO + col;
+                    const int col = !need ? 0 : (lane < 32) ? PX * lane : PX * (lane - 64 + HL);        // lanes that need nothing poll a dummy
+                    gu64 *src = ex_img + (size_t) (need ? nb : tile) * EX_TILE + (size_t) (((j - 1) & 1) * 2 + (lane < 32 ? 1 : 0)) * HALO + col;
                     const unsigned want = ((unsigned) epoch << 8) | (unsigned) j;
-                    unsigned long long g[4];
+                    unsigned long long g[PX];
                     int spins = 0;
                     bool failed = false;
                     while (true) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) g[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int k = 0; k < PX; k++) g[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         bool ok = true;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) ok &= ((unsigned) (g[k] >> 32) == want);
+                        for (int k = 0; k < PX; k++) ok &= ((unsigned) (g[k] >> 32) == want);
                         if (__all(ok || !need)) break;
                         __builtin_amdgcn_s_sleep(1);
                         ++spins;
@@ -1982,24 +2043,26 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     if (failed) s_fail = 1;
                     if (need) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) mp[k] = in[k] ? __uint_as_float((unsigned) g[k]) : INF;
+                        for (int k = 0; k < PX; k++) mp[k] = in[k] ? __uint_as_float((unsigned) g[k]) : INF;
                     }
                 }
                 if (yb > 0 && yb + R <= h) { if (interior) batch(yb, std::false_type{}, std::false_type{}); else batch(yb, std::false_type{}, std::true_type{}); }
                 else batch(yb, std::true_type{}, std::true_type{});
                 {
-                    f32x4 v = {mp[0], mp[1], mp[2], mp[3]};
+                    FV v;
+#pragma unroll
+                    for (int k = 0; k < PX; k++) v[k] = mp[k];
                     s_mp[lane] = v;
                 }
                 if (yb + R > ylast && j + 1 < nblk) {
-                    // publish the block's last row (still in mp): the outer DPP_HALO own columns on each side are the
+                    // publish the block's last row (still in mp): the outer HALO own columns on each side are the
                     // neighbours' halo; lanes 16..31 write the left-going granules, lanes 32..47 the right-going ones
                     if (own_lane) {
                         const int side = lane < 32 ? 0 : 1;
-                        gu64 *dst = ex_img + (size_t) tile * DPP_EX_TILE + (size_t) ((j & 1) * 2 + side) * DPP_HALO + 4 * (lane - (side ? 32 : DPP_HALO / 4));
+                        gu64 *dst = ex_img + (size_t) tile * EX_TILE + (size_t) ((j & 1) * 2 + side) * HALO + PX * (lane - (side ? 32 : HL));
                         const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 8) | (unsigned) (j + 1)) << 32;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) __hip_atomic_store(dst + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int k = 0; k < PX; k++) __hip_atomic_store(dst + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
@@ -2227,7 +2290,7 @@ struct LqrHipBatch {
     hipStream_t stream = nullptr;
     unsigned long long *exch = nullptr;     // k_dp_tile_p: halo granules per image and tile + finished-tile counters
     size_t exch_elems = 0;
-    int exch_ntiles = 0, exch_n = 0;        // geometry the exchange area was last laid out for
+    int exch_ntiles = 0, exch_n = 0, exch_px = 0;      // geometry the exchange area was last laid out for
     int tile_epoch = 0;                     // launches of k_dp_tile_p on this batch (part of the granule tags)
     bool dirty = true;
     bool shared = false;                    // other batches of the same group run concurrently on their own streams:
@@ -2259,8 +2322,11 @@ static int dpp_resident_workgroups(int dev)
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 64 * DPP_W, 0) != hipSuccess) { (void) hipGetLastError(); n = 0; }
         per_cu = std::min(per_cu, n);
     };
-    q(k_dp_tile_p<false, false, false>); q(k_dp_tile_p<false, true, false>); q(k_dp_tile_p<true, false, false>); q(k_dp_tile_p<true, true, false>);
-    q(k_dp_tile_p<false, false, true>); q(k_dp_tile_p<false, true, true>); q(k_dp_tile_p<true, false, true>); q(k_dp_tile_p<true, true, true>);
+    q(k_dp_tile_p<4, false, false, false>); q(k_dp_tile_p<4, false, true, false>); q(k_dp_tile_p<4, true, false, false>); q(k_dp_tile_p<4, true, true, false>);
+    q(k_dp_tile_p<4, false, false, true>); q(k_dp_tile_p<4, false, true, true>); q(k_dp_tile_p<4, true, false, true>); q(k_dp_tile_p<4, true, true, true>);
+    q(k_dp_tile_p<2, false, false, false>); q(k_dp_tile_p<2, false, true, false>); q(k_dp_tile_p<2, true, false, false>); q(k_dp_tile_p<2, true, true, false>);
+    q(k_dp_tile_p<2, false, false, true>); q(k_dp_tile_p<2, false, true, true>); q(k_dp_tile_p<2, true, false, true>); q(k_dp_tile_p<2, true, true, true>);
+
     return std::max(0, per_cu - 1) * prop.multiProcessorCount;
 }
 
@@ -2607,6 +2673,8 @@ static int g_update_mode = -1;
 // grid fits; 2: the per-row-barrier band kernel (k_band_update_mw)
 extern "C" void lqrhip_set_update_mode(int mode) { g_update_mode = mode; }
 static int g_dpp_limit_override = -1;
+static int g_dpp_px_override = 0;       // test hook: 2 or 4 pins the persistent sweep's pixels per lane (0 = by batch size)
+extern "C" void lqrhip_set_dp_persistent_px(int px) { g_dpp_px_override = (px == 2 || px == 4) ? px : 0; }
 // -1: the occupancy-derived bound (dpp_resident_workgroups); >= 0: at most that many workgroups for the persistent
 // tiled sweep -- 0 sends every full DP to k_dp_tile and every incremental update to a band kernel
 extern "C" void lqrhip_set_dp_persistent_limit(int workgroups) { g_dpp_limit_override = workgroups; }
@@ -2678,13 +2746,20 @@ static int launch_dp_tiled(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
 
 // can the persistent tiled sweep (k_dp_tile_p) take this batch?  Its tiles spin on each other, so the
 // whole grid has to be resident at once.
-static bool dp_persistent_ok(const LqrHipBatch *b, int w)
+// Pixels per lane of the persistent sweep for this batch: 2 while twice the tiles still fit the residency bound (the row
+// chain is then ~33 instructions per wave instead of ~58; measured per 4K seam round, 2 vs 4 px per lane:
+// 1 image 0.40 / 0.50 ms, 4: 0.45 / 0.55, 8: 0.58 / 0.62, 12: 0.76 / 0.77), else 4, 0 = not at all.
+static int dp_persistent_px(const LqrHipBatch *b, int w)
 {
-    if (b->shared) return false;
-    if (b->cs[0]->wk_h > 255 * DPP_HALO) return false;       // the block index is 8 bits of the granule tag
+    if (b->shared) return 0;
     const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs) : g_dpp_max_wgs;
-    return (size_t) ((w + DPP_OWN - 1) / DPP_OWN) * b->cs.size() <= (size_t) limit;
+    const size_t n = b->cs.size();
+    const int hh = b->cs[0]->wk_h;                            // the block index is 8 bits of the granule tag
+    if (g_dpp_px_override != 4 && hh <= 255 * dpp_halo(2) && (size_t) ((w + dpp_own(2) - 1) / dpp_own(2)) * n <= (size_t) limit) return 2;
+    if (g_dpp_px_override != 2 && hh <= 255 * dpp_halo(4) && (size_t) ((w + dpp_own(4) - 1) / dpp_own(4)) * n <= (size_t) limit) return 4;
+    return 0;
 }
+static bool dp_persistent_ok(const LqrHipBatch *b, int w) { return dp_persistent_px(b, w) != 0; }
 
 // E5 (UPDATE = false) or the full-width form of E9 (UPDATE = true) as one persistent launch
 template <bool UPDATE>
@@ -2692,9 +2767,11 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
 {
     LqrHipCarver *c0 = b->cs[0];
     const size_t n = b->cs.size();
-    const int ntiles = (w + DPP_OWN - 1) / DPP_OWN;
+    const int px = dp_persistent_px(b, w);
+    if (!px) return LQRHIP_EARG;
+    const int ntiles = (w + dpp_own(px) - 1) / dpp_own(px);
     int rc;
-    const size_t need_elems = ((size_t) ntiles * DPP_EX_TILE + 8) * n;
+    const size_t need_elems = ((size_t) ntiles * dpp_ex_tile(px) + 8) * n;
     if (b->exch_elems < need_elems) {
         HIPCK(hipStreamSynchronize(b->stream));
         dfree(b->exch);
@@ -2703,11 +2780,11 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
         b->exch_elems = need_elems;
         b->exch_ntiles = 0;
     }
-    if (b->exch_ntiles != ntiles || b->exch_n != (int) n) {
+    if (b->exch_ntiles != ntiles || b->exch_n != (int) n || b->exch_px != px) {
         // (re)lay the exchange area out: tags and finished-tile counters start at 0 (afterwards nothing is ever
         // cleared: tags carry the launch epoch, the last tile re-arms the counter)
         HIPCK(hipMemsetAsync(b->exch, 0, need_elems * sizeof(unsigned long long), b->stream));
-        b->exch_ntiles = ntiles; b->exch_n = (int) n;
+        b->exch_ntiles = ntiles; b->exch_n = (int) n; b->exch_px = px;
     }
     if (UPDATE) {
         // second planes, allocated on first use -- per carver: a batch may mix carvers that already went
@@ -2727,9 +2804,14 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
     }
     const int epoch = 1 + ((b->tile_epoch++) % 0x7ffffe);          // never 0; 23 bits above the 8-bit block index
     const dim3 grid(ntiles, (unsigned) n);
-#define LAUNCH_TILE(LRV, RIGV) hipLaunchKernelGGL((k_dp_tile_p<LRV, RIGV, UPDATE>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
-    if (lr) { if (k.use_rig) LAUNCH_TILE(true, true); else LAUNCH_TILE(true, false); }
-    else { if (k.use_rig) LAUNCH_TILE(false, true); else LAUNCH_TILE(false, false); }
+#define LAUNCH_TILE(PXV, LRV, RIGV) hipLaunchKernelGGL((k_dp_tile_p<PXV, LRV, RIGV, UPDATE>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
+#define LAUNCH_TILE_PX(PXV)                                                                 \
+    do {                                                                                    \
+        if (lr) { if (k.use_rig) LAUNCH_TILE(PXV, true, true); else LAUNCH_TILE(PXV, true, false); }     \
+        else { if (k.use_rig) LAUNCH_TILE(PXV, false, true); else LAUNCH_TILE(PXV, false, false); }      \
+    } while (0)
+    if (px == 2) LAUNCH_TILE_PX(2); else LAUNCH_TILE_PX(4);
+#undef LAUNCH_TILE_PX
 #undef LAUNCH_TILE
     HIPCK(hipGetLastError());
     if (UPDATE)       // the kernel's last tile swapped the pointers in the device descriptors: mirror it

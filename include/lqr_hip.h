@@ -164,6 +164,9 @@ void lqrhip_set_update_mode(int mode);
  * must all be resident: -1 = the bound derived from the occupancy query at lqrhip_init, n >= 0 = min(n, that bound).
  * Grids above the cap run as k_dp_tile (one launch per 32 rows).  0 forces that path (tests). */
 void lqrhip_set_dp_persistent_limit(int workgroups);
+/* Pixels per lane of the persistent tiled sweep: 0 = by batch size (2 while twice the tiles fit the residency bound,
+ * else 4), 2 or 4 = pinned (tests) */
+void lqrhip_set_dp_persistent_px(int px);
 void lqrhip_prof_reset(void);
 int lqrhip_prof_get(const char *kernel, double *ms_total, long long *launches, double *bytes_total);
 

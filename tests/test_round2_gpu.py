@@ -280,3 +280,26 @@ def test_sub_batches_on_separate_streams(oracle, engine, nsub):
         assert np.array_equal(c.read_image(), ref["image"])
         assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"])
         c.destroy()
+
+
+@pytest.mark.parametrize("px", [2, 4])
+def test_persistent_sweep_pixels_per_lane(oracle, engine, px):
+    """k_dp_tile_p runs with 2 pixels per lane (128-column tiles) while twice the tiles fit the residency bound and with
+    4 (256-column tiles) beyond that; both pinned here on the same cases: full builds with both tie rules, incremental
+    updates, rigidity, tiles that straddle the image borders, a batch"""
+    engine.lib.lqrhip_set_dp_persistent_px.argtypes = [ctypes.c_int]
+    engine.lib.lqrhip_set_dp_persistent_px(px)
+    try:
+        both(oracle, engine, D.photo_like(700, 300, 990), 640, 260, output_seams=True)
+        both(oracle, engine, D.noise(450, 131, 991), 400, 131, switch_freq=1000, rigidity=3.0)
+        both(oracle, engine, D.flat_blocks(129, 70, 992), 100, 70)
+        both(oracle, engine, D.noise(63, 40, 993, channels=1), 40, 40, nrg_func=0)
+        imgs = [D.photo_like(520, 200, 994 + i) for i in range(3)]
+        cs = [L.Carver(engine, im).configure() for im in imgs]
+        assert L.resize_batch(engine, cs, 470, 200) == L.LQR_OK
+        for im, c in zip(imgs, cs):
+            ref = H.run_case(oracle, im, 470, 200)
+            assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"])
+            c.destroy()
+    finally:
+        engine.lib.lqrhip_set_dp_persistent_px(0)
