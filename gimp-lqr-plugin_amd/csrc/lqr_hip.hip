@@ -515,21 +515,25 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
 // k_vpath1: k_vpath for delta_x == 1.  The chase is a chain of H dependent steps on one wave, so what counts
 // is the length of one step and that the back pointers are there when the chase reaches them.  In k_vpath a step
 // is v_readlane + 7 scalar instructions (find the lane, pull the dword, extract and sign-extend the byte), ~55 ns.
-// Here the rows are taken in chunks of 30:
+// Here the rows are taken in chunks of 28:
 //   * a 256-column window of back-pointer bytes per row is prefetched THREE chunks ahead (the chunk's start
-//     column is then known to within 3 * 30 columns, and it moves at most 30 more inside the chunk: 120 <= 126
-//     columns of margin).  One load instruction fetches TWO rows (8 bytes per lane, 32 lanes per row): a wave can
-//     have 63 vector-memory operations outstanding, and with one row per load the third chunk ahead did not fit;
+//     column is then known to within 3 * 28 columns, and it moves at most 28 more inside the chunk; the window
+//     leaves 88 columns of margin on each side of the 64 that are used).  One load instruction fetches FOUR rows
+//     (16 bytes per lane, 16 lanes per row): a load instruction costs the CU's memory path ~42 cycles whatever its
+//     width, and a wave can have only 63 of them outstanding;
 //   * when a chunk's turn comes its start column xc is known exactly: the staged rows go through an LDS scratch
 //     (row-major, 256 bytes per row: exactly what the loads hold lane by lane) and the 64 columns xc - 32 .. xc + 31
-//     come back one per lane, sign-extended (ds_write_b64 x 15, ds_read_i8 x 30, all independent);
-//   * the chase step is then v_readlane (the lane IS the column) + s_add, plus a v_writelane that records the
-//     path: ~3 instructions, ~17 ns measured.
+//     come back one per lane, sign-extended (ds_write_b128 x 7, ds_read_i8 x 28, all independent);
+//   * rows are then composed in PAIRS, for all 64 columns at once: the two-row displacement of column c is
+//     d(r, c) + d(r + 1, c + d(r, c)), one ds_bpermute per pair (independent, pipelined) -- so the chase, the only
+//     serial part, has 14 steps per chunk instead of 28.  A step is v_readlane (the lane IS the column) + s_add +
+//     a v_writelane that records the path: ~45 cycles with its wait states;
+//   * the odd rows' columns are filled in afterwards, all at once (one LDS read).
 // No load is guarded or predicated (rows above the image re-read row 1 and their steps are discarded).
 // No LEAST_INVALID test: the carve marks a back pointer invalid only next to the seam, inside the interval
 // every form of update_mmap recomputes before the next backtrack, so none survives to this point.
 // ---------------------------------------------------------------------------
-#define VP1_ROWS 30
+#define VP1_ROWS 28
 #define VP1_AHEAD 3
 template <int r>
 __device__ __forceinline__ void vp1_step(const int e, int &o, int &path)
@@ -538,7 +542,7 @@ __device__ __forceinline__ void vp1_step(const int e, int &o, int &path)
     o += __builtin_amdgcn_readlane(e, o);
 }
 template <int... Rs>
-__device__ __forceinline__ void vp1_chase(const int (&e)[VP1_ROWS], int &o, int &path, std::integer_sequence<int, Rs...>)
+__device__ __forceinline__ void vp1_chase(const int (&e)[VP1_ROWS / 2], int &o, int &path, std::integer_sequence<int, Rs...>)
 {
     (vp1_step<Rs>(e[Rs], o, path), ...);
 }
@@ -590,47 +594,56 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, i
     const int lane = tid;
     gi32 *seam = c.seam_x;
     gi32 *logp = c.seam_log + (size_t) log_index * h;
-    constexpr int R = VP1_ROWS, NB = VP1_AHEAD + 1, RL = VP1_ROWS / 2;      // RL loads per chunk, two rows each
-    static_assert(VP1_ROWS % 2 == 0 && (VP1_AHEAD + 1) * VP1_ROWS <= 126, "window margin");
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 regs[NB][RL];                          // ring of packed windows: chunk k lives in regs[k % NB]
+    constexpr int R = VP1_ROWS, NB = VP1_AHEAD + 1, RL = VP1_ROWS / 4;      // RL loads per chunk, four rows each
+    // window [base, base + 256) with base in [cx - 135, cx - 120]: the 64 columns around a start column that has moved up to
+    // 88 either way since the load are inside
+    static_assert(VP1_ROWS % 4 == 0 && VP1_AHEAD * VP1_ROWS + 32 <= 120 && VP1_AHEAD * VP1_ROWS + 31 <= 120, "window margin");
+    u32x4 regs[NB][RL];                          // ring of packed windows: chunk k lives in regs[k % NB]
     int xa[NB];                                  // their base columns
-    auto window_base = [&](int cx) { return (cx - 126) & ~7; };      // multiple of 8: a lane's 8 columns never straddle column 0
+    auto window_base = [&](int cx) { return (cx - 120) & ~15; };     // multiple of 16: a lane's 16 columns never straddle column 0
     // Nothing is predicated (a select per load cost more instructions than the chase itself): columns outside
     // the plane are clamped into it -- the path never goes there -- and rows above row 1 re-read row 1; the steps
     // taken on those are discarded (see run_chunk).  Uniform row base + 32-bit lane offset: one VALU per load.
     auto load_chunk = [&](int b, int y_top, int cx) {
         const int base = window_base(cx);
         xa[b] = base;
-        // lanes 0..31: row y_top - 2q, lanes 32..63: row y_top - 2q - 1; 8 columns per lane
-        const unsigned voff = (unsigned) min(max(base + 8 * (lane & 31), 0), stride - 8);
+        // lanes 16s .. 16s + 15: row y_top - 4q - s, 16 columns per lane
+        const int voff = min(max(base + 16 * (lane & 15), 0), stride - 16);
+        const int rsub = (lane >> 4) * stride;
 #pragma unroll
         for (int q = 0; q < RL; q++) {
-            const unsigned rowa = (unsigned) max(y_top - 2 * q, 1) * (unsigned) stride;
-            const unsigned rowb = (unsigned) max(y_top - 2 * q - 1, 1) * (unsigned) stride;
-            regs[b][q] = *(const GLOBAL_AS u32x2 *) (c.least + ((lane < 32 ? rowa : rowb) + voff));
+            const int row = max((y_top - 4 * q) * stride - rsub, stride);          // rows above row 1 re-read row 1
+            regs[b][q] = *(const GLOBAL_AS u32x4 *) (c.least + (unsigned) (row + voff));
         }
     };
     // one chunk: spread the 64 columns around the start column out over the lanes, chase, record
     int acc = 0;
     auto run_chunk = [&](int b, int y_top) {
-        const int rel = x - 32 + lane - xa[b];               // this lane's column, 0 .. 255 inside the window
+        const int relbase = x - 32 - xa[b];                  // window column of lane 0's column
         int e[R];
         // through LDS: what the loads hold lane by lane IS row-major [row][256 columns]; same wave writes and reads, LDS
         // operations of a wave execute in order
 #pragma unroll
-        for (int q = 0; q < RL; q++) *(u32x2 *) (s_win + q * 512 + lane * 8) = regs[b][q];
+        for (int q = 0; q < RL; q++) *(u32x4 *) (s_win + q * 1024 + lane * 16) = regs[b][q];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < R; r++) e[r] = s_win[r * 256 + rel];
-        __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < R; r++) e[r] = s_win[r * 256 + relbase + lane];
+        // two-row displacements of every column (the path stays within lanes 4 .. 60, so the wrap-around of the
+        // outermost lanes' neighbours never matters)
+        int e2[R / 2];
+#pragma unroll
+        for (int k = 0; k < R / 2; k++) e2[k] = e[2 * k] + __builtin_amdgcn_ds_bpermute((lane + e[2 * k]) << 2, e[2 * k + 1]);
         int o = 32, path = 0;
-        vp1_chase(e, o, path, std::make_integer_sequence<int, R>{});
-        path += x - 32;                                      // lane r: column at row y_top - r (before step r)
+        vp1_chase(e2, o, path, std::make_integer_sequence<int, R / 2>{});          // lane k <- window offset at row y_top - 2k
+        // the odd rows, all at once: lane k looks its even row's displacement up at the column it stands on
+        const int odd = path + s_win[min(lane, R / 2 - 1) * 512 + relbase + path];
+        __builtin_amdgcn_wave_barrier();
+        const int pe = path + x - 32, po = odd + x - 32;     // columns at rows y_top - 2k and y_top - 2k - 1
         const int nrows = min(R, y_top);
-        if (lane < nrows) { seam[y_top - lane] = path; logp[y_top - lane] = path; acc += path; }
+        if (2 * lane < nrows) { seam[y_top - 2 * lane] = pe; logp[y_top - 2 * lane] = pe; acc += pe; }
+        if (2 * lane + 1 < nrows) { seam[y_top - 2 * lane - 1] = po; logp[y_top - 2 * lane - 1] = po; acc += po; }
         // the column after `nrows` steps: the last chunk may hold fewer real rows than R (the rest re-read row 1)
-        x = (nrows == R) ? x + o - 32 : __builtin_amdgcn_readlane(path, nrows);
+        x = (nrows == R) ? x + o - 32 : __builtin_amdgcn_readlane((nrows & 1) ? po : pe, nrows >> 1);
     };
     int y_top = h - 1;
     // chunks are issued VP1_AHEAD ahead; the first ones all around the argmin
