@@ -177,8 +177,20 @@ __device__ __forceinline__ int dev_failed(int *flag)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double norm255(uint32_t v) { return __ddiv_rn((double) v, 255.0); }
 
-// brightness / luma of one packed pixel, in double, times alpha (E3)
-__device__ __forceinline__ double px_bright(uint32_t p, int ch, bool luma)
+// brightness / luma of one packed pixel, in double, times alpha (E3).  N255(v) = (double) v / 255.0, correctly rounded:
+// norm255 computes it (an FP64 division: ~40 instructions); kernels that need many of them keep the 256 quotients in
+// an LDS table filled once per workgroup with that same division (fill_norm255 / Norm255Lut) -- bit-identical values
+struct Norm255Div { __device__ __forceinline__ double operator()(uint32_t v) const { return norm255(v); } };
+struct Norm255Lut {
+    const double *t;
+    __device__ __forceinline__ double operator()(uint32_t v) const { return t[v]; }
+};
+__device__ __forceinline__ void fill_norm255(double *t, int tid, int nthreads)
+{
+    for (int v = tid; v < 256; v += nthreads) t[v] = norm255((uint32_t) v);
+}
+template <class N255>
+__device__ __forceinline__ double px_bright(uint32_t p, int ch, bool luma, N255 norm255)
 {
     double b;
     uint32_t c0 = p & 0xffu, c1 = (p >> 8) & 0xffu, c2 = (p >> 16) & 0xffu, c3 = p >> 24;
@@ -225,17 +237,17 @@ __device__ __forceinline__ float grad_energy_f(BF B, int x, int y, int w, int h)
     return __double2float_rn(g);
 }
 
-template <int NRG>
-__device__ __forceinline__ float grad_energy(const gu32 *pix, int stride, int x, int y, int w, int h, int ch)
+template <int NRG, class N255>
+__device__ __forceinline__ float grad_energy(const gu32 *pix, int stride, int x, int y, int w, int h, int ch, N255 n255)
 {
     constexpr bool luma = (NRG >= 3);
-    return grad_energy_f<NRG>([&](int xx, int yy) { return px_bright(pix[(size_t) yy * stride + xx], ch, luma); }, x, y, w, h);
+    return grad_energy_f<NRG>([&](int xx, int yy) { return px_bright(pix[(size_t) yy * stride + xx], ch, luma, n255); }, x, y, w, h);
 }
 
-template <int NRG>
-__device__ __forceinline__ float energy_at(const GCarver &c, const DpK &p, int stride, int x, int y, int w, int h)
+template <int NRG, class N255>
+__device__ __forceinline__ float energy_at(const GCarver &c, const DpK &p, int stride, int x, int y, int w, int h, N255 n255)
 {
-    float e = grad_energy<NRG>(c.pix, stride, x, y, w, h, p.ch);
+    float e = grad_energy<NRG>(c.pix, stride, x, y, w, h, p.ch, n255);
     if (c.bias) e = __fadd_rn(e, __fdiv_rn(c.bias[(size_t) y * stride + x], (float) p.w_start));
     return e;
 }
@@ -279,10 +291,13 @@ __global__ void k_wk_init(const DevCarver *cs, int w, int h, int stride, int ch)
 template <int NRG>
 __global__ void k_emap_full(const DevCarver *cs, DpK p, int w, int h, int stride)
 {
+    __shared__ double s_n255[256];
+    fill_norm255(s_n255, threadIdx.x, blockDim.x);
+    __syncthreads();
     const GCarver c = gview(cs[blockIdx.z]);
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
-    c.en[(size_t) y * stride + x] = energy_at<NRG>(c, p, stride, x, y, w, h);
+    c.en[(size_t) y * stride + x] = energy_at<NRG>(c, p, stride, x, y, w, h, Norm255Lut{s_n255});
 }
 
 // E2: mask value = mean(colour)/255 * alpha/255 (help/en/index.wiki:48)
@@ -953,7 +968,10 @@ __global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, 
     __shared__ double bt[64][EU_NT];
     __shared__ float bb[64][EU_NT];
     __shared__ int slo[64];
+    __shared__ double s_n255[256];
     const int tid = threadIdx.x;
+    fill_norm255(s_n255, tid, 64);
+    __syncthreads();
     const int y = blockIdx.x * EU_ROWS + tid - 1;
     const bool row_ok = (y >= 0 && y < h);
     constexpr bool luma = (NRG >= 3);
@@ -968,18 +986,27 @@ __global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, 
         int pos[EU_NT];
 #pragma unroll
         for (int i = 0; i < EU_NT; i++) pos[i] = lo + i;
+        // undo seams k .. epoch, newest first.  The log entries are loaded eight at a time (unconditionally: indices
+        // below `epoch` are clamped and their values replaced by one that moves nothing), so that a row does not wait
+        // for one global load per logged seam
         const gi32 *lg = c.seam_log + y;
-        for (int j = k; j >= epoch; j--) {
-            const int v = lg[(size_t) j * h];
+        for (int j = k; j >= epoch; j -= 8) {
+            int v[8];
 #pragma unroll
-            for (int i = 0; i < EU_NT; i++) pos[i] += (v <= pos[i]) ? 1 : 0;
+            for (int u = 0; u < 8; u++) v[u] = lg[(size_t) max(j - u, epoch) * h];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int vu = (j - u >= epoch) ? v[u] : 0x7fffffff;
+#pragma unroll
+                for (int i = 0; i < EU_NT; i++) pos[i] += (vu <= pos[i]) ? 1 : 0;
+            }
         }
         const int wf = w + (k - epoch) + 1;           // width of the frozen frame
 #pragma unroll
         for (int i = 0; i < EU_NT; i++) {
             const bool ok = (lo + i <= min(r, w - 1)) && pos[i] < wf;
             const size_t o = (size_t) y * stride + (ok ? pos[i] : 0);
-            bt[tid][i] = ok ? px_bright(c.pix[o], p.ch, luma) : 0.0;
+            bt[tid][i] = ok ? px_bright(c.pix[o], p.ch, luma, Norm255Lut{s_n255}) : 0.0;
             bb[tid][i] = (ok && c.bias) ? c.bias[o] : 0.0f;
         }
     }
