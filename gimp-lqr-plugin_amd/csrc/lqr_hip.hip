@@ -1763,8 +1763,12 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
             };
             const bool interior = (x0 - 4 * lane >= 0) && (x0 - 4 * lane + 256 <= w);      // uniform per wave
             if (active) {
+                // the computing wave outranks its partner's load issue on the SIMD they share (-3 % on the kernel; no
+                // effect in k_dp_tile_p, whose two waves sit on different SIMDs)
+                __builtin_amdgcn_s_setprio(2);
                 if (nrows == R) { if (interior) rows(std::false_type{}, std::false_type{}); else rows(std::false_type{}, std::true_type{}); }
                 else rows(std::true_type{}, std::true_type{});
+                __builtin_amdgcn_s_setprio(0);
             }
             else if (nrows == R) {
                 // nothing can change in this slot during the batch: its last row is what memory holds
