@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--sub-batches", type=int, default=1,
                     help="split the batch over this many HIP streams (chain kernels of one under the carve of another): more "
                          "throughput, but every kernel then shares the chip and the per-launch roofline figure drops")
+    ap.add_argument("--update-mode", type=int, default=-1,
+                    help="update_mmap kernel: -1 the engine's choice, 0 band, 1 tiled full width, 2 band-mw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--switch-freq", type=int, default=2, help="lqr side switch frequency (plug-in: 2, render.c:237)")
@@ -170,6 +172,8 @@ def main():
         raise SystemExit("bench.py: torch sees no GPU")
     lib.lqrhip_set_sub_batches.argtypes = [C.c_int]
     lib.lqrhip_set_sub_batches(args.sub_batches)
+    lib.lqrhip_set_update_mode.argtypes = [C.c_int]
+    lib.lqrhip_set_update_mode(args.update_mode)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

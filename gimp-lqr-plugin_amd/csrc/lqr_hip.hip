@@ -1727,7 +1727,9 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
             auto rows = [&](auto guard, auto mask) {
                 constexpr bool GUARD = decltype(guard)::value, MASK = decltype(mask)::value;
                 const bool own = own_lane && x0 < w;
-                // running store offsets (see k_dp_tile_p)
+                // running store offsets (see k_dp_tile_p).  The stores stay conditional here: four slots share this CU's
+                // memory path, which is the bound (section 4.5) -- without the condition the row is 100 cycles shorter for
+                // the wave and the kernel 3 % slower (the halo lanes' stores are traffic on that path)
                 unsigned so = (unsigned) y * (unsigned) stride + (unsigned) x0, so4 = so * 4u;
 #pragma unroll
                 for (int r = 0; r < R; r++, so += (unsigned) stride, so4 += 4u * (unsigned) stride) {
@@ -1899,8 +1901,8 @@ __global__ __launch_bounds__(64) void k_dp_tile(const DevCarver *cs, DpK p, int 
                             lnew |= ((uint32_t) bdx & 0xffu) << (8 * k);
                         }
                     }
-                    if (own) {
-                        const unsigned so = (unsigned) y * (unsigned) stride + (unsigned) x0;
+                    {   // no condition on the stores (k_dp_tile_p): lanes that own nothing write to the spare row
+                        const unsigned so = own ? (unsigned) y * (unsigned) stride + (unsigned) x0 : (unsigned) h * (unsigned) stride + 4u * lane;
                         f32x4 t = {mc[0], mc[1], mc[2], mc[3]};
                         *(GLOBAL_AS f32x4 *) (c.m + so) = t;
                         *(gu32 *) (c.least + so) = lnew;
@@ -2001,10 +2003,14 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
     auto batch = [&](int ybase, auto guard, auto mask) {
         constexpr bool GUARD = decltype(guard)::value, MASK = decltype(mask)::value;
         // store offsets run down the rows in two VGPRs (elements for the byte plane, bytes for m): one v_add each per
-        // row instead of a scalar multiply + two adds; opaque to the compiler so that it keeps them that way
-        unsigned so = (unsigned) ybase * (unsigned) stride + (unsigned) x0, so4 = so * 4u;
+        // row instead of a scalar multiply + two adds; opaque to the compiler so that it keeps them that way.
+        // The stores carry no condition: `if (own)` costs s_and_saveexec + s_cbranch_execz + s_or exec per row, which a
+        // lone wave pays with ~90 of its ~350 cycles per row (scripts/dbg/t_row.hip: 352 -> 250 cycles).  Lanes that own
+        // nothing (halo, beyond the image) write to the spare row below the image instead, their offsets standing still.
+        const unsigned inc = own ? (unsigned) stride : 0u, inc4 = inc * 4u;
+        unsigned so = own ? (unsigned) ybase * (unsigned) stride + (unsigned) x0 : (unsigned) h * (unsigned) stride + (unsigned) (PX * lane), so4 = so * 4u;
 #pragma unroll
-        for (int r = 0; r < R; r++, so += (unsigned) stride, so4 += 4u * (unsigned) stride) {
+        for (int r = 0; r < R; r++, so += inc, so4 += inc4) {
             const int y = ybase + r;
             asm volatile("" : "+v"(so), "+v"(so4));
             if (!GUARD || y < h) {
@@ -2021,7 +2027,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     bool ch[PX];
                     dp_row<PX, LR, RIG, UPDATE, MASK>(mp, left, right, e, mo, UPDATE ? (uint32_t) q_lo[r] : 0u, in, rig_l, rig_r, mc, lnew, ch);
                 }
-                if (own) {
+                {
                     FV t;
 #pragma unroll
                     for (int k = 0; k < PX; k++) t[k] = mc[k];
