@@ -2204,12 +2204,29 @@ __device__ __forceinline__ void px_avg(uint8_t *dst, const uint8_t *a, const uin
     }
 }
 
-// E14: one block per row.  dup(c) = the seam was computed in this session.
-__global__ __launch_bounds__(256) void k_inflate(const uint8_t *rgb, const int32_t *vs, const float *bias, const float *rig,
-                                                  uint8_t *nrgb, int32_t *nvs, float *nbias, float *nrig, int w0, int w1, int ch,
-                                                  int l, int max_level)
+// E14: one block per row (blockIdx.x) of one carver of the batch (blockIdx.y: every carver and attached carver of the
+// batch in ONE launch -- a launch per carver leaves most of the chip idle behind each row's serial rank scan).
+// dup(c) = the seam was computed in this session.
+struct InflateDev {
+    const uint8_t *rgb;
+    const int32_t *vs;
+    const float *bias, *rig;
+    uint8_t *nrgb;
+    int32_t *nvs;
+    float *nbias, *nrig;
+    int ch;
+};
+__global__ __launch_bounds__(256) void k_inflate(const InflateDev *jobs, int w0, int w1, int l, int max_level)
 {
     __shared__ int s_wave[4];
+    const InflateDev j = jobs[blockIdx.y];
+    const uint8_t *rgb = j.rgb;
+    const int32_t *vs = j.vs;
+    const float *bias = j.bias, *rig = j.rig;
+    uint8_t *nrgb = j.nrgb;
+    int32_t *nvs = j.nvs;
+    float *nbias = j.nbias, *nrig = j.nrig;
+    const int ch = j.ch;
     const int y = blockIdx.x, tid = threadIdx.x;
     const int32_t *vrow = vs + (size_t) y * w0;
     const size_t ri = (size_t) y * w0, ro = (size_t) y * w1;
@@ -3061,16 +3078,16 @@ extern "C" int lqrhip_vs_commit(LqrHipBatch *b, int w0, int h0, int wc0, int n_s
     return 0;
 }
 
-// E14: every carver of the batch (roots and their attached carvers) is inflated by one launch
-// each, all enqueued before a single synchronisation; planes are swapped afterwards
+// E14: every carver of the batch (roots and their attached carvers) is inflated by ONE launch (a job table in device
+// memory, one grid row of blocks per job); planes are swapped after its synchronisation
 struct InflateJob {
     LqrHipCarver *c;
     uint8_t *nrgb;
     float *nbias, *nrig;
 };
 
-static int inflate_enqueue(LqrHipCarver *c, const int32_t *vs_old, int32_t *nvs, int w0, int h0, int w1, int l, int max_level,
-                           hipStream_t s, std::vector<InflateJob> &jobs)
+static int inflate_prepare(LqrHipCarver *c, const int32_t *vs_old, int32_t *nvs, int h0, int w1, std::vector<InflateJob> &jobs,
+                           std::vector<InflateDev> &dev)
 {
     InflateJob j{c, nullptr, nullptr, nullptr};
     int rc;
@@ -3078,10 +3095,8 @@ static int inflate_enqueue(LqrHipCarver *c, const int32_t *vs_old, int32_t *nvs,
     if ((rc = dmalloc(&j.nrgb, n1 * c->ch))) return rc;
     if (c->bias0 && (rc = dmalloc(&j.nbias, n1))) return rc;
     if (c->rig0 && (rc = dmalloc(&j.nrig, n1))) return rc;
-    hipLaunchKernelGGL(k_inflate, dim3(h0), dim3(256), 0, s, c->rgb0, vs_old, c->bias0, c->rig0, j.nrgb, nvs, j.nbias, j.nrig, w0, w1,
-                       c->ch, l, max_level);
-    HIPCK(hipGetLastError());
     jobs.push_back(j);
+    dev.push_back(InflateDev{c->rgb0, vs_old, c->bias0, c->rig0, j.nrgb, nvs, j.nbias, j.nrig, c->ch});
     return 0;
 }
 
@@ -3090,16 +3105,23 @@ extern "C" int lqrhip_inflate(LqrHipBatch *b, int w0, int h0, int l, int max_lev
     int rc;
     const int w1 = w0 + l - max_level + 1;
     std::vector<InflateJob> jobs;
+    std::vector<InflateDev> dev;
     std::vector<int32_t *> new_vs;
     for (auto *c : b->cs) {
         int32_t *nvs = nullptr;
         if ((rc = dmalloc(&nvs, (size_t) w1 * h0))) return rc;
         new_vs.push_back(nvs);
         for (auto *a : c->aux)
-            if ((rc = inflate_enqueue(a, c->vs, nullptr, w0, h0, w1, l, max_level, b->stream, jobs))) return rc;
-        if ((rc = inflate_enqueue(c, c->vs, nvs, w0, h0, w1, l, max_level, b->stream, jobs))) return rc;
+            if ((rc = inflate_prepare(a, c->vs, nullptr, h0, w1, jobs, dev))) return rc;
+        if ((rc = inflate_prepare(c, c->vs, nvs, h0, w1, jobs, dev))) return rc;
     }
+    InflateDev *d_jobs = nullptr;
+    if ((rc = dmalloc(&d_jobs, dev.size()))) return rc;
+    HIPCK(hipMemcpyAsync(d_jobs, dev.data(), dev.size() * sizeof(InflateDev), hipMemcpyHostToDevice, b->stream));
+    hipLaunchKernelGGL(k_inflate, dim3(h0, (unsigned) dev.size()), dim3(256), 0, b->stream, d_jobs, w0, w1, l, max_level);
+    HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(b->stream));
+    dfree(d_jobs);
     for (auto &j : jobs) {
         dfree(j.c->rgb0); j.c->rgb0 = j.nrgb;
         if (j.nbias) { dfree(j.c->bias0); j.c->bias0 = j.nbias; }
