@@ -303,3 +303,25 @@ def test_persistent_sweep_pixels_per_lane(oracle, engine, px):
             c.destroy()
     finally:
         engine.lib.lqrhip_set_dp_persistent_px(0)
+
+
+def test_batch_with_attached_carvers_enlarges_in_steps(oracle, engine):
+    """a lock-step batch whose carvers each carry masks AND attached carvers (resize_aux_layers), enlarged past enl_step
+    so that every session ends in E14 (inflate) with several jobs per image in its one launch; both directions.
+    Each image must come out as the oracle's one-by-one run: pixels, attached carvers, final seam map."""
+    w, h = 150, 90
+    imgs = [D.photo_like(w, h, 990 + i) if i % 2 else D.noise(w, h, 990 + i) for i in range(4)]
+    pres, disc, rig = D.ellipse_mask(w, h), D.band_mask(w, h, 20, 50), D.top_half_mask(w, h)
+    kw = dict(pres=pres, disc=disc, rigmask=rig, rigidity=2.0, resize_aux_layers=True, no_disc_on_enlarge=False, enl_step=130)
+    nw, nh = 240, 100                                   # 150 -> 194 -> 240 in two sessions, then 90 -> 100
+    cs = [H.init_carver(engine, im, nw, nh, **kw)[0] for im in imgs]
+    assert L.resize_batch(engine, cs, nw, nh) == L.LQR_OK
+    for im, c in zip(imgs, cs):
+        ref = H.run_case(oracle, im, nw, nh, **kw)
+        got, _ = c.read_scanlines()
+        assert np.array_equal(got, ref["image"])
+        assert len(c.aux) == len(ref["aux"]) == 3
+        for a, b in zip(c.aux, ref["aux"]):
+            assert np.array_equal(a.read_scanlines()[0], b)
+        assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"])
+        c.destroy()
