@@ -1588,6 +1588,12 @@ template <> struct LaneVec<4> { typedef f32x4 F; typedef uint32_t L; };
 // ---------------------------------------------------------------------------
 constexpr int TW_R = 16;                     // rows per batch = halo columns
 constexpr int TW_OWN = 256 - 2 * TW_R;       // own columns per slot
+// Within an active slot only the lanes near the changes are staged, stored and handed over: pixels further than R
+// columns from the changed ones cannot change during a batch; lanes that were not staged compute garbage, which moves
+// inwards one column per row, so staging reaches R (kept lanes) + R (rows) + 8 (a kept lane's own four columns, slack).
+// A vector-memory instruction costs the CU's memory path ~12 + 0.7 cycles per ACTIVE lane (scripts/dbg/t_ta.hip),
+// and that path is this kernel's bound.
+constexpr int TW_LANE_MARGIN = 2 * TW_R + 8;
 
 template <int NW, bool LR, bool RIG>
 __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs, DpK p, int w, int h, int stride, int *dev_err)
@@ -1642,7 +1648,7 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
     // Addresses as uniform plane base + 32-bit lane offset (global_load ... v_off, s[base]): per row one scalar
     // multiply and two VALU adds for the three loads.  With 64-bit per-lane addresses the 48 loads of a batch cost
     // ~2600 cycles of issue (measured), on the SIMD the partner wave is computing on.
-    auto issue = [&](int ybase, bool full) {
+    auto issue = [&](int ybase, bool full) {        // full: per LANE (see TW_LANE_MARGIN)
         const int x0 = B + OWN * slot - R + 4 * lane;
         const unsigned lo_off = (unsigned) min(max(x0, 0), stride - 4);
         if (full) {
@@ -1666,6 +1672,7 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
 
     int y = 1, ovf = h, kpar = 0;
     bool loads_full = true;                  // does this wave's staged batch hold all rows (or only the hand-over row)?
+    bool lane_staged = true;                 // ... for this lane (a slot stages only the lanes near the changes)
     int dlo = 1 << 30, dhi = -1;             // px changed on the last finished row (absolute x)
     bool have_window = false, force_active = false, just_rebased = false;
     while (y < h) {
@@ -1675,7 +1682,8 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
         if (dhi >= dlo) { lo = min(lo, dlo - 1); hi = max(hi, dhi + 1); }
         lo = max(lo, 0); hi = min(hi, w - 1);
         const bool fits = have_window && (B == 0 || lo - R >= B) && (B + WIN >= w || hi + R <= B + WIN - 1);
-        bool issue_full = true;
+        bool issue_full = true, lane_all = true;     // lane_all: stage every lane (after a re-centring, or nothing known)
+        int plo_l = 0, phi_l = 0;
         int y_issue = -1;                    // batch this wave prefetches at the end of the iteration (one issue site:
                                              // a second one makes the register allocator spill the staging rows)
         if (!fits) {
@@ -1709,6 +1717,12 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
             // the prediction below is a superset by construction; should it ever fail, say so instead of
             // computing on rows that were not loaded (the host turns the flag into LQR_ERROR)
             if (active && !loads_full && lane == 0) dev_fail(dev_err, DEVERR_BAND_PREDICTION);
+            // Lane granularity of the same superset argument: pixels further than R columns from [lo, hi] cannot change
+            // in this batch, so only the lanes touching [lo - R, hi + R] are kept (stored, handed over, counted); for
+            // those to be right through R rows their neighbours up to TW_LANE_MARGIN columns out must have been staged.
+            const bool lane_valid = force_active || (x0 + 3 >= lo - R && x0 <= hi + R);
+            if (active && __any(!force_active && (x0 + 3 >= lo - TW_LANE_MARGIN && x0 <= hi + TW_LANE_MARGIN) && !lane_staged) && lane == 0)
+                dev_fail(dev_err, DEVERR_BAND_PREDICTION);
             bool in[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) in[k] = (x0 + k >= 0) && (x0 + k < w);
@@ -1726,7 +1740,7 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
             // the image's left or right border
             auto rows = [&](auto guard, auto mask) {
                 constexpr bool GUARD = decltype(guard)::value, MASK = decltype(mask)::value;
-                const bool own = own_lane && x0 < w;
+                const bool own = own_lane && x0 < w && lane_valid;
                 // running store offsets (see k_dp_tile_p).  The stores stay conditional here: four slots share this CU's
                 // memory path, which is the bound (section 4.5) -- without the condition the row is 100 cycles shorter for
                 // the wave and the kernel 3 % slower (the halo lanes' stores are traffic on that path)
@@ -1752,7 +1766,7 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
                             // extent of the changes on the batch's last row (own columns)
 #pragma unroll
                             for (int k = 0; k < 4; k++) {
-                                const unsigned long long chm = __ballot(ch[k] && (!MASK || in[k]) && own_lane);
+                                const unsigned long long chm = __ballot(ch[k] && (!MASK || in[k]) && own_lane && lane_valid);
                                 if (chm) {
                                     const int first = __builtin_ctzll(chm), last = 63 - __builtin_clzll(chm);
                                     rlo = min(rlo, B + OWN * slot - R + 4 * first + k);
@@ -1771,6 +1785,11 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
                 if (nrows == R) { if (interior) rows(std::false_type{}, std::false_type{}); else rows(std::false_type{}, std::true_type{}); }
                 else rows(std::true_type{}, std::true_type{});
                 __builtin_amdgcn_s_setprio(0);
+                if (!lane_valid && nrows == R) {
+                    // unchanged by construction (and possibly computed from rows that were not staged): memory has it
+#pragma unroll
+                    for (int k = 0; k < 4; k++) mp[k] = in[k] ? q_mo[R - 1][k] : INF;
+                }
             }
             else if (nrows == R) {
                 // nothing can change in this slot during the batch: its last row is what memory holds
@@ -1811,12 +1830,21 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
             plo = min(plo, min((t1 & 0xffff) - 2 * R - 3, (t2 & 0xffff) - R - 3));
             phi = max(phi, max((t1 >> 16) + 2 * R + 3, (t2 >> 16) + R + 3));
             issue_full = (plo <= own_hi && phi >= own_lo);
+            lane_all = false;
+            plo_l = plo - (TW_LANE_MARGIN - R); phi_l = phi + (TW_LANE_MARGIN - R);
         }
         y += R;
         kpar ^= 1;
         force_active = false;
         }
-        if (y_issue >= 0) { issue(y_issue, issue_full); loads_full = issue_full; }
+        if (y_issue >= 0) {
+            // per lane: whatever can be within TW_LANE_MARGIN columns of the changes when the batch is computed (plo / phi
+            // already contain the R columns of the slot test)
+            const int xl = B + OWN * slot - R + 4 * lane;
+            lane_staged = issue_full && (lane_all || (xl + 3 >= plo_l && xl <= phi_l));
+            issue(y_issue, lane_staged);
+            loads_full = issue_full;
+        }
         if (just_rebased) {
             landed();                        // before anybody stores rows >= y
             __syncthreads();
