@@ -2982,8 +2982,8 @@ static int frozen_catchup(LqrHipBatch *b, int to, int w_at_to, int h)
 }
 
 // batches up to this many pixels use the tiled full-width update (measured break-even with the band kernel at 4K, Mseams*px/s
-// tiled / band: 8 images 122 k / 99 k, 9: 110 / 109, 10: 116 / 120, 12: 130 / 139, 16: 158 / 175)
-static const long long g_tiled_update_px = 9LL * 3840 * 2160;
+// tiled / band: 7 images 118 k / 97 k, 8: 130 / 109, 9: 119 / 121, 12: 130 / 139+, 16: 158 / 175+)
+static const long long g_tiled_update_px = 8LL * 3840 * 2160;
 
 // One seam of a lock-step batch: k_vpath* (pick + backtrack, publishes the side to move) -> k_carve ->
 // k_emap_update -> one form of update_mmap (or the full DP after a side switch), all on the batch's stream.

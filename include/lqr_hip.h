@@ -156,7 +156,7 @@ int lqrhip_read_working(LqrHipCarver *c, int w, int h, float *en, float *m, int 
 /* 0 off; 1 HIP-event pairs around every kernel of the seam loop; 2 around k_carve only (each pair costs ~10 us
  * of queue time, so the bench's timed region uses 2 and takes the other kernels' times from rocprofv3) */
 void lqrhip_prof_enable(int on);
-/* how E9 (update_mmap) runs: -1 by batch size (tiled full-width keep-rule sweep up to ~9 4K images, the band
+/* how E9 (update_mmap) runs: -1 by batch size (tiled full-width keep-rule sweep up to 8 4K images, the band
  * kernel k_band_update_tw above), 0 band kernel always, 1 tiled sweep whenever its grid fits the device,
  * 2 the per-row-barrier band kernel k_band_update_mw (the default for rows wider than 4200 px) */
 void lqrhip_set_update_mode(int mode);
