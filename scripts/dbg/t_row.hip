@@ -137,6 +137,49 @@ __global__ __launch_bounds__(128) void k_rows2(const float *src, float *big, uns
     img[60000 + lane] = mp[0] + mp[1] + mp[2] + mp[3];
 }
 
+// several waves of one workgroup (one CU, different SIMDs) walking rows at the same time, as two active slots of the band
+// kernel do: do they slow each other down?
+template <int NC>
+__global__ __launch_bounds__(64 * NC) void k_rowsN(const float *src, float *big, unsigned long long *cyc, int iters, int stride)
+{
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    constexpr int R = 16;
+    float *img = big + (size_t) (blockIdx.x * NC + q) * ((size_t) stride * 2800);
+    f32x4 q_e[R], q_mo[R];
+    uint32_t q_lo[R];
+    for (int r = 0; r < R; r++) {
+        q_e[r] = *(const f32x4 *) (src + (r * 64 + lane) * 4);
+        q_mo[r] = *(const f32x4 *) (src + 8192 + (r * 64 + lane) * 4);
+        q_lo[r] = __float_as_uint(src[16384 + r * 64 + lane]) & 0x01ff01ffu;
+    }
+    float mp[4] = {src[lane], src[lane + 64], src[lane + 128], src[lane + 192]};
+    const bool in[4] = {true, true, true, true};
+    const bool own = lane >= 4 && lane < 60;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+        unsigned so = (unsigned) ((it * R) % 2100) * (unsigned) stride + 1 + 4 * lane, so4 = so * 4u;
+#pragma unroll
+        for (int r = 0; r < R; r++, so += (unsigned) stride, so4 += 4u * (unsigned) stride) {
+            asm volatile("" : "+v"(so), "+v"(so4));
+            float mc[4];
+            uint32_t lnew = 0;
+            bool ch[4];
+            const float left = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[3]), DPP_WAVE_SHR1, 0xf, 0xf, true));
+            const float right = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[0]), DPP_WAVE_SHL1, 0xf, 0xf, true));
+            dp_row4<false, false, true, false>(mp, left, right, q_e[r], q_mo[r], q_lo[r], in, 0.f, 0.f, mc, lnew, ch);
+            if (own) {
+                *(f32x4 *) ((char *) img + so4) = f32x4{mc[0], mc[1], mc[2], mc[3]};
+                *(uint32_t *) ((char *) img + (size_t) stride * 2200 * 4 + so) = lnew;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) mp[k] = mc[k];
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (lane == 0 && q == 0) cyc[blockIdx.x] = t1 - t0;
+    img[60000 + lane] = mp[0] + mp[1] + mp[2] + mp[3];
+}
+
 int main()
 {
     setvbuf(stdout, nullptr, _IONBF, 0);
@@ -182,6 +225,22 @@ int main()
             (void) hipMemcpy(c, cyc, grid * 8, hipMemcpyDeviceToHost);
             double sum = 0; for (int i = 0; i < grid; i++) sum += c[i];
             printf("2 waves, 4K stride, partner %s: %.1f cycles per row\n", (const char *[]){"exits", "spins", "prefetches"}[var], sum / grid / (500 * 16.0));
+        }
+    }
+    {
+        const int stride = 3904, grid = 32;
+        float *big3; (void) hipMalloc(&big3, (size_t) grid * 4 * stride * 2800 * 4);
+        for (int nc : {1, 2, 4}) {
+            for (int rep = 0; rep < 2; rep++) {
+                if (nc == 1) hipLaunchKernelGGL(k_rowsN<1>, dim3(grid), dim3(64), 0, 0, src, big3, cyc, 500, stride);
+                else if (nc == 2) hipLaunchKernelGGL(k_rowsN<2>, dim3(grid), dim3(128), 0, 0, src, big3, cyc, 500, stride);
+                else hipLaunchKernelGGL(k_rowsN<4>, dim3(grid), dim3(256), 0, 0, src, big3, cyc, 500, stride);
+                (void) hipDeviceSynchronize();
+            }
+            unsigned long long c[256];
+            (void) hipMemcpy(c, cyc, grid * 8, hipMemcpyDeviceToHost);
+            double sum = 0; for (int i = 0; i < grid; i++) sum += c[i];
+            printf("%d wave(s) of one workgroup walking rows at once (conditional stores): %.1f cycles per row\n", nc, sum / grid / (500 * 16.0));
         }
     }
     return 0;
