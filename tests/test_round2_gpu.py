@@ -325,3 +325,32 @@ def test_batch_with_attached_carvers_enlarges_in_steps(oracle, engine):
             assert np.array_equal(a.read_scanlines()[0], b)
         assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"])
         c.destroy()
+
+
+@pytest.mark.parametrize("kind,w,h,n_seams", [("photo", 1500, 700, 60), ("noise", 2000, 333, 50), ("noise", 1024, 1201, 30),
+                                              ("photo", 1300, 66, 30), ("noise", 3000, 97, 25)])
+def test_dp_planes_on_images_wider_than_the_band_window(oracle, engine, kind, w, h, n_seams):
+    """images wider than the band kernel's 896-column window, so that the window follows the seam, slots straddle the
+    changes and (lane staging) only part of a slot's lanes is loaded and stored: en, m and the back
+    pointers after the last incremental update must equal the oracle's bit for bit, for every form of update_mmap"""
+    img = D.photo_like(w, h, w + h) if kind == "photo" else D.noise(w, h, w + h)
+    engine.lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]
+    oracle.lqrx_set_debug(1)
+    c, _ = H.init_carver(oracle, img, w - n_seams, h, switch_freq=0)
+    assert c.resize(w - n_seams, h) == L.LQR_OK
+    ea, ma, da = c.debug_snapshot()
+    oracle.lqrx_set_debug(0)
+    c.destroy()
+    try:
+        for mode in (-1, 0, 2):
+            engine.lib.lqrhip_set_update_mode(mode)
+            engine.lqrx_set_debug(1)
+            c, _ = H.init_carver(engine, img, w - n_seams, h, switch_freq=0)
+            assert c.resize(w - n_seams, h) == L.LQR_OK
+            eb, mb, db = c.debug_snapshot()
+            engine.lqrx_set_debug(0)
+            c.destroy()
+            assert np.array_equal(ea, eb) and np.array_equal(ma, mb) and np.array_equal(da[1:], db[1:]), (kind, w, h, mode)
+    finally:
+        engine.lqrx_set_debug(0)
+        engine.lib.lqrhip_set_update_mode(-1)
