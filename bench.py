@@ -69,6 +69,9 @@ def parse():
                          "throughput, but every kernel then shares the chip and the per-launch roofline figure drops")
     ap.add_argument("--update-mode", type=int, default=-1,
                     help="update_mmap kernel: -1 the engine's choice, 0 band, 1 tiled full width, 2 band-mw")
+    ap.add_argument("--band-kernel", type=int, default=None,
+                    help="A/B hook (experiments build): 0 k_band_update_tw, 1 k_band_update_td<4 px>, 2 k_band_update_td<2 px>, 3 k_band_update_ls")
+    ap.add_argument("--band-variant", type=int, default=0, help="A/B hook for band-kernel experiments")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--switch-freq", type=int, default=2, help="lqr side switch frequency (plug-in: 2, render.c:237)")
@@ -174,6 +177,13 @@ def main():
     lib.lqrhip_set_sub_batches(args.sub_batches)
     lib.lqrhip_set_update_mode.argtypes = [C.c_int]
     lib.lqrhip_set_update_mode(args.update_mode)
+    if args.band_kernel is not None or args.band_variant:      # only in a -DLQR_BAND_EXPERIMENTS build of the library
+        if not hasattr(lib, "lqrhip_set_band_kernel"):
+            raise SystemExit("bench.py: --band-kernel / --band-variant need a library built with -DLQR_BAND_EXPERIMENTS")
+        lib.lqrhip_set_band_kernel.argtypes = [C.c_int]
+        lib.lqrhip_set_band_kernel(args.band_kernel or 0)
+        lib.lqrhip_set_band_variant.argtypes = [C.c_int]
+        lib.lqrhip_set_band_variant(args.band_variant)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

@@ -1853,6 +1853,10 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
     if (tid == 0) c.flags[FLAG_OVF_ROW] = ovf;
 }
 
+#ifdef LQR_BAND_EXPERIMENTS
+#include "band_experiments.inc"
+#endif
+
 // ---------------------------------------------------------------------------
 // E5 build_mmap, multi-CU form (delta_x == 1, no rigidity mask): trapezoid tiling of the
 // dependency cone.  One launch covers DPT_ROWS rows of every image; one WAVE per tile of
@@ -2778,6 +2782,20 @@ static int g_update_mode = -1;
 // -1: by batch size (g_tiled_update_px); 0: band kernel (k_band_update_tw); 1: tiled full-width update whenever its
 // grid fits; 2: the per-row-barrier band kernel (k_band_update_mw)
 extern "C" void lqrhip_set_update_mode(int mode) { g_update_mode = mode; }
+#ifdef LQR_BAND_EXPERIMENTS
+// which trapezoid band kernel update mode 0 (and the engine's own choice for large batches) means:
+// 0 k_band_update_tw, 1 k_band_update_td<4 px per lane, 4 slots>, 2 k_band_update_td<2, 8>
+static int g_band_kernel = 0;
+extern "C" void lqrhip_set_band_kernel(int k) { g_band_kernel = k; }
+static int g_band_variant = 0;
+extern "C" void lqrhip_set_band_variant(int v) { g_band_variant = v; }
+static int g_band_repeat = 1;
+extern "C" void lqrhip_set_band_repeat(int n) { g_band_repeat = n; }
+#ifdef LQR_BAND_TIMING
+extern "C" int lqrhip_ls_hist(unsigned long long *out) { (void) hipDeviceSynchronize(); return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ls_hist), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1; }
+extern "C" int lqrhip_band_timing(unsigned long long *out) { (void) hipDeviceSynchronize(); return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_band_dbg), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -1; }
+#endif
+#endif
 static int g_dpp_limit_override = -1;
 static int g_dpp_px_override = 0;       // test hook: 2 or 4 pins the persistent sweep's pixels per lane (0 = by batch size)
 extern "C" void lqrhip_set_dp_persistent_px(int px) { g_dpp_px_override = (px == 2 || px == 4) ? px : 0; }
@@ -3055,6 +3073,25 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     // the trapezoid-wave band kernel takes rows up to ~4200 px (wider rows: the changes outgrow its 896-column window
     // too often, and an 8-slot build spills registers); beyond that, and in update mode 2, k_band_update_mw
     const bool band_tw = fast_band && g_update_mode != 2 && wnew <= 4200 && (size_t) 2 * h * sizeof(int) <= 64 * 1024;
+#ifdef LQR_BAND_EXPERIMENTS
+    if (band_tw && g_band_kernel == 3 && ls_lds_bytes(2, 7, h) <= 160 * 1024) {
+        ProfScope ps("band_update", b->stream, 0);
+        const size_t lds = ls_lds_bytes(2, 7, h);
+#define LAUNCH_LS(LRV, RIGV) do { HIPCK(hipFuncSetAttribute((const void *) k_band_update_ls<2, 7, LRV, RIGV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
+                                  hipLaunchKernelGGL((k_band_update_ls<2, 7, LRV, RIGV>), dim3(n), dim3(ls_threads(7)), lds, b->stream, b->d_desc, k, wnew, h, stride, g_dev_err, g_band_variant); } while (0)
+        if (leftright_next) { if (p->use_rigidity) LAUNCH_LS(true, true); else LAUNCH_LS(true, false); }
+        else { if (p->use_rigidity) LAUNCH_LS(false, true); else LAUNCH_LS(false, false); }
+#undef LAUNCH_LS
+    } else if (band_tw && g_band_kernel != 0) {
+        ProfScope ps("band_update", b->stream, 0);
+#define LAUNCH_TD(PXV, NWV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_td<PXV, NWV, LRV, RIGV>), dim3(n), dim3(128 * NWV), (size_t) 2 * h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, g_dev_err, g_band_variant)
+#define LAUNCH_TD_LR(PXV, NWV) do { if (leftright_next) { if (p->use_rigidity) LAUNCH_TD(PXV, NWV, true, true); else LAUNCH_TD(PXV, NWV, true, false); } \
+                                    else { if (p->use_rigidity) LAUNCH_TD(PXV, NWV, false, true); else LAUNCH_TD(PXV, NWV, false, false); } } while (0)
+        for (int rep = 0; rep < g_band_repeat; rep++) { if (g_band_kernel == 1) LAUNCH_TD_LR(4, 4); else LAUNCH_TD_LR(2, 8); }
+#undef LAUNCH_TD_LR
+#undef LAUNCH_TD
+    } else
+#endif
     if (band_tw) {
         ProfScope ps("band_update", b->stream, 0);
 #define LAUNCH_TW(LRV, RIGV) hipLaunchKernelGGL((k_band_update_tw<4, LRV, RIGV>), dim3(n), dim3(128 * 4), (size_t) 2 * h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, g_dev_err)

@@ -29,4 +29,9 @@ def engine():
     """The HIP engine through its C ABI.  Fails loudly (no fallback) if the library
     or the GPU is missing."""
     import lqr_ctypes
-    return lqr_ctypes.engine_api()
+    api = lqr_ctypes.engine_api()
+    if os.environ.get("LQR_BAND_KERNEL"):          # A/B runs of the suite against one band-kernel variant (-DLQR_BAND_EXPERIMENTS builds)
+        import ctypes
+        api.lib.lqrhip_set_band_kernel.argtypes = [ctypes.c_int]
+        api.lib.lqrhip_set_band_kernel(int(os.environ["LQR_BAND_KERNEL"]))
+    return api
