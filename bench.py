@@ -8,32 +8,46 @@ pick/backtrack -> carve) over one batch of synthetic
 images that are already resident in HBM.  Default workload = config 4 of
 BASELINE.json ("batch of 64 independent 4K RGBA images, 200 seams each"): every
 rank carves its own batch of 64 images of 3840x2160 RGBA by 200 vertical seams as
-one lock-step batch (--images-per-gpu 8 gives the literal 64/8 shard); images are
-independent, so there is no data-path collective and scaling is weak.
---workload single4k | fhd | 8k run configs 3 / 2 / 5's geometry instead.
+one lock-step batch; images are independent, so there is no data-path collective
+and scaling is weak.  With N > 1 the same invocation afterwards also runs config 4
+AS STATED -- 64 images in total, 64 / N per GPU -- and reports it as `strong` on the
+same JSON line (--strong makes that the timed workload itself).
+--workload single4k | fhd | 8k run configs 3 / 2 / 5's geometry; --workload config5
+is config 5 as stated: 7680x4320 RGBA, preservation ellipse (+1000), discard band
+(-1000) at x in [1500, 2100), rigidity 10, 1000 seams (--delta 2, --rigmask for its
+variants; src/render.c:224-233,781-792).
 
 Memory: ONE set of carvers per rank, whatever K and W are.  The input batch is
 generated on the GPU once and stays in HBM; every step starts by re-loading the
 carvers from it (lqrx_carver_reload_device_batch: a device-to-device copy, the
-HBM-resident analogue of lqr_carver_new's buffer hand-over, src/render.c:222) and
-that copy is INSIDE the timed region.  The three phases the reference brackets
-with __CLOCK_IT__ (src/render.c:214-217 read, :314-316 resize, :358-362 write)
-map to: image generation + first upload (untimed, reported as setup_s), the K
-timed steps, and the read-out + gather after the timed region (gather_ms).
+HBM-resident analogue of lqr_carver_new's buffer hand-over, src/render.c:222), adds
+the masks where the workload has them (host buffers, as the plug-in hands them over,
+src/io_functions.c:94-95,125-126) and resizes; all of that is INSIDE the timed region.
 
 value = Mseams*px/s over ALL ranks = sum over phases (n_seams * W * H) * images
 * K / wall time; wall time = max over ranks of the time of exactly K steps,
 bracketed by barrier + device synchronize on both sides.
 
+The three phases the reference brackets with __CLOCK_IT__ (src/render.c:214-217
+read, :314-316 + :358-362 resize, :437-440 write) are reported under `phases`:
+upload_ms (lqr_carver_new + lqr_carver_init of every image from HOST memory),
+resize_ms (= ms_per_step), readout_ms (every result back to host memory), and
+value_end_to_end is the metric over their sum -- the PCIe-inclusive figure; it is
+never `value`.
+
 Run with --gpus N > 1 and no RANK in the environment, the script re-executes
 itself under torch.distributed.run with N ranks (one per GPU, RCCL).
 
 Also on the JSON line:
-  roofline      the dominant HBM kernel (k_carve), HIP-event timed on its own
-                stream inside the timed region; achieved = algorithmic bytes
-                (8 B x W*H/2 per image per launch) / mean launch
-                time; peak 8 TB/s nominal, measured_copy_peak = this device's
-                own 16-B streaming-copy rate (read+write).
+  roofline      the dominant HBM kernel (k_carve), HIP-event timed per launch on its
+                own stream(s) inside the timed region.  achieved = algorithmic bytes
+                (8 B x W*H/2 per image per launch) / the time during which
+                a carve was running (launches of sub-batch streams overlap: the union of
+                their intervals, not the sum); avg_launch_us is the plain mean per launch
+                (what rocprofv3 --kernel-trace reports).  peak 8 TB/s nominal,
+                measured_copy_peak = this device's own 16-B streaming-copy rate.
+                end_to_end = the whole step against the roof: value x (4 B carve + 9 B x
+                full DPs per phase / seams per phase) / 8 TB/s.
   cpu_baseline  the CPU oracle (oracle/, a port -- real liblqr is not available
                 here) timed on this host: one image on one core, and one image
                 per core on all cores for the batch workload (nproc stated).
@@ -48,9 +62,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# --sub-batches N (opt-in) runs the batch on N HIP streams; each needs a hardware queue of its own and the HIP runtime's
-# default is 4 per process, shared with torch's streams.  The variable must be in the environment before the first HIP
-# call of the process, i.e. before torch is imported; it changes nothing for the default single-stream run.
+# Large batches run on 4 HIP streams (sub-batches: the latency-bound chain kernels of one under the bandwidth-bound carve
+# of another, +10 %).  Each stream needs a hardware queue of its own and the HIP runtime's default is 4 per process,
+# shared with torch's streams; with fewer queues than streams the split is slower than one stream, so the engine only
+# makes it when this variable says there are 8 or more.  It must be in the environment before the first HIP call of the
+# process, i.e. before torch is imported.  INTEGRATION.md says the same to a host application.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
@@ -59,20 +75,26 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="batch4k", choices=["batch4k", "single4k", "fhd", "8k"])
+    ap.add_argument("--workload", default="batch4k", choices=["batch4k", "single4k", "fhd", "8k", "config5"])
     ap.add_argument("--images-per-gpu", type=int, default=64)
+    ap.add_argument("--strong", action="store_true",
+                    help="config 4 as stated: 64 images in total, 64 // N per GPU (scaling: strong)")
     ap.add_argument("--seams", type=int, default=None)
+    ap.add_argument("--delta", type=int, default=1, help="delta_x (lqr_carver_init, render.c:224); the plug-in's UI offers up to 10")
+    ap.add_argument("--rigidity", type=float, default=None, help="rigidity (default: 10 for config5, else 0)")
+    ap.add_argument("--rigmask", action="store_true", help="config5 variant: rigidity mask over the top half (rigidity x 3, render.c:784-787)")
     ap.add_argument("--kernel-times", action="store_true",
                     help="HIP-event time every kernel of the seam loop (kernels_ms), not only k_carve; costs ~2.5 %% of the step")
-    ap.add_argument("--sub-batches", type=int, default=1,
-                    help="split the batch over this many HIP streams (chain kernels of one under the carve of another): more "
-                         "throughput, but every kernel then shares the chip and the per-launch roofline figure drops")
+    ap.add_argument("--sub-batches", type=int, default=0,
+                    help="HIP streams the batch is split over (chain kernels of one sub-batch under the carve of another); "
+                         "0 = the engine's choice: 4 for 32 images and more, given GPU_MAX_HW_QUEUES >= 8 (set above)")
     ap.add_argument("--update-mode", type=int, default=-1,
                     help="update_mmap kernel: -1 the engine's choice, 0 band, 1 tiled full width, 2 band-mw")
     ap.add_argument("--band-kernel", type=int, default=None,
                     help="A/B hook (experiments build): 0 k_band_update_tw, 1 k_band_update_td<4 px>, 2 k_band_update_td<2 px>, 3 k_band_update_ls")
     ap.add_argument("--band-variant", type=int, default=0, help="A/B hook for band-kernel experiments")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-phases", action="store_true", help="skip the upload / read-out phase measurement")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--switch-freq", type=int, default=2, help="lqr side switch frequency (plug-in: 2, render.c:237)")
     return ap.parse_args()
@@ -83,13 +105,26 @@ WORKLOADS = {
     "batch4k": (3840, 2160, 3640, 2160),      # config 4, per-GPU shard
     "single4k": (3840, 2160, 3340, 1660),     # config 3
     "fhd": (1920, 1080, 1720, 1080),          # config 2
-    "8k": (7680, 4320, 6680, 4320),           # config 5 geometry (no masks)
+    "8k": (7680, 4320, 6680, 4320),           # config 5's geometry, no masks, no rigidity
+    "config5": (7680, 4320, 6680, 4320),      # config 5 as stated
 }
 
 
 def work_seam_px(w, h, nw, nh):
     """sum over phases of n_seams * W_start * H_start (HOR order)"""
     return abs(w - nw) * w * h + abs(h - nh) * nw * h
+
+
+def alg_bytes_per_seam_px(w, h, nw, nh, switch_freq):
+    """Algorithmic HBM bytes per seam*px of the whole step with the schedule the engine runs: the carve moves
+    one 4-byte plane over half a row, read + write (4 B per seam*px), and a full DP (9 B/px) runs once at the start of a
+    phase and once after each of the `switch_freq` side switches."""
+    work, by = 0.0, 0.0
+    for n, ww, hh in ((abs(w - nw), w, h), (abs(h - nh), nw, h)):
+        if n:
+            work += n * ww * hh
+            by += 4.0 * n * ww * hh + 9.0 * ww * hh * (1 + min(switch_freq, max(n - 1, 0)))
+    return by / work if work else 0.0
 
 
 def make_images(n, w, h, seed, device):
@@ -123,6 +158,24 @@ def make_images(n, w, h, seed, device):
     return out_all
 
 
+def config5_masks(w, h, rigmask):
+    """config 5's layers, RGBA u8 as the plug-in reads them from GIMP layers: a filled
+    white ellipse at the centre covering a quarter of the image (preservation), a white band x in [1500, 2100)
+    (discard), and -- variant -- the top half (rigidity mask); same shapes as tests/datasets.py"""
+    import numpy as np
+    yy = (np.arange(h, dtype=np.float32)[:, None] - (h - 1) / 2) / (h / 2)
+    xx = (np.arange(w, dtype=np.float32)[None, :] - (w - 1) / 2) / (w / 2)
+    pres = np.zeros((h, w, 4), np.uint8)
+    pres[(xx * xx + yy * yy) <= 0.25 * 4 / np.pi] = 255
+    disc = np.zeros((h, w, 4), np.uint8)
+    disc[:, 1500 * w // 7680:2100 * w // 7680] = 255
+    rig = None
+    if rigmask:
+        rig = np.zeros((h, w, 4), np.uint8)
+        rig[: h // 2] = 255
+    return pres, disc, rig
+
+
 def spawn_command(gpus, argv):
     """the launcher line the driver uses for N > 1: one rank per GPU of one node, rendezvous on 127.0.0.1"""
     s = socket.socket()
@@ -137,6 +190,11 @@ def self_spawn(args):
     """--gpus N without a launcher: become N ranks under torch.distributed.run (one per GPU)"""
     cmd = spawn_command(args.gpus, sys.argv[1:])
     os.execvp(cmd[0], cmd)
+
+
+def strong_images_per_gpu(world, total=64):
+    """config 4 as stated: `total` images over `world` GPUs"""
+    return max(1, total // max(world, 1))
 
 
 def cpu_model():
@@ -175,6 +233,7 @@ def main():
         raise SystemExit("bench.py: torch sees no GPU")
     lib.lqrhip_set_sub_batches.argtypes = [C.c_int]
     lib.lqrhip_set_sub_batches(args.sub_batches)
+    lib.lqrhip_sub_batches.argtypes = [C.c_int]
     lib.lqrhip_set_update_mode.argtypes = [C.c_int]
     lib.lqrhip_set_update_mode(args.update_mode)
     if args.band_kernel is not None or args.band_variant:      # only in a -DLQR_BAND_EXPERIMENTS build of the library
@@ -193,9 +252,18 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     W, H, NW, NH = WORKLOADS[args.workload]
-    nimg = args.images_per_gpu if args.workload == "batch4k" else 1
+    batch = args.workload == "batch4k"
+    nimg = args.images_per_gpu if batch else 1
+    if batch and args.strong:
+        nimg = strong_images_per_gpu(world)
     if args.seams is not None:
         NW = W - args.seams
+    rigidity = args.rigidity if args.rigidity is not None else (10.0 if args.workload == "config5" else 0.0)
+    pres = disc = rigm = None
+    if args.workload == "config5":
+        pres, disc, rigm = config5_masks(W, H, args.rigmask)
+        if rigm is not None:
+            rigidity *= 3           # render.c:784-787
 
     def sync():
         rc = lib.lqrhip_device_sync()
@@ -211,48 +279,73 @@ def main():
         lib.lqrhip_mem_info(C.byref(f), C.byref(t), C.byref(c))
         return (t.value - f.value) / 1e9, t.value / 1e9
 
-    # ---- phase "read" (render.c:214-217): inputs generated on the GPU, resident in HBM from here on;
-    # ONE set of carvers, created (working planes allocated) before the timed region
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- phase "read" (render.c:214-217, 220-224): inputs generated on the GPU and kept in HBM for the timed steps; the
+    # carvers are created from HOST copies of them, as the plug-in creates its carver from a host buffer -- that is the
+    # measured upload phase (lqr_carver_new uploads, lqr_carver_init allocates the working planes)
     t_setup = time.perf_counter()
     images = make_images(nimg, W, H, 100 + rank * nimg, dev)
     torch.cuda.synchronize()
-    img0_host = images[0].cpu().numpy()
+    host_imgs = [images[i].cpu().numpy() for i in range(nimg)]
     ptrs = [images[i].data_ptr() for i in range(nimg)]
-    carvers = []
-    for i in range(nimg):
-        c = L.Carver(eng, img0_host if i == 0 else np.zeros((H, W, 4), np.uint8))      # pixels come from `images` at every step
+    bufs = [L._malloc_copy(im) for im in host_imgs]      # liblqr takes ownership of a malloc'ed buffer (render.c:222)
+    sync()
+    tu = time.perf_counter()
+    carvers = [L.Carver.from_buffer(eng, bufs[i], W, H, 4, delta_x=args.delta, rigidity=rigidity) for i in range(nimg)]
+    sync()
+    upload_ms = (time.perf_counter() - tu) * 1e3
+    for c in carvers:
         c.configure(switch_freq=args.switch_freq, enl_step=1.5)                          # plug-in defaults, main.c:62-87
-        carvers.append(c)
+    img0_host = host_imgs[0]
+    host_keep = host_imgs[:min(nimg, os.cpu_count() or 1)]      # for the all-cores CPU baseline
+    del host_imgs
     sync()
     t_setup = time.perf_counter() - t_setup
 
-    def run_step():
-        ret = L.reload_device_batch(eng, carvers, ptrs)
+    def add_masks(cs):
+        # render.c:225-233 (pres_coeff / disc_coeff defaults 1000, main.c:62-87)
+        for c in cs:
+            if pres is not None:
+                assert c.bias_add(pres, 1000) == L.LQR_OK
+            if disc is not None:
+                assert c.bias_add(disc, -1000) == L.LQR_OK
+            if rigm is not None:
+                assert c.rigmask_add(rigm) == L.LQR_OK
+
+    def run_step(cs, ps):
+        ret = L.reload_device_batch(eng, cs, ps)
         assert ret == L.LQR_OK, "reload failed: %d (%s)" % (ret, lib.lqrhip_last_error().decode())
-        if len(carvers) == 1:
-            ret = carvers[0].resize(NW, NH)
+        add_masks(cs)
+        if len(cs) == 1:
+            ret = cs[0].resize(NW, NH)
         else:
-            ret = L.resize_batch(eng, carvers, NW, NH)
+            ret = L.resize_batch(eng, cs, NW, NH)
         assert ret == L.LQR_OK, "resize failed: %d (%s)" % (ret, lib.lqrhip_last_error().decode())
 
+    def timed(cs, ps, steps, warmup, prof_mode):
+        for _ in range(warmup):
+            run_step(cs, ps)
+        lib.lqrhip_prof_reset()
+        lib.lqrhip_prof_enable(prof_mode)
+        barrier(); sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run_step(cs, ps)
+        sync(); barrier()
+        t1 = time.perf_counter()
+        lib.lqrhip_prof_enable(0)
+        return max_over_ranks(t1 - t0)
+
     # ---- phase "resize" (render.c:314-316): W warm-up steps, then exactly K timed steps
-    for _ in range(args.warmup):
-        run_step()
-    lib.lqrhip_prof_reset()
-    lib.lqrhip_prof_enable(1 if args.kernel_times else 2)
-    barrier(); sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
-    sync(); barrier()
-    t1 = time.perf_counter()
-    lib.lqrhip_prof_enable(0)
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(carvers, ptrs, args.steps, args.warmup, 1 if args.kernel_times else 2)
     used_gb, total_gb = mem_used_gb()
+    streams = lib.lqrhip_sub_batches(nimg) if nimg > 1 else 1
 
     # ---- per-kernel HIP-event times collected inside the timed region
     def prof(name):
@@ -261,21 +354,31 @@ def main():
         return ms.value, n.value, by.value
     kern = {k: prof(k) for k in ("carve", "vpath", "band_update", "dp_update", "dp_update_tiled", "dp_sweep", "emap_update")}
     c_ms, c_n, c_bytes = kern["carve"]
+    work_rank = work_seam_px(W, H, NW, NH) * nimg * args.steps       # seam*px per rank
+    value = work_rank * world / elapsed / 1e6
     roofline = None
     if c_n:
-        achieved = c_bytes / (c_ms * 1e-3) / 1e9
+        un = C.c_double(0)
+        lib.lqrhip_prof_get_union.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
+        lib.lqrhip_prof_get_union(b"carve", C.byref(un))
+        active_ms = un.value if un.value > 0 else c_ms
+        achieved = c_bytes / (active_ms * 1e-3) / 1e9
         # HBM traffic of k_carve per launch from the committed rocprofv3 PMC passes of this command
         # (separate FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
-        # note), scaled from the profiled batch size to this run's; null if the profile is missing
+        # note), scaled from the profiled images per launch to this run's; null if the profile is missing
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_k_carve.json")
-        if os.path.exists(pmc) and args.workload == "batch4k" and args.seams is None:
+        if os.path.exists(pmc) and batch and args.seams is None:
             pj = json.load(open(pmc))
-            traffic = round((2 * pj["fetch_size_kb_mean"] + pj["write_size_kb_mean"]) * 1024 / pj["images_per_launch"] * nimg)
+            traffic = round((2 * pj["fetch_size_kb_mean"] + pj["write_size_kb_mean"]) * 1024 / pj["images_per_launch"] * nimg / streams)
+        b_alg = alg_bytes_per_seam_px(W, H, NW, NH, args.switch_freq)
         roofline = {"bound": "hbm", "kernel": "k_carve", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                    "avg_launch_us": round(c_ms * 1e3 / c_n, 2), "launches": c_n,
-                    "alg_bytes_per_launch": round(c_bytes / c_n)}
+                    "carve_active_ms": round(active_ms, 3), "sum_of_launches_ms": round(c_ms, 3),
+                    "avg_launch_us": round(c_ms * 1e3 / c_n, 2), "launches": c_n, "streams": streams,
+                    "alg_bytes_per_launch": round(c_bytes / c_n),
+                    "end_to_end": {"bytes_per_seam_px": round(b_alg, 4), "achieved": round(value * b_alg * 1e-3 / max(world, 1), 1),
+                                   "unit": "GB/s per GPU", "frac": round(value * b_alg * 1e-3 / max(world, 1) / 8000.0, 4)}}
         if rank == 0:
             # this device's own ceiling: 16-B streaming copy of 2 GiB (read + write), outside the timed region
             g = C.c_double(0)
@@ -284,7 +387,18 @@ def main():
                 roofline["measured_copy_peak"] = round(g.value, 1)
                 roofline["frac_of_measured"] = round(achieved / g.value, 4)
 
-    # ---- phase "write" (render.c:358-362): results of the last step, gathered to rank 0 over RCCL
+    # ---- phase "write" (render.c:358-362, io_functions.c:134-182): every result of the last step back to host memory
+    # (device compaction of the visible pixels + D2H; the scan-line loop of io_functions.c:155-164 is served from that
+    # host copy), then -- N > 1 -- the gather to rank 0 over RCCL
+    readout_ms = None
+    if not args.no_phases:
+        sync()
+        tr = time.perf_counter()
+        host_out = [c.read_image() for c in carvers]
+        readout_ms = max_over_ranks((time.perf_counter() - tr) * 1e3)
+        assert host_out[0].shape == (NH, NW, 4)
+        del host_out
+        upload_ms = max_over_ranks(upload_ms)
     gather_ms = None
     outs = torch.empty((nimg, NH, NW, 4), dtype=torch.uint8, device=dev)
     if carvers[0].getters()["orientation"] == 0:
@@ -305,19 +419,24 @@ def main():
     g = carvers[0].getters()
     assert (g["width"], g["height"]) == (NW, NH), g
 
-    work = work_seam_px(W, H, NW, NH) * nimg * args.steps       # seam*px per rank
-    value = work * world / elapsed / 1e6
-
+    ms_per_step = elapsed * 1e3 / args.steps
+    mode = "strong" if (batch and args.strong) else "weak"
+    variant = ""
+    if args.workload == "config5":
+        variant = ", preservation ellipse +1000, discard band -1000, rigidity %g, delta_x %d%s" % (
+            rigidity, args.delta, ", rigidity mask (top half)" if rigm is not None else "")
+    elif args.delta != 1 or rigidity:
+        variant = ", rigidity %g, delta_x %d" % (rigidity, args.delta)
     result = {
         "metric": "Mseams*pixels/sec on 4K RGBA", "value": round(value, 1), "unit": "Mseams*px/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": mode,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d x %dx%d RGBA per GPU, resize to %dx%d (%d vertical%s seams each), side-switch %d" % (
+        "config": {"workload": "%s: %d x %dx%d RGBA per GPU, resize to %dx%d (%d vertical%s seams each), side-switch %d%s" % (
                        args.workload, nimg, W, H, NW, NH, W - NW, (" + %d horizontal" % (H - NH)) if NH != H else "",
-                       args.switch_freq),
+                       args.switch_freq, variant),
                    "images_per_gpu": nimg, "width": W, "height": H, "new_width": NW, "new_height": NH,
-                   "parallelism": "images sharded i mod N, no data-path collective", "streams_per_gpu": args.sub_batches},
+                   "parallelism": "images sharded i mod N, no data-path collective", "streams_per_gpu": streams},
         "roofline": roofline,
         "kernels_ms": {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in kern.items() if v[1]},
         "gather_ms": None if gather_ms is None else round(gather_ms, 2),
@@ -325,6 +444,23 @@ def main():
         "hbm_used_gb": round(used_gb, 1), "hbm_total_gb": round(total_gb, 1),
         "output_checksum": checksum,
     }
+    if readout_ms is not None:
+        e2e_ms = upload_ms + ms_per_step + readout_ms
+        result["phases"] = {
+            "upload_ms": round(upload_ms, 2), "resize_ms": round(ms_per_step, 3), "readout_ms": round(readout_ms, 2),
+            "value_end_to_end": round(work_rank / args.steps * world / (e2e_ms * 1e-3) / 1e6, 1),
+            "note": "upload = lqr_carver_new + lqr_carver_init of every image from pageable host memory (render.c:222-224), "
+                    "readout = every result into host memory (io_functions.c:134-182); value_end_to_end = the metric over "
+                    "upload + resize + readout; `value` itself is the HBM-resident rate"}
+
+    # ---- config 4 as stated, on the same line when N > 1: 64 images in total = 64 // N per GPU (strong scaling)
+    if batch and world > 1 and not args.strong:
+        ns = strong_images_per_gpu(world)
+        el = timed(carvers[:ns], ptrs[:ns], args.steps, 1, 0)
+        result["strong"] = {"images_total": ns * world, "images_per_gpu": ns, "scaling": "strong",
+                            "ms_per_step": round(el * 1e3 / args.steps, 3),
+                            "value": round(work_seam_px(W, H, NW, NH) * ns * args.steps * world / el / 1e6, 1),
+                            "streams_per_gpu": lib.lqrhip_sub_batches(ns) if ns > 1 else 1}
 
     # ---- CPU baseline: the oracle (a port of the algorithm; test infrastructure, loaded here only as the
     # reported baseline and the spot checker) on this host's cores
@@ -334,10 +470,15 @@ def main():
         ncores = os.cpu_count() or 1
         cw, chh, cnw, cnh = W, H, NW, NH
         sample = "1 image of the workload (%dx%d -> %dx%d), 1 core" % (cw, chh, cnw, cnh)
-        if args.workload in ("single4k", "8k"):     # bound the sample: 100 (+100) seams instead of 500+500 / 1000
+        if args.workload in ("single4k", "8k", "config5"):     # bound the sample: 100 (+100) seams instead of 500+500 / 1000
             cnw, cnh = W - 100, (H - 100 if NH != H else H)
             sample = "1 image %dx%d -> %dx%d (first %d seams of the workload), 1 core" % (cw, chh, cnw, cnh, (W - cnw) + (H - cnh))
-        oc = L.Carver(orc, img0_host).configure(switch_freq=args.switch_freq, enl_step=1.5)
+
+        def oracle_carver(im):
+            o = L.Carver(orc, im, delta_x=args.delta, rigidity=rigidity).configure(switch_freq=args.switch_freq, enl_step=1.5)
+            add_masks([o])
+            return o
+        oc = oracle_carver(img0_host)
         tc = time.perf_counter()
         assert oc.resize(cnw, cnh) == L.LQR_OK
         tc = time.perf_counter() - tc
@@ -353,17 +494,16 @@ def main():
         if nimg > 1:
             # for the batch, one image per core over all host cores (liblqr itself is single-threaded;
             # ctypes releases the GIL inside the C call, so threads run the oracle truly in parallel)
-            nt = min(ncores, nimg)
-            host_imgs = [images[i].cpu().numpy() for i in range(nt)]
+            nt = min(ncores, nimg, len(host_keep))
 
             def one(im):
-                o = L.Carver(orc, im).configure(switch_freq=args.switch_freq, enl_step=1.5)
+                o = oracle_carver(im)
                 r = o.resize(NW, NH)
                 o.destroy()
                 return r
             ta = time.perf_counter()
             with ThreadPoolExecutor(max_workers=nt) as ex:
-                rets = list(ex.map(one, host_imgs))
+                rets = list(ex.map(one, host_keep[:nt]))
             ta = time.perf_counter() - ta
             assert all(r == L.LQR_OK for r in rets)
             result["cpu_baseline"]["all_cores"] = {

@@ -159,6 +159,23 @@ class Carver:
             ret = api.lqr_carver_init(self.p, delta_x, float(rigidity))
             assert ret == LQR_OK, ret
 
+    @classmethod
+    def from_buffer(cls, api, buf, w, h, ch, delta_x=1, rigidity=0.0):
+        """lqr_carver_new + lqr_carver_init (render.c:222-224) on a malloc'ed interleaved u8 buffer the library takes
+        ownership of (_malloc_copy): the two C calls and nothing else, for callers that time the upload"""
+        self = cls.__new__(cls)
+        self.api = api
+        self.h0, self.w0, self.ch = h, w, ch
+        self._cbs = []
+        self.events = []
+        self.aux = []
+        self.p = api.lqr_carver_new(buf, w, h, ch)
+        if not self.p:
+            raise MemoryError("lqr_carver_new returned NULL")
+        ret = api.lqr_carver_init(self.p, delta_x, float(rigidity))
+        assert ret == LQR_OK, ret
+        return self
+
     # -- configuration, in the order of render.c:225-248 ------------------
     def bias_add(self, mask, factor, x_off=0, y_off=0):
         mask = np.ascontiguousarray(mask, dtype=np.uint8)

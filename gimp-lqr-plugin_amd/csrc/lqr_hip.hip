@@ -2314,20 +2314,52 @@ __global__ __launch_bounds__(256) void k_compact(const uint8_t *rgb, const int32
     }
 }
 
-__global__ void k_transpose(const uint8_t *rgb, const float *bias, const float *rig, uint8_t *nrgb, float *nbias, float *nrig,
-                            int w, int h, int ch)
+// E11 flatten for every carver of a batch in ONE launch (job table as k_inflate: blockIdx.y = job, blockIdx.x = row)
+__global__ __launch_bounds__(256) void k_compact_jobs(const InflateDev *jobs, int w0, int w, int level)
+{
+    __shared__ int s_wave[4];
+    const InflateDev j = jobs[blockIdx.y];
+    const int y = blockIdx.x, tid = threadIdx.x, ch = j.ch;
+    const int32_t *vrow = j.vs + (size_t) y * w0;
+    const size_t ri = (size_t) y * w0, ro = (size_t) y * w;
+    int carry = 0;
+    for (int base = 0; base < w0; base += 256) {
+        int col = base + tid;
+        int v = (col < w0) ? vrow[col] : 0;
+        bool keep = (col < w0) && (v == 0 || v >= level);
+        int total;
+        int rank = carry + block_rank_256(keep, s_wave, total);
+        if (keep && rank < w) {
+            px_copy(j.nrgb + (ro + rank) * ch, j.rgb + (ri + col) * ch, ch);
+            if (j.nbias) j.nbias[ro + rank] = j.bias[ri + col];
+            if (j.nrig) j.nrig[ro + rank] = j.rig[ri + col];
+        }
+        carry += total;
+    }
+}
+
+// E11 transpose of every carver of a batch in one launch (blockIdx.z = job); RGBA pixels move as dwords
+__global__ void k_transpose(const InflateDev *jobs, int w, int h)
 {
     __shared__ uint32_t t32[32][33];
     __shared__ float tb[32][33], tr[32][33];
+    const InflateDev j = jobs[blockIdx.z];
+    const uint8_t *rgb = j.rgb;
+    const float *bias = j.bias, *rig = j.rig;
+    uint8_t *nrgb = j.nrgb;
+    float *nbias = j.nbias, *nrig = j.nrig;
+    const int ch = j.ch;
     int x = blockIdx.x * 32 + threadIdx.x;
     for (int i = threadIdx.y; i < 32; i += blockDim.y) {
         int y = blockIdx.y * 32 + i;
         if (x < w && y < h) {
+            const size_t o = (size_t) y * w + x;
             uint32_t p = 0;
-            for (int k = 0; k < ch; k++) p |= (uint32_t) rgb[((size_t) y * w + x) * ch + k] << (8 * k);
+            if (ch == 4) p = *(const uint32_t *) (rgb + o * 4);
+            else for (int k = 0; k < ch; k++) p |= (uint32_t) rgb[o * ch + k] << (8 * k);
             t32[i][threadIdx.x] = p;
-            if (bias) tb[i][threadIdx.x] = bias[(size_t) y * w + x];
-            if (rig) tr[i][threadIdx.x] = rig[(size_t) y * w + x];
+            if (bias) tb[i][threadIdx.x] = bias[o];
+            if (rig) tr[i][threadIdx.x] = rig[o];
         }
     }
     __syncthreads();
@@ -2337,7 +2369,8 @@ __global__ void k_transpose(const uint8_t *rgb, const float *bias, const float *
         if (ox < w && oy < h) {
             uint32_t p = t32[threadIdx.x][i];
             size_t o = (size_t) ox * h + oy;
-            for (int k = 0; k < ch; k++) nrgb[o * ch + k] = (uint8_t) (p >> (8 * k));
+            if (ch == 4) *(uint32_t *) (nrgb + o * 4) = p;
+            else for (int k = 0; k < ch; k++) nrgb[o * ch + k] = (uint8_t) (p >> (8 * k));
             if (nbias) nbias[o] = tb[threadIdx.x][i];
             if (nrig) nrig[o] = tr[threadIdx.x][i];
         }
@@ -2462,12 +2495,18 @@ extern "C" int lqrhip_init(void)
     return dev;
 }
 
-// a kernel recorded a failure (dev_fail): report it once, as an error return, and clear the word
+// A kernel recorded a failure (dev_fail): report it once, as an error return, and clear the word.  The word is one per
+// process and whoever synchronises first finds it -- not necessarily the batch whose kernel failed.  A persistent sweep that
+// gave up half way leaves its batch's exchange area (tags, finished-tile counter) and, for an update, the plane pointers
+// in the device descriptors in an unknown state, so EVERY live batch is marked for a fresh lay-out of both.
+static std::vector<LqrHipBatch *> g_live_batches;
+static void invalidate_all_batches(void);
 static int check_dev_error(void)
 {
     if (!g_dev_err_host || *g_dev_err_host == 0) return 0;
     const int code = *g_dev_err_host;
     *g_dev_err_host = 0;
+    invalidate_all_batches();
     g_err = code == DEVERR_TILE_TIMEOUT ? "persistent tiled DP sweep: a neighbour tile never became resident (GPU shared or partitioned?); "
                                           "results of this resize are invalid"
                                         : "band update: activity prediction failed; results of this resize are invalid";
@@ -2539,6 +2578,62 @@ static hipError_t dzero(void *p, size_t bytes)
     return e != hipSuccess ? e : hipStreamSynchronize(g_stream0);
 }
 
+// Host <-> device copies of whole images.  The plug-in hands over and takes back PAGEABLE memory (a g_malloc'ed buffer at
+// lqr_carver_new, render.c:222; the scan-line buffer at read-out, io_functions.c:155-164); hipMemcpy on pageable memory
+// runs at ~1-2 GB/s here (it pins and unpins as it goes).  These go through two pinned bounce buffers instead: the CPU
+// copies chunk k + 1 into (out of) one while the DMA engine moves chunk k from (to) the other, on the shim's stream.
+// Both return with the transfer complete.
+static const size_t STAGE_BYTES = (size_t) 8 << 20;
+static uint8_t *g_stage[2] = {nullptr, nullptr};
+static hipEvent_t g_stage_ev[2] = {nullptr, nullptr};
+static int stage_init(void)
+{
+    if (g_stage[0]) return 0;
+    for (int i = 0; i < 2; i++) {
+        HIPCK(hipHostMalloc((void **) &g_stage[i], STAGE_BYTES, hipHostMallocDefault));
+        HIPCK(hipEventCreateWithFlags(&g_stage_ev[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+static int h2d_staged(void *dst, const void *src, size_t bytes)
+{
+    int rc = stage_init();
+    if (rc) return rc;
+    int k = 0;
+    for (size_t off = 0; off < bytes; off += STAGE_BYTES, k ^= 1) {
+        const size_t n = std::min(STAGE_BYTES, bytes - off);
+        HIPCK(hipEventSynchronize(g_stage_ev[k]));                 // the copy that last read this buffer is done
+        memcpy(g_stage[k], (const uint8_t *) src + off, n);
+        HIPCK(hipMemcpyAsync((uint8_t *) dst + off, g_stage[k], n, hipMemcpyHostToDevice, g_stream0));
+        HIPCK(hipEventRecord(g_stage_ev[k], g_stream0));
+    }
+    HIPCK(hipStreamSynchronize(g_stream0));
+    return 0;
+}
+static int d2h_staged(void *dst, const void *src, size_t bytes)
+{
+    int rc = stage_init();
+    if (rc) return rc;
+    // chunk k is copied out of its buffer while chunk k + 1 is in flight into the other
+    size_t off_prev = 0, n_prev = 0;
+    int k = 0;
+    for (size_t off = 0; off < bytes; off += STAGE_BYTES, k ^= 1) {
+        const size_t n = std::min(STAGE_BYTES, bytes - off);
+        HIPCK(hipMemcpyAsync(g_stage[k], (const uint8_t *) src + off, n, hipMemcpyDeviceToHost, g_stream0));
+        HIPCK(hipEventRecord(g_stage_ev[k], g_stream0));
+        if (n_prev) {
+            HIPCK(hipEventSynchronize(g_stage_ev[k ^ 1]));
+            memcpy((uint8_t *) dst + off_prev, g_stage[k ^ 1], n_prev);
+        }
+        off_prev = off; n_prev = n;
+    }
+    if (n_prev) {
+        HIPCK(hipEventSynchronize(g_stage_ev[k ^ 1]));
+        memcpy((uint8_t *) dst + off_prev, g_stage[k ^ 1], n_prev);
+    }
+    return 0;
+}
+
 static int batch_sync_of(LqrHipCarver *c)
 {
     LqrHipCarver *r = c->root ? c->root : c;
@@ -2553,8 +2648,8 @@ extern "C" LqrHipCarver *lqrhip_carver_create(const unsigned char *rgb, int w, i
     c->ch = channels; c->w0 = w; c->h0 = h;
     size_t n = (size_t) w * h;
     if (dmalloc(&c->rgb0, n * channels) || dmalloc(&c->vs, n)) { lqrhip_carver_destroy(c); return nullptr; }
-    if (hipMemcpy(c->rgb0, rgb, n * channels, hipMemcpyHostToDevice) != hipSuccess ||
-        dzero(c->vs, n * sizeof(int32_t)) != hipSuccess) {
+    // the visibility map is cleared on the same stream, under the upload: one synchronisation for both
+    if (hipMemsetAsync(c->vs, 0, n * sizeof(int32_t), g_stream0) != hipSuccess || h2d_staged(c->rgb0, rgb, n * channels) != 0) {
         g_err = "upload failed";
         lqrhip_carver_destroy(c);
         return nullptr;
@@ -2572,7 +2667,15 @@ static void free_working(LqrHipCarver *c)
 extern "C" void lqrhip_carver_destroy(LqrHipCarver *c)
 {
     if (!c) return;
-    (void) hipDeviceSynchronize();
+    // its planes may still be in use by kernels on the owning batch's stream or by the shim's own stream (resets, mask
+    // uploads, read-outs): wait for those two, not for the device (tearing a batch down was 64 device synchronisations)
+    {
+        LqrHipCarver *r = c->root ? c->root : c;
+        if (r->batch && r->batch->stream) (void) hipStreamSynchronize(r->batch->stream);
+        if (c->batch && c->batch != r->batch && c->batch->stream) (void) hipStreamSynchronize(c->batch->stream);
+        if (g_stream0) (void) hipStreamSynchronize(g_stream0);
+        (void) hipGetLastError();
+    }
     dfree(c->rgb0);
     if (!c->root) dfree(c->vs);
     dfree(c->bias0); dfree(c->rig0);
@@ -2660,14 +2763,20 @@ extern "C" int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int c
     uint8_t *dmask = nullptr;
     size_t mbytes = (size_t) width * height * channels;
     if ((rc = dmalloc(&dmask, mbytes))) return rc;
-    HIPCK(hipMemcpy(dmask, mask, mbytes, hipMemcpyHostToDevice));
-    dim3 grid((nx + 255) / 256, ny);
-    hipLaunchKernelGGL(k_mask_add, grid, dim3(256), 0, g_stream0, *plane, c->w0, dmask, channels, width, x0, y0, x1, y1, nx, ny,
-                       transposed, is_rigmask, bias_factor);
-    HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(g_stream0));
+    auto run = [&]() -> int {
+        int rcu = h2d_staged(dmask, mask, mbytes);
+        if (rcu) return rcu;
+        dim3 grid((nx + 255) / 256, ny);
+        hipLaunchKernelGGL(k_mask_add, grid, dim3(256), 0, g_stream0, *plane, c->w0, dmask, channels, width, x0, y0, x1, y1, nx, ny,
+                           transposed, is_rigmask, bias_factor);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(g_stream0));
+        return 0;
+    };
+    rc = run();
+    if (rc) (void) hipStreamSynchronize(g_stream0);
     dfree(dmask);
-    return 0;
+    return rc;
 }
 
 // ---- batch -----------------------------------------------------------------
@@ -2679,9 +2788,21 @@ extern "C" int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int c
 // it needs a hardware queue per stream: with the HIP runtime's default of 4 queues per process (GPU_MAX_HW_QUEUES) the
 // streams share queues and the same split is 30 % SLOWER.  So it is opt-in: lqrhip_set_sub_batches (bench.py
 // --sub-batches), default one stream.  DESIGN.md 4.11.
-static int g_sub_batches = 1;
-extern "C" void lqrhip_set_sub_batches(int n) { g_sub_batches = n > 0 ? n : 1; }
-extern "C" int lqrhip_sub_batches(int n) { return n >= 2 * g_sub_batches ? g_sub_batches : 1; }
+static int g_sub_batches = 0;           // 0: automatic (below)
+extern "C" void lqrhip_set_sub_batches(int n) { g_sub_batches = n > 0 ? n : 0; }
+// Streams a lock-step group of n carvers is split over.  Automatic: 4 for groups of 32 and more WHEN the process has the
+// hardware queues for them -- the HIP runtime's GPU_MAX_HW_QUEUES (default 4, read when HIP initialises, shared with every
+// other stream of the process) must be 8 or more; with fewer, streams share queues and the split is 30 % slower than
+// one stream, so it is not made.
+extern "C" int lqrhip_sub_batches(int n)
+{
+    int nb = g_sub_batches;
+    if (nb == 0) {
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        nb = (n >= 32 && q && atoi(q) >= 8) ? 4 : 1;
+    }
+    return n >= 2 * nb ? nb : 1;
+}
 
 extern "C" void lqrhip_batch_set_shared(LqrHipBatch *b, int shared) { b->shared = shared != 0; }
 
@@ -2696,15 +2817,35 @@ extern "C" LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n)
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **) &b->d_desc, sizeof(DevCarver) * n) != hipSuccess) {
         g_err = "batch_create failed";
+        if (b->stream) (void) hipStreamDestroy(b->stream);
+        for (auto *c : b->cs) if (c->batch == b) c->batch = nullptr;
         delete b;
         return nullptr;
     }
+    g_live_batches.push_back(b);
     return b;
+}
+
+static void invalidate_all_batches(void)
+{
+    for (auto *b : g_live_batches) { b->exch_ntiles = 0; b->dirty = true; }
+}
+
+// after a failed resize: drain the stream, drop whatever the kernels recorded (it belongs to the failed call, the next
+// resize must not report it), lay everything out afresh
+extern "C" void lqrhip_batch_abort(LqrHipBatch *b)
+{
+    if (!b) return;
+    (void) hipStreamSynchronize(b->stream);
+    (void) hipGetLastError();
+    if (g_dev_err_host) *g_dev_err_host = 0;
+    invalidate_all_batches();
 }
 
 extern "C" void lqrhip_batch_destroy(LqrHipBatch *b)
 {
     if (!b) return;
+    g_live_batches.erase(std::remove(g_live_batches.begin(), g_live_batches.end(), b), g_live_batches.end());
     if (b->stream) { (void) hipStreamSynchronize(b->stream); (void) hipStreamDestroy(b->stream); }
     dfree(b->exch);
     for (auto *c : b->cs) if (c->batch == b) c->batch = nullptr;
@@ -2715,14 +2856,7 @@ extern "C" void lqrhip_batch_destroy(LqrHipBatch *b)
 extern "C" int lqrhip_batch_sync(LqrHipBatch *b)
 {
     HIPCK(hipStreamSynchronize(b->stream));
-    const int rc = check_dev_error();
-    if (rc) {
-        // a persistent sweep gave up half way: its exchange area and the device descriptors (plane swap) are in an
-        // unknown state -- lay both out again before anything else runs on this batch
-        b->exch_ntiles = 0;
-        b->dirty = true;
-    }
-    return rc;
+    return check_dev_error();
 }
 extern "C" void *lqrhip_batch_stream(LqrHipBatch *b) { return (void *) b->stream; }
 
@@ -2819,6 +2953,33 @@ extern "C" int lqrhip_prof_get(const char *kernel, double *ms_total, long long *
     }
     *launches = (long long) it->second.ev.size();
     *bytes_total = it->second.bytes;
+    return 0;
+}
+
+// Time during which at least one launch of `kernel` was running: with sub-batch streams launches overlap each other and
+// other kernels, and bytes / (sum of launch times) would count the overlapped time twice.  Event times are taken relative
+// to the first recorded event of the kernel (the GPU's clock is common to all streams).
+extern "C" int lqrhip_prof_get_union(const char *kernel, double *ms_union)
+{
+    *ms_union = 0;
+    auto it = g_profrec.find(kernel);
+    if (it == g_profrec.end() || it->second.ev.empty()) return 0;
+    (void) hipDeviceSynchronize();
+    const hipEvent_t base = it->second.ev[0].first;
+    std::vector<std::pair<float, float>> iv;
+    for (auto &e : it->second.ev) {
+        float a = 0, b = 0;
+        // an event recorded before `base` on another stream gives a negative time: both orders are tried
+        if (hipEventElapsedTime(&a, base, e.first) != hipSuccess) { (void) hipGetLastError(); float t = 0; if (hipEventElapsedTime(&t, e.first, base) == hipSuccess) a = -t; else (void) hipGetLastError(); }
+        if (hipEventElapsedTime(&b, base, e.second) != hipSuccess) { (void) hipGetLastError(); float t = 0; if (hipEventElapsedTime(&t, e.second, base) == hipSuccess) b = -t; else (void) hipGetLastError(); }
+        iv.emplace_back(a, b);
+    }
+    std::sort(iv.begin(), iv.end());
+    float end = -1e30f;
+    for (auto &p : iv) {
+        if (p.first > end) { *ms_union += p.second - p.first; end = p.second; }
+        else if (p.second > end) { *ms_union += p.second - end; end = p.second; }
+    }
     return 0;
 }
 
@@ -3143,133 +3304,132 @@ extern "C" int lqrhip_vs_commit(LqrHipBatch *b, int w0, int h0, int wc0, int n_s
     return 0;
 }
 
-// E14: every carver of the batch (roots and their attached carvers) is inflated by ONE launch (a job table in device
-// memory, one grid row of blocks per job); planes are swapped after its synchronisation
-struct InflateJob {
+// E14 / E11: every carver of the batch (roots and their attached carvers) goes through ONE launch (a job table in device
+// memory, one grid slice of blocks per job); the new planes replace the old ones after its synchronisation.  Everything
+// staged for the pass is owned by a PlaneJobs object until then: any error return gives all of it back to the pool.
+struct PlaneJob {
     LqrHipCarver *c;
     uint8_t *nrgb;
     float *nbias, *nrig;
 };
-
-static int inflate_prepare(LqrHipCarver *c, const int32_t *vs_old, int32_t *nvs, int h0, int w1, std::vector<InflateJob> &jobs,
-                           std::vector<InflateDev> &dev)
-{
-    InflateJob j{c, nullptr, nullptr, nullptr};
-    int rc;
-    size_t n1 = (size_t) w1 * h0;
-    if ((rc = dmalloc(&j.nrgb, n1 * c->ch))) return rc;
-    if (c->bias0 && (rc = dmalloc(&j.nbias, n1))) return rc;
-    if (c->rig0 && (rc = dmalloc(&j.nrig, n1))) return rc;
-    jobs.push_back(j);
-    dev.push_back(InflateDev{c->rgb0, vs_old, c->bias0, c->rig0, j.nrgb, nvs, j.nbias, j.nrig, c->ch});
-    return 0;
-}
+struct PlaneJobs {
+    std::vector<PlaneJob> jobs;
+    std::vector<InflateDev> dev;
+    std::vector<int32_t *> new_vs;          // one per root (may be null)
+    InflateDev *d_jobs = nullptr;
+    bool committed = false;
+    ~PlaneJobs()
+    {
+        dfree(d_jobs);
+        if (committed) return;
+        for (auto &j : jobs) { dfree(j.nrgb); dfree(j.nbias); dfree(j.nrig); }
+        for (auto *&v : new_vs) dfree(v);
+    }
+    // stage the output planes of carver c: n1 pixels each
+    int add(LqrHipCarver *c, const int32_t *vs_old, int32_t *nvs, size_t n1)
+    {
+        PlaneJob j{c, nullptr, nullptr, nullptr};
+        int rc = dmalloc(&j.nrgb, n1 * c->ch);
+        if (!rc && c->bias0) rc = dmalloc(&j.nbias, n1);
+        if (!rc && c->rig0) rc = dmalloc(&j.nrig, n1);
+        jobs.push_back(j);                  // owned from here on, also when rc != 0
+        if (rc) return rc;
+        dev.push_back(InflateDev{c->rgb0, vs_old, c->bias0, c->rig0, j.nrgb, nvs, j.nbias, j.nrig, c->ch});
+        return 0;
+    }
+    int upload(hipStream_t s)
+    {
+        int rc = dmalloc(&d_jobs, dev.size());
+        if (rc) return rc;
+        HIPCK(hipMemcpyAsync(d_jobs, dev.data(), dev.size() * sizeof(InflateDev), hipMemcpyHostToDevice, s));
+        return 0;
+    }
+    // after the pass has completed: the new base planes become the carvers'
+    void commit()
+    {
+        for (auto &j : jobs) {
+            dfree(j.c->rgb0); j.c->rgb0 = j.nrgb;
+            if (j.nbias) { dfree(j.c->bias0); j.c->bias0 = j.nbias; }
+            if (j.nrig) { dfree(j.c->rig0); j.c->rig0 = j.nrig; }
+        }
+        committed = true;
+    }
+};
 
 extern "C" int lqrhip_inflate(LqrHipBatch *b, int w0, int h0, int l, int max_level)
 {
     int rc;
     const int w1 = w0 + l - max_level + 1;
-    std::vector<InflateJob> jobs;
-    std::vector<InflateDev> dev;
-    std::vector<int32_t *> new_vs;
+    PlaneJobs pj;
     for (auto *c : b->cs) {
         int32_t *nvs = nullptr;
         if ((rc = dmalloc(&nvs, (size_t) w1 * h0))) return rc;
-        new_vs.push_back(nvs);
+        pj.new_vs.push_back(nvs);
         for (auto *a : c->aux)
-            if ((rc = inflate_prepare(a, c->vs, nullptr, h0, w1, jobs, dev))) return rc;
-        if ((rc = inflate_prepare(c, c->vs, nvs, h0, w1, jobs, dev))) return rc;
+            if ((rc = pj.add(a, c->vs, nullptr, (size_t) w1 * h0))) return rc;
+        if ((rc = pj.add(c, c->vs, nvs, (size_t) w1 * h0))) return rc;
     }
-    InflateDev *d_jobs = nullptr;
-    if ((rc = dmalloc(&d_jobs, dev.size()))) return rc;
-    HIPCK(hipMemcpyAsync(d_jobs, dev.data(), dev.size() * sizeof(InflateDev), hipMemcpyHostToDevice, b->stream));
-    hipLaunchKernelGGL(k_inflate, dim3(h0, (unsigned) dev.size()), dim3(256), 0, b->stream, d_jobs, w0, w1, l, max_level);
+    if ((rc = pj.upload(b->stream))) return rc;
+    hipLaunchKernelGGL(k_inflate, dim3(h0, (unsigned) pj.dev.size()), dim3(256), 0, b->stream, pj.d_jobs, w0, w1, l, max_level);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(b->stream));
-    dfree(d_jobs);
-    for (auto &j : jobs) {
-        dfree(j.c->rgb0); j.c->rgb0 = j.nrgb;
-        if (j.nbias) { dfree(j.c->bias0); j.c->bias0 = j.nbias; }
-        if (j.nrig) { dfree(j.c->rig0); j.c->rig0 = j.nrig; }
-        j.c->w0 = w1;
-    }
+    pj.commit();
+    for (auto &j : pj.jobs) j.c->w0 = w1;
     size_t i = 0;
     for (auto *c : b->cs) {
         dfree(c->vs);
-        c->vs = new_vs[i++];
+        c->vs = pj.new_vs[i++];
         for (auto *a : c->aux) a->vs = c->vs;
     }
     b->dirty = true;
-    return 0;
-}
-
-static int flatten_one(LqrHipCarver *c, const int32_t *vs_old, int w0, int h0, int w, int level, hipStream_t s)
-{
-    uint8_t *nrgb = nullptr;
-    float *nbias = nullptr, *nrig = nullptr;
-    int rc;
-    size_t n1 = (size_t) w * h0;
-    if ((rc = dmalloc(&nrgb, n1 * c->ch))) return rc;
-    if (c->bias0 && (rc = dmalloc(&nbias, n1))) return rc;
-    if (c->rig0 && (rc = dmalloc(&nrig, n1))) return rc;
-    hipLaunchKernelGGL(k_compact, dim3(h0), dim3(256), 0, s, c->rgb0, vs_old, c->bias0, c->rig0, nrgb, nbias, nrig,
-                       (int32_t *) nullptr, w0, w, c->ch, level, 0);
-    HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(s));
-    dfree(c->rgb0); c->rgb0 = nrgb;
-    if (nbias) { dfree(c->bias0); c->bias0 = nbias; }
-    if (nrig) { dfree(c->rig0); c->rig0 = nrig; }
-    c->w0 = w;
     return 0;
 }
 
 extern "C" int lqrhip_flatten(LqrHipBatch *b, int w0, int h0, int w, int level)
 {
     int rc;
-    HIPCK(hipStreamSynchronize(b->stream));
+    PlaneJobs pj;
     for (auto *c : b->cs) {
+        int32_t *nvs = nullptr;                 // the flat carver's visibility map: all zero
+        if ((rc = dmalloc(&nvs, (size_t) w * h0))) return rc;
+        pj.new_vs.push_back(nvs);
+        HIPCK(hipMemsetAsync(nvs, 0, (size_t) w * h0 * sizeof(int32_t), b->stream));
         for (auto *a : c->aux)
-            if ((rc = flatten_one(a, c->vs, w0, h0, w, level, b->stream))) return rc;
-        if ((rc = flatten_one(c, c->vs, w0, h0, w, level, b->stream))) return rc;
+            if ((rc = pj.add(a, c->vs, nullptr, (size_t) w * h0))) return rc;
+        if ((rc = pj.add(c, c->vs, nullptr, (size_t) w * h0))) return rc;
+    }
+    if ((rc = pj.upload(b->stream))) return rc;
+    hipLaunchKernelGGL(k_compact_jobs, dim3(h0, (unsigned) pj.dev.size()), dim3(256), 0, b->stream, pj.d_jobs, w0, w, level);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(b->stream));
+    pj.commit();
+    for (auto &j : pj.jobs) j.c->w0 = w;
+    size_t i = 0;
+    for (auto *c : b->cs) {
         dfree(c->vs);
-        if ((rc = dmalloc(&c->vs, (size_t) w * h0))) return rc;
-        HIPCK(hipMemsetAsync(c->vs, 0, (size_t) w * h0 * sizeof(int32_t), b->stream));
+        c->vs = pj.new_vs[i++];
         for (auto *a : c->aux) a->vs = c->vs;
     }
     b->dirty = true;
     return 0;
 }
 
-static int transpose_one(LqrHipCarver *c, int w, int h, hipStream_t s)
-{
-    uint8_t *nrgb = nullptr;
-    float *nbias = nullptr, *nrig = nullptr;
-    int rc;
-    size_t n = (size_t) w * h;
-    if ((rc = dmalloc(&nrgb, n * c->ch))) return rc;
-    if (c->bias0 && (rc = dmalloc(&nbias, n))) return rc;
-    if (c->rig0 && (rc = dmalloc(&nrig, n))) return rc;
-    hipLaunchKernelGGL(k_transpose, dim3((w + 31) / 32, (h + 31) / 32), dim3(32, 8), 0, s, c->rgb0, c->bias0, c->rig0, nrgb, nbias,
-                       nrig, w, h, c->ch);
-    HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(s));
-    dfree(c->rgb0); c->rgb0 = nrgb;
-    if (nbias) { dfree(c->bias0); c->bias0 = nbias; }
-    if (nrig) { dfree(c->rig0); c->rig0 = nrig; }
-    c->w0 = h; c->h0 = w;
-    return 0;
-}
-
 extern "C" int lqrhip_transpose(LqrHipBatch *b, int w, int h)
 {
     int rc;
-    HIPCK(hipStreamSynchronize(b->stream));
+    PlaneJobs pj;
     for (auto *c : b->cs) {
         for (auto *a : c->aux)
-            if ((rc = transpose_one(a, w, h, b->stream))) return rc;
-        if ((rc = transpose_one(c, w, h, b->stream))) return rc;
+            if ((rc = pj.add(a, nullptr, nullptr, (size_t) w * h))) return rc;
+        if ((rc = pj.add(c, nullptr, nullptr, (size_t) w * h))) return rc;
         HIPCK(hipMemsetAsync(c->vs, 0, (size_t) w * h * sizeof(int32_t), b->stream));   // flat carver: all zero already
     }
+    if ((rc = pj.upload(b->stream))) return rc;
+    hipLaunchKernelGGL(k_transpose, dim3((w + 31) / 32, (h + 31) / 32, (unsigned) pj.dev.size()), dim3(32, 8), 0, b->stream, pj.d_jobs, w, h);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(b->stream));
+    pj.commit();
+    for (auto &j : pj.jobs) { j.c->w0 = h; j.c->h0 = w; }
     b->dirty = true;
     return 0;
 }
@@ -3282,13 +3442,16 @@ extern "C" int lqrhip_read_visible(LqrHipCarver *c, int w0, int h0, int w, int l
     uint8_t *d = nullptr;
     size_t n = (size_t) w * h0 * c->ch;
     if ((rc = dmalloc(&d, n))) return rc;
-    hipLaunchKernelGGL(k_compact, dim3(h0), dim3(256), 0, g_stream0, c->rgb0, c->vs, (const float *) nullptr, (const float *) nullptr,
-                       d, (float *) nullptr, (float *) nullptr, (int32_t *) nullptr, w0, w, c->ch, level, 0);
-    HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(g_stream0));
-    HIPCK(hipMemcpy(out, d, n, hipMemcpyDeviceToHost));
+    auto run = [&]() -> int {
+        hipLaunchKernelGGL(k_compact, dim3(h0), dim3(256), 0, g_stream0, c->rgb0, c->vs, (const float *) nullptr, (const float *) nullptr,
+                           d, (float *) nullptr, (float *) nullptr, (int32_t *) nullptr, w0, w, c->ch, level, 0);
+        HIPCK(hipGetLastError());
+        return d2h_staged(out, d, n);
+    };
+    rc = run();
+    if (rc) (void) hipStreamSynchronize(g_stream0);
     dfree(d);
-    return 0;
+    return rc;
 }
 
 extern "C" int lqrhip_read_visible_device(LqrHipCarver *c, int w0, int h0, int w, int level, void *device_out)
@@ -3311,15 +3474,20 @@ extern "C" int lqrhip_mask_line_max(const unsigned char *mask, int channels, int
     int *dout = nullptr;
     int rc, result = 0;
     size_t bytes = (size_t) width * height * channels;
-    if ((rc = dmalloc(&d, bytes)) || (rc = dmalloc(&dout, 1))) return rc;
-    HIPCK(hipMemcpy(d, mask, bytes, hipMemcpyHostToDevice));
-    HIPCK(dzero(dout, sizeof(int)));
-    hipLaunchKernelGGL(k_mask_line_max, dim3(n_lines), dim3(256), 0, g_stream0, d, channels, width, a0, b0, line_len, direction, dout);
-    HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(g_stream0));
-    HIPCK(hipMemcpy(&result, dout, sizeof(int), hipMemcpyDeviceToHost));
+    if ((rc = dmalloc(&d, bytes)) || (rc = dmalloc(&dout, 1))) { dfree(d); return rc; }
+    auto run = [&]() -> int {
+        HIPCK(hipMemcpyAsync(d, mask, bytes, hipMemcpyHostToDevice, g_stream0));
+        HIPCK(hipMemsetAsync(dout, 0, sizeof(int), g_stream0));
+        hipLaunchKernelGGL(k_mask_line_max, dim3(n_lines), dim3(256), 0, g_stream0, d, channels, width, a0, b0, line_len, direction, dout);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(&result, dout, sizeof(int), hipMemcpyDeviceToHost, g_stream0));
+        HIPCK(hipStreamSynchronize(g_stream0));
+        return 0;
+    };
+    rc = run();
+    if (rc) (void) hipStreamSynchronize(g_stream0);
     dfree(d); dfree(dout);
-    return result;
+    return rc ? rc : result;
 }
 
 extern "C" void lqrhip_pool_trim(void)
@@ -3343,14 +3511,17 @@ extern "C" int lqrhip_read_vmap(LqrHipCarver *c, int w0, int h0, int w, int leve
     int32_t *d = nullptr;
     size_t n = (size_t) w * h0;
     if ((rc = dmalloc(&d, n))) return rc;
-    hipLaunchKernelGGL(k_compact, dim3(h0), dim3(256), 0, g_stream0, (const uint8_t *) nullptr, c->vs, (const float *) nullptr,
-                       (const float *) nullptr, (uint8_t *) nullptr, (float *) nullptr, (float *) nullptr, d, w0, w, c->ch, level,
-                       depth);
-    HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(g_stream0));
-    HIPCK(hipMemcpy(out, d, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    auto run = [&]() -> int {
+        hipLaunchKernelGGL(k_compact, dim3(h0), dim3(256), 0, g_stream0, (const uint8_t *) nullptr, c->vs, (const float *) nullptr,
+                           (const float *) nullptr, (uint8_t *) nullptr, (float *) nullptr, (float *) nullptr, d, w0, w, c->ch, level,
+                           depth);
+        HIPCK(hipGetLastError());
+        return d2h_staged(out, d, n * sizeof(int32_t));
+    };
+    rc = run();
+    if (rc) (void) hipStreamSynchronize(g_stream0);
     dfree(d);
-    return 0;
+    return rc;
 }
 
 extern "C" int lqrhip_read_working(LqrHipCarver *c, int w, int h, float *en, float *m, int *least_dx)
@@ -3434,20 +3605,27 @@ extern "C" int lqrhip_copy_bandwidth(unsigned long long bytes, int iters, double
     uint8_t *a = nullptr, *b = nullptr;
     int rc;
     if ((rc = dmalloc(&a, bytes)) || (rc = dmalloc(&b, bytes))) { dfree(a); return rc; }
-    HIPCK(hipMemsetAsync(a, 1, bytes, g_stream0));
-    hipEvent_t e0, e1;
-    HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
-    const size_t n16 = bytes / 16;
-    const dim3 grid((unsigned) ((n16 + 255) / 256));
-    hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, g_stream0, (const u32x4 *) a, (u32x4 *) b, n16);     // warm-up
-    HIPCK(hipEventRecord(e0, g_stream0));
-    for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, g_stream0, (const u32x4 *) a, (u32x4 *) b, n16);
-    HIPCK(hipEventRecord(e1, g_stream0));
-    HIPCK(hipStreamSynchronize(g_stream0));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0;
-    HIPCK(hipEventElapsedTime(&ms, e0, e1));
-    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    const size_t n16 = bytes / 16;
+    auto run = [&]() -> int {
+        HIPCK(hipMemsetAsync(a, 1, bytes, g_stream0));
+        HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
+        const dim3 grid((unsigned) ((n16 + 255) / 256));
+        hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, g_stream0, (const u32x4 *) a, (u32x4 *) b, n16);     // warm-up
+        HIPCK(hipEventRecord(e0, g_stream0));
+        for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, g_stream0, (const u32x4 *) a, (u32x4 *) b, n16);
+        HIPCK(hipEventRecord(e1, g_stream0));
+        HIPCK(hipStreamSynchronize(g_stream0));
+        HIPCK(hipEventElapsedTime(&ms, e0, e1));
+        return 0;
+    };
+    rc = run();
+    if (rc) (void) hipStreamSynchronize(g_stream0);
+    if (e0) (void) hipEventDestroy(e0);
+    if (e1) (void) hipEventDestroy(e1);
     dfree(a); dfree(b);
+    if (rc) return rc;
     if (gbps) *gbps = 2.0 * (double) (n16 * 16) * iters / (ms * 1e-3) / 1e9;
     return 0;
 }
@@ -3487,12 +3665,17 @@ extern "C" int lqrhip_vmap_to_rgba(const int *vmap, int w, int h, int depth, con
     uint32_t *dout = nullptr;
     int rc;
     if ((rc = dmalloc(&dv, n)) || (rc = dmalloc(&dout, n))) { dfree(dv); return rc; }
-    HIPCK(hipMemcpyAsync(dv, vmap, n * sizeof(int32_t), hipMemcpyHostToDevice, g_stream0));
-    hipLaunchKernelGGL(k_vmap_ramp, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, g_stream0, dv, dout, n, depth, col_start[0], col_start[1],
-                       col_start[2], col_end[0], col_end[1], col_end[2]);
-    HIPCK(hipGetLastError());
-    HIPCK(hipMemcpyAsync(out_rgba, dout, n * 4, hipMemcpyDeviceToHost, g_stream0));
-    HIPCK(hipStreamSynchronize(g_stream0));
+    auto run = [&]() -> int {
+        HIPCK(hipMemcpyAsync(dv, vmap, n * sizeof(int32_t), hipMemcpyHostToDevice, g_stream0));
+        hipLaunchKernelGGL(k_vmap_ramp, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, g_stream0, dv, dout, n, depth, col_start[0], col_start[1],
+                           col_start[2], col_end[0], col_end[1], col_end[2]);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(out_rgba, dout, n * 4, hipMemcpyDeviceToHost, g_stream0));
+        HIPCK(hipStreamSynchronize(g_stream0));
+        return 0;
+    };
+    rc = run();
+    if (rc) (void) hipStreamSynchronize(g_stream0);      // nothing may still use the blocks when they go back to the pool
     dfree(dv); dfree(dout);
-    return 0;
+    return rc;
 }

@@ -312,7 +312,13 @@ static LqrRetVal group_open(Group *g, LqrCarver **rs, int n)
         for (k = 0; k < nb; k++) {
             int lo = (int) ((long long) n * k / nb), hi = (int) ((long long) n * (k + 1) / nb);
             g->b[k] = lqrhip_batch_create(ds + lo, hi - lo);
-            if (!g->b[k]) { free(ds); return LQR_NOMEM; }
+            if (!g->b[k]) {     /* give the sub-batches (and their streams) created so far back */
+                int q;
+                for (q = 0; q < k; q++) { lqrhip_batch_destroy(g->b[q]); g->b[q] = NULL; }
+                g->nb = 0;
+                free(ds);
+                return LQR_NOMEM;
+            }
             lqrhip_batch_set_shared(g->b[k], nb > 1);
             g->nb = k + 1;
         }
@@ -644,6 +650,7 @@ static LqrRetVal group_resize(LqrCarver **rs, int n, int w1, int h1)
         if ((ret = group_resize_dir(&g, h1, 1)) == LQR_OK) ret = group_resize_dir(&g, w1, 0);
     }
     if (ret == LQR_OK) { int k; for (k = 0; k < g.nb && ret == LQR_OK; k++) ret = hip_ret(lqrhip_batch_sync(g.b[k])); }
+    else { int k; for (k = 0; k < g.nb; k++) lqrhip_batch_abort(g.b[k]); }      /* nothing of this resize may surface in the next one */
     FOR_TREE(&g, i, r, { r->ro_valid = 0; r->ro_line = 0; });
     group_close(&g);
     return ret;

@@ -80,8 +80,10 @@ int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int channels, in
                     int x_off, int y_off, int transposed, int is_rigmask, int bias_factor);
 
 /* -- batch ------------------------------------------------------------------ */
-/* into how many device batches (HIP streams) the host should split a lock-step group of n carvers: 1 unless
- * lqrhip_set_sub_batches asked for more (opt-in: needs a hardware queue per stream, GPU_MAX_HW_QUEUES >= streams + 2) */
+/* into how many device batches (HIP streams) the host splits a lock-step group of n carvers.  Automatic (set 0): 4 for
+ * groups of 32 carvers and more when the process has the hardware queues for them (the HIP runtime's GPU_MAX_HW_QUEUES
+ * >= 8 in the environment before HIP initialises; its default of 4 makes the split 30 % slower than one stream, so it is
+ * then not made), else 1.  lqrhip_set_sub_batches(n > 0) pins it. */
 int lqrhip_sub_batches(int n);
 void lqrhip_set_sub_batches(int n);
 LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n);
@@ -90,6 +92,9 @@ LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n);
 void lqrhip_batch_set_shared(LqrHipBatch *b, int shared);
 void lqrhip_batch_destroy(LqrHipBatch *b);
 int lqrhip_batch_sync(LqrHipBatch *b);
+/* after a failed call on the batch: drain its stream, discard the device-side error record of the failed call, and have
+ * every live batch lay its descriptors and exchange areas out afresh */
+void lqrhip_batch_abort(LqrHipBatch *b);
 void *lqrhip_batch_stream(LqrHipBatch *b);      /* hipStream_t, for event timing in bench.py */
 
 /* base layout -> working planes, identity map (carver must be flat):
@@ -169,6 +174,8 @@ void lqrhip_set_dp_persistent_limit(int workgroups);
 void lqrhip_set_dp_persistent_px(int px);
 void lqrhip_prof_reset(void);
 int lqrhip_prof_get(const char *kernel, double *ms_total, long long *launches, double *bytes_total);
+/* time during which at least one launch of `kernel` was running (launches of sub-batch streams overlap) */
+int lqrhip_prof_get_union(const char *kernel, double *ms_union);
 
 #ifdef __cplusplus
 }
