@@ -1558,6 +1558,53 @@ __device__ __forceinline__ void dp_row(const float (&mp)[PX], const float left, 
         mc[k] = (!MASK || in[k]) ? v : INF;
     }
 }
+// The same row for delta_x = DELTA (2 * DELTA + 1 candidate parents) and / or with a rigidity mask (RIGM: the rigidity
+// term of pixel k is rf[k] * rg[dx + DELTA], liblqr's rigidity_mask * rigidity_map).  nl[i] / nr[i]: the row above at the
+// lane's first pixel - 1 - i / last pixel + 1 + i.  The parent is found by liblqr's ascending scan dx = -DELTA .. DELTA
+// with strict < (LR = 0: the leftmost minimum wins) or <= (LR = 1: the rightmost), written as compare-and-select;
+// candidates outside the image are +inf and never win against the pixel straight above.  As in the delta_x = 1 rows the
+// rigidity term of dx = 0 (zero by construction of the table) is not added.
+template <int PX, int DELTA, bool LR, bool RIG, bool RIGM, bool UPDATE, bool MASK>
+__device__ __forceinline__ void dp_row_g(const float (&mp)[PX], const float (&nl)[DELTA], const float (&nr)[DELTA], const float (&e)[PX],
+                                         const float (&mo)[PX], const uint32_t lo, const bool (&in)[PX], const float (&rg)[2 * DELTA + 1],
+                                         const float (&rf)[PX], float (&mc)[PX], uint32_t &lnew, bool (&ch)[PX])
+{
+    static_assert(DELTA <= PX, "the neighbouring lane holds the whole reach");
+    const float INF = __int_as_float(0x7f800000);
+    float nm[PX];
+    lnew = 0;
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+        float best = 0.0f;
+        int bdx = 0;
+#pragma unroll
+        for (int dx = -DELTA; dx <= DELTA; dx++) {
+            const int j = k + dx;
+            float v = j < 0 ? nl[j < 0 ? -j - 1 : 0] : j >= PX ? nr[j >= PX ? j - PX : 0] : mp[j >= 0 && j < PX ? j : 0];
+            if (RIG && dx != 0) v = __fadd_rn(v, RIGM ? __fmul_rn(rf[k], rg[dx + DELTA]) : rg[dx + DELTA]);
+            if (dx == -DELTA) { best = v; bdx = dx; }
+            else {
+                const bool take = LR ? (v <= best) : (v < best);
+                best = take ? v : best;
+                bdx = take ? dx : bdx;
+            }
+        }
+        nm[k] = __fadd_rn(e[k], best);
+        lnew |= ((uint32_t) bdx & 0xffu) << (8 * k);
+    }
+    const uint32_t diff = lo ^ lnew;
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+        float v = nm[k];
+        if (UPDATE) {
+            float d = fabsf(__fsub_rn(mo[k], v));
+            d = ((diff >> (8 * k)) & 0xffu) ? INF : d;
+            ch[k] = d > 1e-5f;
+            v = ch[k] ? v : mo[k];
+        }
+        mc[k] = (!MASK || in[k]) ? v : INF;
+    }
+}
 // PX floats / PX back-pointer bytes of one lane, as one load or store
 template <int PX> struct LaneVec;
 template <> struct LaneVec<2> { typedef float F __attribute__((ext_vector_type(2))); typedef uint16_t L; };
@@ -1973,14 +2020,20 @@ constexpr int dpp_own(int px) { return 64 * px - 2 * dpp_halo(px); }     // colu
 constexpr int dpp_ex_tile(int px) { return 2 * 2 * dpp_halo(px); }       // granules a tile publishes: [block parity][side: 0 to the left, 1 to the right][column]
 constexpr int DPP_R = 16;                       // rows per batch
 constexpr int DPP_W = 2;                        // waves taking turns
-static_assert(dpp_halo(2) % (DPP_R * DPP_W) == 0 && dpp_halo(4) % (DPP_R * DPP_W) == 0, "a block is a whole number of rounds");
+static_assert(dpp_halo(2) % (2 * DPP_R) == 0 && dpp_halo(4) % (2 * DPP_R) == 0, "a block (halo / delta_x rows, delta_x <= 2) is a whole number of batches");
+constexpr int DPP_BLK_BITS = 12;                // bits of the block index in a granule's tag
 // co-residency bound for the spin waits, set from the occupancy query in lqrhip_init (dpp_resident_workgroups)
 static int g_dpp_max_wgs = 0;
+static int g_dpp_max_wgs_plain = 0, g_dpp_max_wgs_general = 0;      // ... of the plain / the delta_x = 2, rigidity-mask instantiations
 
 
-template <int PX, bool LR, bool RIG, bool UPDATE>
+// DELTA = delta_x (1 or 2: errors move DELTA columns per row, so a block is HALO / DELTA rows); RIGM = a rigidity mask
+// scales the rigidity term per pixel (one more 4-byte plane read).  The plain instantiations (1, false) use the
+// 3-neighbour row above, the others dp_row_g.
+template <int PX, bool LR, bool RIG, bool UPDATE, int DELTA = 1, bool RIGM = false>
 __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err)
 {
+    static_assert(DELTA >= 1 && DELTA <= 2 && (RIG || !RIGM), "delta_x 1 or 2; a rigidity mask only matters with rigidity");
     typedef typename LaneVec<PX>::F FV;
     typedef typename LaneVec<PX>::L LV;
     typedef GLOBAL_AS FV GFV;
@@ -2014,14 +2067,19 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
     for (int k = 0; k < PX; k++) in[k] = lane_in && x0 + k < w;
 
     constexpr int R = DPP_R;
-    FV q_e[R], q_mo[R];
+    FV q_e[R], q_mo[R], q_rf[RIGM ? R : 1];
     LV q_lo[R];
+    constexpr int RB = HALO / DELTA, NBB = RB / R;          // rows, batches per block
+    float rg[2 * DELTA + 1];
+#pragma unroll
+    for (int i = 0; i < 2 * DELTA + 1; i++) rg[i] = p.rigmap[i];
     auto issue = [&](int ybase) {      // uniform plane base + 32-bit lane offset, as in k_band_update_tw
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const unsigned row = (unsigned) min(ybase + r, h - 1) * (unsigned) stride;
             const unsigned ro = row + lo_off, ro4 = (row << 2) + (lo_off << 2);
             q_e[r] = *(const GFV *) ((const gu8 *) c.en + ro4);
+            if (RIGM) q_rf[r] = *(const GFV *) ((const gu8 *) c.rig + ro4);
             if (UPDATE) {
                 q_mo[r] = *(const GFV *) ((const gu8 *) c.m + ro4);
                 q_lo[r] = *(const GLV *) (c.least + ro);
@@ -2055,10 +2113,23 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
 #pragma unroll
                     for (int k = 0; k < PX; k++) mc[k] = in[k] ? e[k] : INF;     // row 0: m = en
                 } else {
-                    const float left = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1]), DPP_WAVE_SHR1, 0xf, 0xf, true));
-                    const float right = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[0]), DPP_WAVE_SHL1, 0xf, 0xf, true));
                     bool ch[PX];
-                    dp_row<PX, LR, RIG, UPDATE, MASK>(mp, left, right, e, mo, UPDATE ? (uint32_t) q_lo[r] : 0u, in, rig_l, rig_r, mc, lnew, ch);
+                    if constexpr (DELTA == 1 && !RIGM) {
+                        const float left = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1]), DPP_WAVE_SHR1, 0xf, 0xf, true));
+                        const float right = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[0]), DPP_WAVE_SHL1, 0xf, 0xf, true));
+                        dp_row<PX, LR, RIG, UPDATE, MASK>(mp, left, right, e, mo, UPDATE ? (uint32_t) q_lo[r] : 0u, in, rig_l, rig_r, mc, lnew, ch);
+                    } else {
+                        // the neighbouring lanes' pixels next to this lane's: DELTA on each side (DELTA <= PX)
+                        float nl[DELTA], nr[DELTA], rf[PX];
+#pragma unroll
+                        for (int i = 0; i < DELTA; i++) {
+                            nl[i] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1 - i]), DPP_WAVE_SHR1, 0xf, 0xf, true));
+                            nr[i] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[i]), DPP_WAVE_SHL1, 0xf, 0xf, true));
+                        }
+#pragma unroll
+                        for (int k = 0; k < PX; k++) rf[k] = RIGM ? q_rf[RIGM ? r : 0][k] : 1.0f;
+                        dp_row_g<PX, DELTA, LR, RIG, RIGM, UPDATE, MASK>(mp, nl, nr, e, mo, UPDATE ? (uint32_t) q_lo[r] : 0u, in, rg, rf, mc, lnew, ch);
+                    }
                 }
                 {
                     FV t;
@@ -2074,15 +2145,15 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
     };
     const bool interior = (x0 - PX * lane >= 0) && (x0 - PX * lane + TILE <= w);      // uniform: the whole tile window is inside the image
 
-    const int nblk = (h + HALO - 1) / HALO;
+    const int nblk = (h + RB - 1) / RB;
     issue(q * R);
     for (int j = 0; j < nblk; j++) {
-        const int y0 = j * HALO;
-        const int ylast = min(y0 + HALO, h) - 1;
+        const int y0 = j * RB;
+        const int ylast = min(y0 + RB, h) - 1;
 #pragma unroll 1
-        for (int bb = 0; bb < HALO / R; bb++) {
+        for (int bb = 0; bb < NBB; bb++) {
             const int yb = y0 + bb * R;
-            const bool mine = (bb & (DPP_W - 1)) == q && yb < h;
+            const bool mine = ((j * NBB + bb) & (DPP_W - 1)) == q && yb < h;          // batches alternate between the two waves
             if (mine) {
                 if (yb > 0) {
                     const FV v = s_mp[lane];
@@ -2107,7 +2178,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     const int nb = (lane < 32) ? tile - 1 : tile + 1;                     // left halo <- left neighbour's right-going granules
                     const int col = !need ? 0 : (lane < 32) ? PX * lane : PX * (lane - 64 + HL);        // lanes that need nothing poll a dummy
                     gu64 *src = ex_img + (size_t) (need ? nb : tile) * EX_TILE + (size_t) (((j - 1) & 1) * 2 + (lane < 32 ? 1 : 0)) * HALO + col;
-                    const unsigned want = ((unsigned) epoch << 8) | (unsigned) j;
+                    const unsigned want = ((unsigned) epoch << DPP_BLK_BITS) | (unsigned) j;
                     unsigned long long g[PX];
                     int spins = 0;
                     bool failed = false;
@@ -2144,7 +2215,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     if (own_lane) {
                         const int side = lane < 32 ? 0 : 1;
                         gu64 *dst = ex_img + (size_t) tile * EX_TILE + (size_t) ((j & 1) * 2 + side) * HALO + PX * (lane - (side ? 32 : HL));
-                        const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 8) | (unsigned) (j + 1)) << 32;
+                        const unsigned long long tag = (unsigned long long) (((unsigned) epoch << DPP_BLK_BITS) | (unsigned) (j + 1)) << 32;
 #pragma unroll
                         for (int k = 0; k < PX; k++) __hip_atomic_store(dst + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -2159,7 +2230,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                 // The wave that finished the block holds its loads back until the partner has received the neighbours'
                 // hand-over: the hand-off's price sits in the CONSUMER CU's memory queue, where ~50 prefetch loads in front of
                 // the poll double the wait (measured on the band variant of this kernel: 4200 -> 2200 cycles per block).
-                if (bb == HALO / R - 1 && j + 1 < nblk) {
+                if (bb == NBB - 1 && j + 1 < nblk) {
                     int spins = 0;
                     while (s_polled < j + 1 && !*(volatile int *) &s_fail && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
                 }
@@ -2469,8 +2540,14 @@ static int dpp_resident_workgroups(int dev)
     q(k_dp_tile_p<4, false, false, true>); q(k_dp_tile_p<4, false, true, true>); q(k_dp_tile_p<4, true, false, true>); q(k_dp_tile_p<4, true, true, true>);
     q(k_dp_tile_p<2, false, false, false>); q(k_dp_tile_p<2, false, true, false>); q(k_dp_tile_p<2, true, false, false>); q(k_dp_tile_p<2, true, true, false>);
     q(k_dp_tile_p<2, false, false, true>); q(k_dp_tile_p<2, false, true, true>); q(k_dp_tile_p<2, true, false, true>); q(k_dp_tile_p<2, true, true, true>);
-
-    return std::max(0, per_cu - 1) * prop.multiProcessorCount;
+    g_dpp_max_wgs_plain = std::max(0, per_cu - 1) * prop.multiProcessorCount;
+    // the delta_x = 2 / rigidity-mask instantiations (2 px per lane only) hold more registers
+    per_cu = 1 << 20;
+#define QG(LRV, UPD) q(k_dp_tile_p<2, LRV, true, UPD, 1, true>); q(k_dp_tile_p<2, LRV, false, UPD, 2, false>); q(k_dp_tile_p<2, LRV, true, UPD, 2, false>); q(k_dp_tile_p<2, LRV, true, UPD, 2, true>)
+    QG(false, false); QG(false, true); QG(true, false); QG(true, true);
+#undef QG
+    g_dpp_max_wgs_general = std::max(0, per_cu - 1) * prop.multiProcessorCount;
+    return g_dpp_max_wgs_plain;
 }
 
 extern "C" int lqrhip_init(void)
@@ -3034,14 +3111,17 @@ static int launch_dp_tiled(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
 // Pixels per lane of the persistent sweep for this batch: 2 while twice the tiles still fit the residency bound (the row
 // chain is then ~33 instructions per wave instead of ~58; measured per 4K seam round, 2 vs 4 px per lane:
 // 1 image 0.40 / 0.50 ms, 4: 0.45 / 0.55, 8: 0.58 / 0.62, 12: 0.76 / 0.77), else 4, 0 = not at all.
-static int dp_persistent_px(const LqrHipBatch *b, int w)
+// `general`: delta_x = 2 and / or a rigidity mask (with rigidity): those instantiations exist for 2 px per lane only
+static int dp_persistent_px(const LqrHipBatch *b, int w, bool general = false, int delta = 1)
 {
     if (b->shared) return 0;
-    const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs) : g_dpp_max_wgs;
+    const int bound = general ? g_dpp_max_wgs_general : g_dpp_max_wgs;
+    const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, bound) : bound;
     const size_t n = b->cs.size();
-    const int hh = b->cs[0]->wk_h;                            // the block index is 8 bits of the granule tag
-    if (g_dpp_px_override != 4 && hh <= 255 * dpp_halo(2) && (size_t) ((w + dpp_own(2) - 1) / dpp_own(2)) * n <= (size_t) limit) return 2;
-    if (g_dpp_px_override != 2 && hh <= 255 * dpp_halo(4) && (size_t) ((w + dpp_own(4) - 1) / dpp_own(4)) * n <= (size_t) limit) return 4;
+    const int hh = b->cs[0]->wk_h;                            // the block index is DPP_BLK_BITS bits of the granule tag
+    const int maxblk = (1 << DPP_BLK_BITS) - 1;
+    if ((general || g_dpp_px_override != 4) && hh <= maxblk * (dpp_halo(2) / delta) && (size_t) ((w + dpp_own(2) - 1) / dpp_own(2)) * n <= (size_t) limit) return 2;
+    if (!general && g_dpp_px_override != 2 && hh <= maxblk * dpp_halo(4) && (size_t) ((w + dpp_own(4) - 1) / dpp_own(4)) * n <= (size_t) limit) return 4;
     return 0;
 }
 static bool dp_persistent_ok(const LqrHipBatch *b, int w) { return dp_persistent_px(b, w) != 0; }
@@ -3052,7 +3132,12 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
 {
     LqrHipCarver *c0 = b->cs[0];
     const size_t n = b->cs.size();
-    const int px = dp_persistent_px(b, w);
+    bool rigm = false;
+    for (auto *c : b->cs) rigm |= (c->rig != nullptr);
+    rigm = rigm && k.use_rig;                                  // without rigidity the mask multiplies nothing
+    const bool general = k.delta != 1 || rigm;
+    if (k.delta < 1 || k.delta > 2) return LQRHIP_EARG;
+    const int px = dp_persistent_px(b, w, general, k.delta);
     if (!px) return LQRHIP_EARG;
     const int ntiles = (w + dpp_own(px) - 1) / dpp_own(px);
     int rc;
@@ -3087,7 +3172,7 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
             if ((rc = batch_upload(b))) return rc;
         }
     }
-    const int epoch = 1 + ((b->tile_epoch++) % 0x7ffffe);          // never 0; 23 bits above the 8-bit block index
+    const int epoch = 1 + ((b->tile_epoch++) % ((1 << (31 - DPP_BLK_BITS)) - 2));          // never 0; above the block index in the 32-bit tag
     const dim3 grid(ntiles, (unsigned) n);
 #define LAUNCH_TILE(PXV, LRV, RIGV) hipLaunchKernelGGL((k_dp_tile_p<PXV, LRV, RIGV, UPDATE>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
 #define LAUNCH_TILE_PX(PXV)                                                                 \
@@ -3095,7 +3180,17 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
         if (lr) { if (k.use_rig) LAUNCH_TILE(PXV, true, true); else LAUNCH_TILE(PXV, true, false); }     \
         else { if (k.use_rig) LAUNCH_TILE(PXV, false, true); else LAUNCH_TILE(PXV, false, false); }      \
     } while (0)
-    if (px == 2) LAUNCH_TILE_PX(2); else LAUNCH_TILE_PX(4);
+#define LAUNCH_TILE_G(LRV, RIGV, DV, RMV) hipLaunchKernelGGL((k_dp_tile_p<2, LRV, RIGV, UPDATE, DV, RMV>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
+#define LAUNCH_TILE_G_LR(RIGV, DV, RMV) do { if (lr) LAUNCH_TILE_G(true, RIGV, DV, RMV); else LAUNCH_TILE_G(false, RIGV, DV, RMV); } while (0)
+    if (general) {
+        if (k.delta == 1) LAUNCH_TILE_G_LR(true, 1, true);
+        else if (!k.use_rig) LAUNCH_TILE_G_LR(false, 2, false);
+        else if (!rigm) LAUNCH_TILE_G_LR(true, 2, false);
+        else LAUNCH_TILE_G_LR(true, 2, true);
+    }
+    else if (px == 2) LAUNCH_TILE_PX(2); else LAUNCH_TILE_PX(4);
+#undef LAUNCH_TILE_G_LR
+#undef LAUNCH_TILE_G
 #undef LAUNCH_TILE_PX
 #undef LAUNCH_TILE
     HIPCK(hipGetLastError());
@@ -3109,9 +3204,11 @@ static int launch_dp(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
 {
     LqrHipCarver *c0 = b->cs[0];
     if (!UPDATE) {
-        bool has_rigmask = false;
-        for (auto *c : b->cs) has_rigmask |= (c->rig != nullptr);
-        if (k.delta == 1 && !has_rigmask) return dp_persistent_ok(b, w) ? launch_dp_persistent<false>(b, k, w, h, lr) : launch_dp_tiled(b, k, w, h, lr);
+        bool rigm = false;
+        for (auto *c : b->cs) rigm |= (c->rig != nullptr);
+        rigm = rigm && k.use_rig;
+        if (k.delta == 1 && !rigm) return dp_persistent_ok(b, w) ? launch_dp_persistent<false>(b, k, w, h, lr) : launch_dp_tiled(b, k, w, h, lr);
+        if (k.delta >= 1 && k.delta <= 2 && dp_persistent_px(b, w, true, k.delta)) return launch_dp_persistent<false>(b, k, w, h, lr);
     }
     int pxt = (w + DP_THREADS - 1) / DP_THREADS;
     size_t lds = (size_t) 2 * ((w + 3) & ~3) * sizeof(float);
@@ -3220,10 +3317,14 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     }
     // How E9 (update_mmap) runs.  Small batches: the whole chip recomputing every row (tiled full-width keep-rule
     // sweep) beats the one-workgroup-per-image band walk; for large batches its 14 B/px of traffic would not.
-    const bool fast_ok = p->delta_x == 1 && !has_rigmask;
-    const bool tiled_update = fast_ok &&
-                              (g_update_mode < 0 ? (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px : g_update_mode == 1) &&
-                              dp_persistent_ok(b, w);
+    // "plain": delta_x = 1 and no rigidity mask that matters -- every fast kernel.  delta_x = 2 and rigidity masks run on the
+    // tiled full-width update (k_dp_tile_p's general instantiations) whenever its grid fits; only beyond that do they fall
+    // to the one-wave-per-image band kernel and the one-workgroup-per-image sweep (measured at 8K: 37x slower)
+    const bool rigm = has_rigmask && p->use_rigidity;
+    const bool fast_ok = p->delta_x == 1 && !rigm;
+    const bool tiled_update = fast_ok ? ((g_update_mode < 0 ? (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px : g_update_mode == 1) &&
+                                         dp_persistent_ok(b, w))
+                                      : (p->delta_x >= 1 && p->delta_x <= 2 && g_update_mode != 0 && g_update_mode != 2 && dp_persistent_px(b, w, true, p->delta_x) != 0);
     if (tiled_update) {
         ProfScope ps("dp_update_tiled", b->stream, 0);
         if ((rc = launch_dp_persistent<true>(b, k, wnew, h, leftright_next))) return rc;
