@@ -2991,7 +2991,8 @@ struct ProfScope {
 extern "C" void lqrhip_prof_enable(int on) { g_prof = on; }
 static int g_update_mode = -1;
 // -1: by batch size (g_tiled_update_px); 0: band kernel (k_band_update_tw); 1: tiled full-width update whenever its
-// grid fits; 2: the per-row-barrier band kernel (k_band_update_mw)
+// grid fits; 2: the per-row-barrier band kernel (k_band_update_mw); 3: the generic one-wave band kernel + sweep
+// (what delta_x > 2 runs on), whatever the parameters
 extern "C" void lqrhip_set_update_mode(int mode) { g_update_mode = mode; }
 #ifdef LQR_BAND_EXPERIMENTS
 // which trapezoid band kernel update mode 0 (and the engine's own choice for large batches) means:
@@ -3321,10 +3322,10 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     // tiled full-width update (k_dp_tile_p's general instantiations) whenever its grid fits; only beyond that do they fall
     // to the one-wave-per-image band kernel and the one-workgroup-per-image sweep (measured at 8K: 37x slower)
     const bool rigm = has_rigmask && p->use_rigidity;
-    const bool fast_ok = p->delta_x == 1 && !rigm;
+    const bool fast_ok = p->delta_x == 1 && !rigm && g_update_mode != 3;
     const bool tiled_update = fast_ok ? ((g_update_mode < 0 ? (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px : g_update_mode == 1) &&
                                          dp_persistent_ok(b, w))
-                                      : (p->delta_x >= 1 && p->delta_x <= 2 && g_update_mode != 0 && g_update_mode != 2 && dp_persistent_px(b, w, true, p->delta_x) != 0);
+                                      : (p->delta_x >= 1 && p->delta_x <= 2 && g_update_mode != 0 && g_update_mode != 2 && g_update_mode != 3 && dp_persistent_px(b, w, true, p->delta_x) != 0);
     if (tiled_update) {
         ProfScope ps("dp_update_tiled", b->stream, 0);
         if ((rc = launch_dp_persistent<true>(b, k, wnew, h, leftright_next))) return rc;

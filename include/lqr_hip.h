@@ -163,7 +163,8 @@ int lqrhip_read_working(LqrHipCarver *c, int w, int h, float *en, float *m, int 
 void lqrhip_prof_enable(int on);
 /* how E9 (update_mmap) runs: -1 by batch size (tiled full-width keep-rule sweep up to 8 4K images, the band
  * kernel k_band_update_tw above), 0 band kernel always, 1 tiled sweep whenever its grid fits the device,
- * 2 the per-row-barrier band kernel k_band_update_mw (the default for rows wider than 4200 px) */
+ * 2 the per-row-barrier band kernel k_band_update_mw (the default for rows wider than 4200 px), 3 the generic
+ * one-wave band kernel k_band_update + k_dp_sweep (what delta_x > 2 runs on) whatever the parameters */
 void lqrhip_set_update_mode(int mode);
 /* Cap on the workgroups of the persistent tiled DP sweep (k_dp_tile_p), whose tiles spin on their neighbours and
  * must all be resident: -1 = the bound derived from the occupancy query at lqrhip_init, n >= 0 = min(n, that bound).

@@ -746,16 +746,21 @@ static LqrRetVal update_mmap(LqrCarver *r)
         x_max = MAXI(x_max, r->nrg_xmax[y]);
         x_min = MAXI(x_min - r->delta_x, 0);
         x_max = MINI(x_max + r->delta_x, r->w - 1);
+#ifndef LQR_ORACLE_STRICT      /* `make strict` builds liblqr_oracle_strict.so without this block: liblqr's band exactly as recollected */
         {
             /* Spec delta 6: the children of the pixel carved on the row above are
              * always inside the band.  With heavily tied maps (null energy + masks) the band can shrink
-             * past them, and a pixel would keep a back pointer to the carved pixel; what liblqr does
-             * then is undefined (it follows a dangling pixel id).  For every other pixel the extra
-             * evaluations are no-ops. */
+             * past them, and a pixel keeps a back pointer to the carved pixel.  liblqr then follows the
+             * stale id deterministically (build_vpath below does the same: the id is not found on the
+             * row above, last_x stays, and update_vsmap overwrites the level of a pixel carved earlier) --
+             * a corrupted seam map, which this restatement chooses not to reproduce.  For every other
+             * pixel the extra evaluations are no-ops.  tests/test_oracle_strict.py records which inputs
+             * are affected. */
             const int p = r->vpath_x[y - 1];
             x_min = MINI(x_min, MAXI(p - r->delta_x - 1, 0));
             x_max = MAXI(x_max, MINI(p + r->delta_x, r->w - 1));
         }
+#endif
         {
             long long bw = (long long) x_max - x_min + 1;
             if (bw < 0) bw = 0;

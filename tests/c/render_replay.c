@@ -18,10 +18,21 @@
  *   progress_init           src/render.c:761-779
  * with GIMP's drawables replaced by plain buffers.  Only lqr_* (liblqr-1) entry points are used.
  *
- * usage: render_replay CASE.bin OUT.bin
+ * A second mode replays the INTERACTIVE path on one persistent carver:
+ *   render_interactive      src/render.c:465-574   (resize, the getters at :547-551, read-out, aux layers)
+ *   render_flatten          src/render.c:576-681   (lqr_carver_flatten, getters, read-out)
+ *   render_dump_vmap        src/render.c:683-759   (lqr_vmap_dump on a caller-owned map + lqr_vmap_get_*)
+ * driven by --steps=r120x100,d,f,...  (r WxH = render_interactive to that size, f = render_flatten, d = render_dump_vmap).
+ *
+ * Built with -DREPLAY_DLOPEN the program links to NO carving library: every lqr_* entry point the header declares is
+ * resolved with dlsym from the shared object named by --lib=PATH (--prefix=o for the oracle's renamed exports), so the
+ * same binary replays the plug-in's sequence on the engine, on the oracle, or on a genuine liblqr-1.so.0 where one exists.
+ *
+ * usage: render_replay [--lib=PATH [--prefix=P]] [--steps=...] CASE.bin OUT.bin
  *   CASE.bin: int32 header[20] then the image and the mask layers (see read_case)
  *   OUT.bin:  int32 records (see the emit_* helpers), compared with tests/harness.py's results
  */
+#define _POSIX_C_SOURCE 200809L
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -45,6 +56,123 @@ typedef int gint32;
 
 #ifndef __LQR_H__
 #error "lqr.h must define __LQR_H__ (src/io_functions.h:22-24)"
+#endif
+
+#ifdef REPLAY_DLOPEN
+/* every function include/lqr.h declares from liblqr-1, through a table filled by dlsym */
+#include <dlfcn.h>
+#define LQR_FUNCS(X) \
+    X(lqr_carver_attach) \
+    X(lqr_carver_bias_add_rgb_area) \
+    X(lqr_carver_destroy) \
+    X(lqr_carver_flatten) \
+    X(lqr_carver_get_channels) \
+    X(lqr_carver_get_depth) \
+    X(lqr_carver_get_enl_step) \
+    X(lqr_carver_get_height) \
+    X(lqr_carver_get_orientation) \
+    X(lqr_carver_get_ref_height) \
+    X(lqr_carver_get_ref_width) \
+    X(lqr_carver_get_width) \
+    X(lqr_carver_init) \
+    X(lqr_carver_list_current) \
+    X(lqr_carver_list_next) \
+    X(lqr_carver_list_start) \
+    X(lqr_carver_new) \
+    X(lqr_carver_resize) \
+    X(lqr_carver_rigmask_add_rgb_area) \
+    X(lqr_carver_scan_by_row) \
+    X(lqr_carver_scan_line) \
+    X(lqr_carver_scan_reset) \
+    X(lqr_carver_set_dump_vmaps) \
+    X(lqr_carver_set_energy_function_builtin) \
+    X(lqr_carver_set_enl_step) \
+    X(lqr_carver_set_progress) \
+    X(lqr_carver_set_resize_order) \
+    X(lqr_carver_set_side_switch_frequency) \
+    X(lqr_progress_new) \
+    X(lqr_progress_set_end) \
+    X(lqr_progress_set_end_height_message) \
+    X(lqr_progress_set_end_width_message) \
+    X(lqr_progress_set_init) \
+    X(lqr_progress_set_init_height_message) \
+    X(lqr_progress_set_init_width_message) \
+    X(lqr_progress_set_update) \
+    X(lqr_progress_set_update_step) \
+    X(lqr_vmap_destroy) \
+    X(lqr_vmap_dump) \
+    X(lqr_vmap_get_data) \
+    X(lqr_vmap_get_depth) \
+    X(lqr_vmap_get_height) \
+    X(lqr_vmap_get_orientation) \
+    X(lqr_vmap_get_width) \
+    X(lqr_vmap_list_current) \
+    X(lqr_vmap_list_foreach) \
+    X(lqr_vmap_list_next) \
+    X(lqr_vmap_list_start)
+#define X(name) static __typeof__(name) *p_##name;
+LQR_FUNCS(X)
+#undef X
+static int load_lib(const char *path, const char *prefix)
+{
+    void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    char sym[128];
+    int missing = 0;
+    if (!h) { fprintf(stderr, "replay: dlopen(%s): %s\n", path, dlerror()); return 0; }
+#define X(name) snprintf(sym, sizeof sym, "%s%s", prefix, #name); *(void **) (&p_##name) = dlsym(h, sym); \
+    if (!p_##name) { fprintf(stderr, "replay: %s does not export %s\n", path, sym); missing++; }
+    LQR_FUNCS(X)
+#undef X
+    return missing == 0;
+}
+#define lqr_carver_attach (*p_lqr_carver_attach)
+#define lqr_carver_bias_add_rgb_area (*p_lqr_carver_bias_add_rgb_area)
+#define lqr_carver_destroy (*p_lqr_carver_destroy)
+#define lqr_carver_flatten (*p_lqr_carver_flatten)
+#define lqr_carver_get_channels (*p_lqr_carver_get_channels)
+#define lqr_carver_get_depth (*p_lqr_carver_get_depth)
+#define lqr_carver_get_enl_step (*p_lqr_carver_get_enl_step)
+#define lqr_carver_get_height (*p_lqr_carver_get_height)
+#define lqr_carver_get_orientation (*p_lqr_carver_get_orientation)
+#define lqr_carver_get_ref_height (*p_lqr_carver_get_ref_height)
+#define lqr_carver_get_ref_width (*p_lqr_carver_get_ref_width)
+#define lqr_carver_get_width (*p_lqr_carver_get_width)
+#define lqr_carver_init (*p_lqr_carver_init)
+#define lqr_carver_list_current (*p_lqr_carver_list_current)
+#define lqr_carver_list_next (*p_lqr_carver_list_next)
+#define lqr_carver_list_start (*p_lqr_carver_list_start)
+#define lqr_carver_new (*p_lqr_carver_new)
+#define lqr_carver_resize (*p_lqr_carver_resize)
+#define lqr_carver_rigmask_add_rgb_area (*p_lqr_carver_rigmask_add_rgb_area)
+#define lqr_carver_scan_by_row (*p_lqr_carver_scan_by_row)
+#define lqr_carver_scan_line (*p_lqr_carver_scan_line)
+#define lqr_carver_scan_reset (*p_lqr_carver_scan_reset)
+#define lqr_carver_set_dump_vmaps (*p_lqr_carver_set_dump_vmaps)
+#define lqr_carver_set_energy_function_builtin (*p_lqr_carver_set_energy_function_builtin)
+#define lqr_carver_set_enl_step (*p_lqr_carver_set_enl_step)
+#define lqr_carver_set_progress (*p_lqr_carver_set_progress)
+#define lqr_carver_set_resize_order (*p_lqr_carver_set_resize_order)
+#define lqr_carver_set_side_switch_frequency (*p_lqr_carver_set_side_switch_frequency)
+#define lqr_progress_new (*p_lqr_progress_new)
+#define lqr_progress_set_end (*p_lqr_progress_set_end)
+#define lqr_progress_set_end_height_message (*p_lqr_progress_set_end_height_message)
+#define lqr_progress_set_end_width_message (*p_lqr_progress_set_end_width_message)
+#define lqr_progress_set_init (*p_lqr_progress_set_init)
+#define lqr_progress_set_init_height_message (*p_lqr_progress_set_init_height_message)
+#define lqr_progress_set_init_width_message (*p_lqr_progress_set_init_width_message)
+#define lqr_progress_set_update (*p_lqr_progress_set_update)
+#define lqr_progress_set_update_step (*p_lqr_progress_set_update_step)
+#define lqr_vmap_destroy (*p_lqr_vmap_destroy)
+#define lqr_vmap_dump (*p_lqr_vmap_dump)
+#define lqr_vmap_get_data (*p_lqr_vmap_get_data)
+#define lqr_vmap_get_depth (*p_lqr_vmap_get_depth)
+#define lqr_vmap_get_height (*p_lqr_vmap_get_height)
+#define lqr_vmap_get_orientation (*p_lqr_vmap_get_orientation)
+#define lqr_vmap_get_width (*p_lqr_vmap_get_width)
+#define lqr_vmap_list_current (*p_lqr_vmap_list_current)
+#define lqr_vmap_list_foreach (*p_lqr_vmap_list_foreach)
+#define lqr_vmap_list_next (*p_lqr_vmap_list_next)
+#define lqr_vmap_list_start (*p_lqr_vmap_list_start)
 #endif
 
 #define MEM_CHECK_N(x) do { if ((x) == NULL) { fprintf(stderr, "replay: out of memory\n"); return NULL; } } while (0)
@@ -271,6 +399,103 @@ static gboolean render_noninteractive(LqrCarver *carver, const Layer *layer, con
     return TRUE;
 }
 
+/* ---- the interactive path: one persistent carver, driven step by step (render.c:465-759) -------------------------- */
+static gboolean emit_state_and_layers(LqrCarver *carver, const Layer *layer, const Layer *pres, const Layer *disc, const Layer *rigmask,
+                                      const Vals *vals, gint width, gint height)
+{
+    LqrCarverList *carver_list;
+    Layer dst;
+    /* carver_data->ref_w ... ->enl_step, render.c:547-551 and :653-657 */
+    emit(lqr_carver_get_ref_width(carver)); emit(lqr_carver_get_ref_height(carver));
+    emit(lqr_carver_get_orientation(carver)); emit(lqr_carver_get_depth(carver));
+    emit((gint) (lqr_carver_get_enl_step(carver) * 1000 + 0.5f));
+    emit(lqr_carver_get_width(carver)); emit(lqr_carver_get_height(carver));
+    dst.w = width; dst.h = height; dst.bpp = layer->bpp;
+    dst.px = (guchar *) calloc((size_t) dst.w * dst.h * dst.bpp + 1, 1);
+    if (!dst.px) return FALSE;
+    MEM_CHECK1(write_carver_to_layer(carver, &dst));                                        /* :555, :661 */
+    emit(dst.w); emit(dst.h); emit(dst.bpp);
+    emit_bytes(dst.px, (size_t) dst.w * dst.h * dst.bpp);
+    free(dst.px);
+    if (vals->resize_aux_layers) {                                                          /* :557-563, :663-669 */
+        carver_list = lqr_carver_list_start(carver);
+        if (!write_aux_carver(&carver_list, pres, width, height)) return FALSE;
+        if (!write_aux_carver(&carver_list, disc, width, height)) return FALSE;
+        if (!write_aux_carver(&carver_list, rigmask, width, height)) return FALSE;
+    }
+    return TRUE;
+}
+
+static gboolean render_interactive(LqrCarver *carver, const Layer *layer, const Layer *pres, const Layer *disc, const Layer *rigmask,
+                                   const Vals *vals, gint new_width, gint new_height)        /* render.c:465-574 */
+{
+    LqrRetVal ret = lqr_carver_resize(carver, new_width, new_height);                       /* :529 */
+    emit((gint) ret);
+    MEM_CHECK1(ret);
+    return emit_state_and_layers(carver, layer, pres, disc, rigmask, vals, new_width, new_height);
+}
+
+static gboolean render_flatten(LqrCarver *carver, const Layer *layer, const Layer *pres, const Layer *disc, const Layer *rigmask,
+                               const Vals *vals, gint old_width, gint old_height)            /* render.c:576-681 */
+{
+    LqrRetVal ret = lqr_carver_flatten(carver);                                             /* :636 */
+    emit((gint) ret);
+    MEM_CHECK1(ret);
+    return emit_state_and_layers(carver, layer, pres, disc, rigmask, vals, old_width, old_height);
+}
+
+static gboolean render_dump_vmap(LqrCarver *carver)                                         /* render.c:683-759 */
+{
+    LqrVMap *vmap = lqr_vmap_dump(carver);                                                  /* :722: a map the CALLER owns */
+    gint w, h, depth;
+    gint *buffer;
+    if (!vmap) { fprintf(stderr, "replay: lqr_vmap_dump returned NULL\n"); return FALSE; }
+    w = lqr_vmap_get_width(vmap);                                                           /* write_vmap_to_layer, io_functions.c:216-219 */
+    h = lqr_vmap_get_height(vmap);
+    buffer = lqr_vmap_get_data(vmap);
+    depth = lqr_vmap_get_depth(vmap);
+    emit(w); emit(h); emit(depth); emit(lqr_vmap_get_orientation(vmap));
+    fwrite(buffer, sizeof(gint), (size_t) w * h, out);
+    lqr_vmap_destroy(vmap);
+    return TRUE;
+}
+
+/* --steps=r120x100,d,f,...: the persistent-carver session; the layer's current size follows the steps as the plug-in's
+ * drawable does */
+static gboolean run_steps(LqrCarver *carver, const Layer *layer, const Layer *pres, const Layer *disc, const Layer *rigmask,
+                          const Vals *vals, const char *steps)
+{
+    gint cur_w = layer->w, cur_h = layer->h, n = 0;
+    const char *p = steps;
+    long pos = ftell(out);
+    emit(0);
+    while (*p) {
+        if (*p == 'r') {
+            gint nw = 0, nh = 0;
+            if (sscanf(p, "r%dx%d", &nw, &nh) != 2) { fprintf(stderr, "replay: bad step %s\n", p); return FALSE; }
+            emit('r');
+            if (!render_interactive(carver, layer, pres, disc, rigmask, vals, nw, nh)) return FALSE;
+            cur_w = nw; cur_h = nh;
+        } else if (*p == 'f') {
+            emit('f');
+            if (!render_flatten(carver, layer, pres, disc, rigmask, vals, cur_w, cur_h)) return FALSE;
+        } else if (*p == 'd') {
+            emit('d');
+            if (!render_dump_vmap(carver)) return FALSE;
+        } else {
+            fprintf(stderr, "replay: bad step %s\n", p);
+            return FALSE;
+        }
+        n++;
+        while (*p && *p != ',') p++;
+        if (*p == ',') p++;
+    }
+    fseek(out, pos, SEEK_SET); emit(n); fseek(out, 0, SEEK_END);
+    lqr_carver_destroy(carver);
+    emit(n_init); emit(n_update); emit(n_end);
+    return TRUE;
+}
+
 static int read_layer(FILE *f, Layer *l, gint w, gint h, gint bpp)
 {
     size_t n = (size_t) w * h * bpp;
@@ -288,7 +513,21 @@ int main(int argc, char **argv)
     LqrCarver *carver;
     FILE *f;
     float fl[2];
-    if (argc != 3) { fprintf(stderr, "usage: %s CASE.bin OUT.bin\n", argv[0]); return 2; }
+    const char *steps = NULL, *lib = NULL, *prefix = "";
+    while (argc > 1 && argv[1][0] == '-' && argv[1][1] == '-') {
+        if (!strncmp(argv[1], "--steps=", 8)) steps = argv[1] + 8;
+        else if (!strncmp(argv[1], "--lib=", 6)) lib = argv[1] + 6;
+        else if (!strncmp(argv[1], "--prefix=", 9)) prefix = argv[1] + 9;
+        else { fprintf(stderr, "replay: unknown option %s\n", argv[1]); return 2; }
+        argv++; argc--;
+    }
+    if (argc != 3) { fprintf(stderr, "usage: %s [--lib=PATH [--prefix=P]] [--steps=...] CASE.bin OUT.bin\n", argv[0]); return 2; }
+#ifdef REPLAY_DLOPEN
+    if (!lib) { fprintf(stderr, "replay: this build resolves the library at run time: --lib=PATH\n"); return 2; }
+    if (!load_lib(lib, prefix)) return 3;
+#else
+    if (lib || prefix[0]) { fprintf(stderr, "replay: --lib needs a -DREPLAY_DLOPEN build\n"); return 2; }
+#endif
     f = fopen(argv[1], "rb");
     if (!f || fread(hd, sizeof(gint32), 20, f) != 20 || fread(fl, sizeof(float), 2, f) != 2) { fprintf(stderr, "replay: bad case file\n"); return 2; }
     /* header: w h bpp new_w new_h delta_x nrg_func res_order output_seams resize_aux scaleback no_disc_on_enlarge
@@ -307,7 +546,9 @@ int main(int argc, char **argv)
     if (!out) return 2;
     carver = render_init_carver(&layer, ppres, pdisc, prig, &v);
     if (!carver) { fprintf(stderr, "replay: render_init_carver failed\n"); return 1; }
-    if (!render_noninteractive(carver, &layer, ppres, pdisc, prig, &v)) { fprintf(stderr, "replay: render failed\n"); return 1; }
+    if (steps) {
+        if (!run_steps(carver, &layer, ppres, pdisc, prig, &v, steps)) { fprintf(stderr, "replay: interactive session failed\n"); return 1; }
+    } else if (!render_noninteractive(carver, &layer, ppres, pdisc, prig, &v)) { fprintf(stderr, "replay: render failed\n"); return 1; }
     fclose(out);
     return 0;
 }
