@@ -2143,6 +2143,58 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
             }
         }
     };
+    // UPDATE: the batch's results stay in the registers that held its inputs (m over q_mo[r], back pointers over q_lo[r]) and
+    // are stored after the barrier, in the phase in which this wave used to issue only its next prefetch -- the row loop
+    // issues no memory instruction (the two stores and their address updates were 50 of a 2-px row's 194 cycles).  ONE
+    // instantiation of the loop (it rewrites the staging registers; a second copy makes the compiler keep two sets of
+    // them): a batch that runs past the image computes its surplus rows from re-read copies of the last row and does
+    // not store them; pixels outside the image get an energy of +inf once per batch, which makes their m +inf on
+    // every row (inf + best; and |m_old - inf| is inf or NaN: never "keep" unless m_old is inf already).
+    auto batch_u = [&](int ybase) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            float mc[PX], e[PX], mo[PX];
+            uint32_t lnew = 0;
+            bool ch[PX];
+#pragma unroll
+            for (int k = 0; k < PX; k++) { e[k] = q_e[r][k]; mo[k] = q_mo[r][k]; }
+            if constexpr (DELTA == 1 && !RIGM) {
+                const float left = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1]), DPP_WAVE_SHR1, 0xf, 0xf, true));
+                const float right = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[0]), DPP_WAVE_SHL1, 0xf, 0xf, true));
+                dp_row<PX, LR, RIG, true, false>(mp, left, right, e, mo, (uint32_t) q_lo[r], in, rig_l, rig_r, mc, lnew, ch);
+            } else {
+                float nl[DELTA], nr[DELTA], rf[PX];
+#pragma unroll
+                for (int i = 0; i < DELTA; i++) {
+                    nl[i] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1 - i]), DPP_WAVE_SHR1, 0xf, 0xf, true));
+                    nr[i] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[i]), DPP_WAVE_SHL1, 0xf, 0xf, true));
+                }
+#pragma unroll
+                for (int k = 0; k < PX; k++) rf[k] = RIGM ? q_rf[RIGM ? r : 0][k] : 1.0f;
+                dp_row_g<PX, DELTA, LR, RIG, RIGM, true, false>(mp, nl, nr, e, mo, (uint32_t) q_lo[r], in, rg, rf, mc, lnew, ch);
+            }
+            if (r == 0 && ybase == 0) {          // row 0: m = en, whatever stood there (update_mmap's first row)
+#pragma unroll
+                for (int k = 0; k < PX; k++) mc[k] = e[k];
+                lnew = 0;
+            }
+#pragma unroll
+            for (int k = 0; k < PX; k++) { mp[k] = mc[k]; q_mo[r][k] = mc[k]; }
+            q_lo[r] = (LV) lnew;
+        }
+    };
+    auto store_u = [&](int ybase) {
+        const unsigned inc = own ? (unsigned) stride : 0u, inc4 = inc * 4u;
+        unsigned so = own ? (unsigned) ybase * (unsigned) stride + (unsigned) x0 : (unsigned) h * (unsigned) stride + (unsigned) (PX * lane), so4 = so * 4u;
+        const int nr = min(R, h - ybase);
+#pragma unroll
+        for (int r = 0; r < R; r++, so += inc, so4 += inc4) {
+            if (r < nr) {
+                *(GFV *) ((gu8 *) m_out + so4) = q_mo[r];
+                *(GLV *) (least_out + so) = q_lo[r];
+            }
+        }
+    };
     const bool interior = (x0 - PX * lane >= 0) && (x0 - PX * lane + TILE <= w);      // uniform: the whole tile window is inside the image
 
     const int nblk = (h + RB - 1) / RB;
@@ -2201,8 +2253,18 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     }
                     if (lane == 0) s_polled = j;          // the partner's prefetch may start (see the issue site)
                 }
-                if (yb > 0 && yb + R <= h) { if (interior) batch(yb, std::false_type{}, std::false_type{}); else batch(yb, std::false_type{}, std::true_type{}); }
-                else batch(yb, std::true_type{}, std::true_type{});
+                if constexpr (UPDATE) {
+                    if (!interior) {
+#pragma unroll
+                        for (int r = 0; r < R; r++)
+#pragma unroll
+                            for (int k = 0; k < PX; k++) q_e[r][k] = in[k] ? q_e[r][k] : INF;
+                    }
+                    batch_u(yb);
+                } else {
+                    if (yb > 0 && yb + R <= h) { if (interior) batch(yb, std::false_type{}, std::false_type{}); else batch(yb, std::false_type{}, std::true_type{}); }
+                    else batch(yb, std::true_type{}, std::true_type{});
+                }
                 {
                     FV v;
 #pragma unroll
@@ -2234,6 +2296,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     int spins = 0;
                     while (s_polled < j + 1 && !*(volatile int *) &s_fail && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
                 }
+                if constexpr (UPDATE) store_u(yb);        // the batch this wave has just computed, before its registers are reloaded
                 issue(yb + DPP_W * R);
             }
         }

@@ -1,0 +1,69 @@
+"""The engine's build carries one internal, unversioned LLVM option (-mllvm -amdgpu-sched-strategy=max-ilp: it only
+reschedules instructions; Makefile).  The parity suite must be green with and without it: this test (-m gpu) compiles
+the library a second time WITHOUT the option into tests/c/build/ and runs a cross-section of the parity cases -- every
+update_mmap form, both tie rules, rigidity, delta_x 2, masks, the tolerance boundary -- through that build."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import datasets as D
+import harness as H
+import lqr_ctypes as L
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "gimp-lqr-plugin_amd")
+OUT = os.path.join(ROOT, "tests", "c", "build")
+
+
+@pytest.fixture(scope="module")
+def plain_build():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    os.makedirs(OUT, exist_ok=True)
+    so = os.path.join(OUT, "liblqr-hip-default-sched.so")
+    src = os.path.join(PKG, "csrc", "lqr_hip.hip")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        obj_h, obj_c = os.path.join(OUT, "nosched_hip.o"), os.path.join(OUT, "nosched_carver.o")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-c", src, "-o", obj_h])
+        subprocess.check_call(["gcc", "-O2", "-std=c99", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-c",
+                               os.path.join(PKG, "host", "lqr_carver.c"), "-o", obj_c])
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, obj_h, obj_c, "-lm"])
+    return L.Api(so, "")
+
+
+CASES = [
+    ("photo 300x160 -> 260x140", lambda: D.photo_like(300, 160, 73), 260, 140, {}),
+    ("noise 1200x200 -> 1150x200, every seam switches side", lambda: D.noise(1200, 200, 5), 1150, 200, dict(switch_freq=1000)),
+    ("masks + rigidity + delta 2", lambda: D.photo_like(420, 260, 77), 380, 240,
+     dict(pres=D.ellipse_mask(420, 260), disc=D.band_mask(420, 260, 60, 110), rigmask=D.top_half_mask(420, 260), rigidity=6.0, delta_x=2)),
+    ("flat blocks, null energy", lambda: D.flat_blocks(276, 80, 4), 216, 80, dict(nrg_func=L.LQR_EF_NULL, pres=D.ellipse_mask(276, 80))),
+    ("enlarge", lambda: D.photo_like(120, 90, 9), 170, 90, {}),
+]
+
+
+@pytest.mark.parametrize("mode", [-1, 0, 2, 3])
+def test_parity_without_the_scheduler_option(plain_build, oracle, mode):
+    plain_build.lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]
+    plain_build.lib.lqrhip_set_update_mode(mode)
+    try:
+        for what, make, nw, nh, kw in CASES:
+            img = make()
+            H.assert_same(H.run_case(oracle, img, nw, nh, **kw), H.run_case(plain_build, img, nw, nh, **kw), "%s, update mode %d" % (what, mode))
+    finally:
+        plain_build.lib.lqrhip_set_update_mode(-1)
+
+
+def test_tolerance_boundary_without_the_scheduler_option(plain_build, oracle):
+    import test_tolerance_boundary as TB
+    import tolerance_case as T
+    cols, b = TB.seam_columns(plain_build)
+    _, a = TB.seam_columns(oracle)
+    assert cols == T.EXPECTED_SEAM2_COLUMNS
+    H.assert_same(a, b, "tolerance boundary, default scheduler")
