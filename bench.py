@@ -90,6 +90,7 @@ def parse():
                          "0 = the engine's choice: 4 for 32 images and more, given GPU_MAX_HW_QUEUES >= 8 (set above)")
     ap.add_argument("--update-mode", type=int, default=-1,
                     help="update_mmap kernel: -1 the engine's choice, 0 band, 1 tiled full width, 2 band-mw")
+    ap.add_argument("--dp-px", type=int, default=0, help="pin the persistent tiled sweep's pixels per lane (2 or 4; 0: by batch size)")
     ap.add_argument("--band-kernel", type=int, default=None,
                     help="A/B hook (experiments build): 0 k_band_update_tw, 1 k_band_update_td<4 px>, 2 k_band_update_td<2 px>, 3 k_band_update_ls")
     ap.add_argument("--band-variant", type=int, default=0, help="A/B hook for band-kernel experiments")
@@ -236,6 +237,9 @@ def main():
     lib.lqrhip_sub_batches.argtypes = [C.c_int]
     lib.lqrhip_set_update_mode.argtypes = [C.c_int]
     lib.lqrhip_set_update_mode(args.update_mode)
+    if args.dp_px:
+        lib.lqrhip_set_dp_persistent_px.argtypes = [C.c_int]
+        lib.lqrhip_set_dp_persistent_px(args.dp_px)
     if args.band_kernel is not None or args.band_variant:      # only in a -DLQR_BAND_EXPERIMENTS build of the library
         if not hasattr(lib, "lqrhip_set_band_kernel"):
             raise SystemExit("bench.py: --band-kernel / --band-variant need a library built with -DLQR_BAND_EXPERIMENTS")

@@ -2030,6 +2030,12 @@ static int g_dpp_max_wgs_plain = 0, g_dpp_max_wgs_general = 0;      // ... of th
 // DELTA = delta_x (1 or 2: errors move DELTA columns per row, so a block is HALO / DELTA rows); RIGM = a rigidity mask
 // scales the rigidity term per pixel (one more 4-byte plane read).  The plain instantiations (1, false) use the
 // 3-neighbour row above, the others dp_row_g.
+#ifdef LQR_TILE_TIMING
+__device__ unsigned long long g_tile_dbg[2 * 16];
+#define TT(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); tdbg[i] += t__ - ttprev; ttprev = t__; } while (0)
+#else
+#define TT(i) do { } while (0)
+#endif
 template <int PX, bool LR, bool RIG, bool UPDATE, int DELTA = 1, bool RIGM = false>
 __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err)
 {
@@ -2199,6 +2205,11 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
 
     const int nblk = (h + RB - 1) / RB;
     issue(q * R);
+#ifdef LQR_TILE_TIMING
+    unsigned long long tdbg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ttprev = __builtin_readcyclecounter();
+    const unsigned long long ttstart = ttprev;
+#endif
     for (int j = 0; j < nblk; j++) {
         const int y0 = j * RB;
         const int ylast = min(y0 + RB, h) - 1;
@@ -2206,6 +2217,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
         for (int bb = 0; bb < NBB; bb++) {
             const int yb = y0 + bb * R;
             const bool mine = ((j * NBB + bb) & (DPP_W - 1)) == q && yb < h;          // batches alternate between the two waves
+            TT(0);
             if (mine) {
                 if (yb > 0) {
                     const FV v = s_mp[lane];
@@ -2253,6 +2265,11 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     }
                     if (lane == 0) s_polled = j;          // the partner's prefetch may start (see the issue site)
                 }
+                TT(1);
+#ifdef LQR_TILE_TIMING
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                TT(2);
                 if constexpr (UPDATE) {
                     if (!interior) {
 #pragma unroll
@@ -2265,6 +2282,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     if (yb > 0 && yb + R <= h) { if (interior) batch(yb, std::false_type{}, std::false_type{}); else batch(yb, std::false_type{}, std::true_type{}); }
                     else batch(yb, std::true_type{}, std::true_type{});
                 }
+                TT(3);
                 {
                     FV v;
 #pragma unroll
@@ -2283,8 +2301,10 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     }
                 }
             }
+            TT(4);
             // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. every wave's prefetch
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            TT(5);
             if (s_fail) return;                  // uniform: written before the barrier, read by both waves after it
             // this wave's next batch, issued AFTER the barrier: the ~50 load instructions (~1500 cycles of issue) then
             // run under the partner's compute instead of in front of it
@@ -2296,11 +2316,17 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     int spins = 0;
                     while (s_polled < j + 1 && !*(volatile int *) &s_fail && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
                 }
+                TT(6);
                 if constexpr (UPDATE) store_u(yb);        // the batch this wave has just computed, before its registers are reloaded
+                TT(7);
                 issue(yb + DPP_W * R);
+                TT(8);
             }
         }
     }
+#ifdef LQR_TILE_TIMING
+    if (UPDATE && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && lane == 0) { for (int i = 0; i < 10; i++) g_tile_dbg[q * 16 + i] = tdbg[i]; g_tile_dbg[q * 16 + 10] = __builtin_readcyclecounter() - ttstart; }
+#endif
     if (UPDATE && threadIdx.x == 0) {
         // the update wrote m2 / least2: the tile that finishes last swaps the image's plane pointers in the device
         // descriptor (every tile read the descriptor before it could finish) and re-arms the counter
@@ -2613,6 +2639,9 @@ static int dpp_resident_workgroups(int dev)
     return g_dpp_max_wgs_plain;
 }
 
+#ifdef LQR_TILE_TIMING
+extern "C" int lqrhip_tile_timing(unsigned long long *out) { (void) hipDeviceSynchronize(); return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_dbg), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }
+#endif
 extern "C" int lqrhip_init(void)
 {
     if (g_device >= 0) return g_device;
