@@ -274,7 +274,7 @@ def test_sub_batches_on_separate_streams(oracle, engine, nsub):
         cs = [L.Carver(engine, im).configure() for im in imgs]
         assert L.resize_batch(engine, cs, 840, 230) == L.LQR_OK           # both directions: transposes and flattens per sub-batch
     finally:
-        engine.lib.lqrhip_set_sub_batches(1)
+        engine.lib.lqrhip_set_sub_batches(0)            # back to the engine's own choice
     for im, c in zip(imgs, cs):
         ref = H.run_case(oracle, im, 840, 230)
         assert np.array_equal(c.read_image(), ref["image"])
