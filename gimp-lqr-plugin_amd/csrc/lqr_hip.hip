@@ -423,6 +423,58 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sweep(const DevCarver *cs, Dp
 // loaded into a second register set before this chunk's chase has finished.
 // ---------------------------------------------------------------------------
 #define VP_ROWS 62
+// argmin of row `mrow` (w floats) over a VPATH_THREADS-thread block with liblqr's tie rule: leftmost (lr = 0) / rightmost
+// (lr = 1) of equal minima; returns (to every thread) the column, or -1 if no candidate beat liblqr's start value 2^29.
+// A thread takes 16 B at a time (4 loads in flight per thread, all issued before the first compare: the row is one
+// memory round trip, not fifteen), keeps its own ascending scan, then the block reduces on (value, index) pairs: within
+// a wave by DPP-free shuffles, across the four waves through LDS.
+__device__ __forceinline__ int row_argmin(const gf32 *mrow, int w, int lr, float *s_val, int *s_idx)
+{
+    const int tid = threadIdx.x;
+    const float INF = __int_as_float(0x7f800000);
+    float bv = INF;
+    int bi = -1;
+    for (int base = 0; base < w; base += 16 * VPATH_THREADS) {
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int x = base + 4 * (tid + VPATH_THREADS * i);
+            // whole vectors only where they are inside the row (the planes have >= 16 floats of padding, but not initialised)
+            if (x + 3 < w) v[i] = *(const GLOBAL_AS f32x4 *) (mrow + x);
+            else { v[i] = (f32x4) {INF, INF, INF, INF}; for (int j = 0; j < 4; j++) if (x + j < w) v[i][j] = mrow[x + j]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = base + 4 * (tid + VPATH_THREADS * i) + j;
+                const float f = v[i][j];
+                if (x < w && (f < bv || (f == bv && lr))) { bv = f; bi = x; }
+            }
+    }
+    auto better = [&](float v2, int i2, float v1, int i1) {        // does (v2, i2) replace (v1, i1)?
+        if (i2 < 0) return false;
+        if (i1 < 0) return true;
+        if (v2 < v1) return true;
+        if (v2 > v1) return false;
+        return lr ? (i2 > i1) : (i2 < i1);
+    };
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(bv, o);
+        const int i2 = __shfl_xor(bi, o);
+        if (better(v2, i2, bv, bi)) { bv = v2; bi = i2; }
+    }
+    if ((tid & 63) == 0) { s_val[tid >> 6] = bv; s_idx[tid >> 6] = bi; }
+    __syncthreads();
+    bv = s_val[0]; bi = s_idx[0];
+#pragma unroll
+    for (int k = 1; k < VPATH_THREADS / 64; k++) if (better(s_val[k], s_idx[k], bv, bi)) { bv = s_val[k]; bi = s_idx[k]; }
+    // liblqr starts from m = 2^29: a candidate must beat it (or tie it when lr == 1)
+    const float lim = 536870912.0f;
+    const bool ok = (bi >= 0) && (bv < lim || (bv == lim && lr));
+    return ok ? bi : -1;
+}
+
 // Which side of the seam the carve moves (wave 0 of k_vpath*, after the backtrack): the part right of the
 // seam holds sum(w - 1 - x), the part left of it sum(x) elements over the rows; the shorter one moves, and
 // moving the left part right advances the image's origin by one.  `acc` = this lane's share of sum(x).
@@ -438,43 +490,14 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
 {
     const GCarver c = gview(cs[blockIdx.x]);
     const int org = c.flags[FLAG_ORG];           // read before wave 0 publishes the next one
-    __shared__ float s_val[VPATH_THREADS];
-    __shared__ int s_idx[VPATH_THREADS];
+    __shared__ float s_val[VPATH_THREADS / 64];
+    __shared__ int s_idx[VPATH_THREADS / 64];
     const int tid = threadIdx.x;
 
     // ---- argmin over the last row: leftmost (lr=0) / rightmost (lr=1) of equals
-    const gf32 *mrow = c.m + (size_t) (h - 1) * stride;
-    float bv = __int_as_float(0x7f800000);    // +inf
-    int bi = -1;
-    for (int x = tid; x < w; x += VPATH_THREADS) {
-        float v = mrow[x];
-        if (v < bv || (v == bv && lr)) { bv = v; bi = x; }
-    }
-    s_val[tid] = bv; s_idx[tid] = bi;
-    __syncthreads();
-    for (int s = VPATH_THREADS / 2; s > 0; s >>= 1) {
-        if (tid < s) {
-            float v2 = s_val[tid + s]; int i2 = s_idx[tid + s];
-            float v1 = s_val[tid]; int i1 = s_idx[tid];
-            bool take2;
-            if (i2 < 0) take2 = false;
-            else if (i1 < 0) take2 = true;
-            else if (v2 < v1) take2 = true;
-            else if (v2 > v1) take2 = false;
-            else take2 = lr ? (i2 > i1) : (i2 < i1);
-            if (take2) { s_val[tid] = v2; s_idx[tid] = i2; }
-        }
-        __syncthreads();
-    }
+    const int xmin = row_argmin(c.m + (size_t) (h - 1) * stride, w, lr, s_val, s_idx);
     if (tid >= 64) return;                       // the chase is one wave
-    int x;
-    {
-        // liblqr starts from m = 2^29: a candidate must beat it (or tie it when lr == 1)
-        const float lim = 536870912.0f;
-        float v = s_val[0]; int i = s_idx[0];
-        bool ok = (i >= 0) && (v < lim || (v == lim && lr));
-        x = __builtin_amdgcn_readfirstlane(ok ? i : 0);
-    }
+    int x = __builtin_amdgcn_readfirstlane(max(xmin, 0));
 
     // ---- backtrack
     const int lane = tid;
@@ -527,7 +550,8 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
 }
 
 // ---------------------------------------------------------------------------
-// k_vpath1: k_vpath for delta_x == 1.  The chase is a chain of H dependent steps on one wave, so what counts
+// k_vpath1<DELTA>: k_vpath for delta_x == 1 (described below) and, with 12-row chunks, delta_x == 2.  The chase is a
+// chain of H dependent steps on one wave, so what counts
 // is the length of one step and that the back pointers are there when the chase reaches them.  In k_vpath a step
 // is v_readlane + 7 scalar instructions (find the lane, pull the dword, extract and sign-extend the byte), ~55 ns.
 // Here the rows are taken in chunks of 28:
@@ -548,7 +572,9 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
 // No LEAST_INVALID test: the carve marks a back pointer invalid only next to the seam, inside the interval
 // every form of update_mmap recomputes before the next backtrack, so none survives to this point.
 // ---------------------------------------------------------------------------
-#define VP1_ROWS 28
+// rows per chunk by delta_x: the path drifts up to ROWS * delta_x columns inside a chunk and must stay within lanes 4 .. 60 of the 64
+// spread around its start (<= 28), and the window loaded VP1_AHEAD chunks ahead must still hold those 64 columns
+constexpr int vp1_rows(int delta) { return delta == 1 ? 28 : 12; }
 #define VP1_AHEAD 3
 template <int r>
 __device__ __forceinline__ void vp1_step(const int e, int &o, int &path)
@@ -556,54 +582,27 @@ __device__ __forceinline__ void vp1_step(const int e, int &o, int &path)
     asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(path) : "s"(o), "n"(r));      // lane r <- window offset at row y_top - r
     o += __builtin_amdgcn_readlane(e, o);
 }
-template <int... Rs>
-__device__ __forceinline__ void vp1_chase(const int (&e)[VP1_ROWS / 2], int &o, int &path, std::integer_sequence<int, Rs...>)
+template <int N, int... Rs>
+__device__ __forceinline__ void vp1_chase(const int (&e)[N], int &o, int &path, std::integer_sequence<int, Rs...>)
 {
     (vp1_step<Rs>(e[Rs], o, path), ...);
 }
 
+template <int DELTA>
 __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, int w, int h, int stride, int lr, int log_index)
 {
     const GCarver c = gview(cs[blockIdx.x]);
     const int org = c.flags[FLAG_ORG];           // read before wave 0 publishes the next one
-    __shared__ float s_val[VPATH_THREADS];
-    __shared__ int s_idx[VPATH_THREADS];
+    __shared__ float s_val[VPATH_THREADS / 64];
+    __shared__ int s_idx[VPATH_THREADS / 64];
+    constexpr int VP1_ROWS = vp1_rows(DELTA);
     __shared__ __attribute__((aligned(16))) int8_t s_win[VP1_ROWS * 256];     // the current chunk's rows, 256 columns each
     const int tid = threadIdx.x;
 
     // ---- argmin over the last row: leftmost (lr=0) / rightmost (lr=1) of equals
-    const gf32 *mrow = c.m + (size_t) (h - 1) * stride;
-    float bv = __int_as_float(0x7f800000);    // +inf
-    int bi = -1;
-    for (int x = tid; x < w; x += VPATH_THREADS) {
-        float v = mrow[x];
-        if (v < bv || (v == bv && lr)) { bv = v; bi = x; }
-    }
-    s_val[tid] = bv; s_idx[tid] = bi;
-    __syncthreads();
-    for (int s = VPATH_THREADS / 2; s > 0; s >>= 1) {
-        if (tid < s) {
-            float v2 = s_val[tid + s]; int i2 = s_idx[tid + s];
-            float v1 = s_val[tid]; int i1 = s_idx[tid];
-            bool take2;
-            if (i2 < 0) take2 = false;
-            else if (i1 < 0) take2 = true;
-            else if (v2 < v1) take2 = true;
-            else if (v2 > v1) take2 = false;
-            else take2 = lr ? (i2 > i1) : (i2 < i1);
-            if (take2) { s_val[tid] = v2; s_idx[tid] = i2; }
-        }
-        __syncthreads();
-    }
+    const int xmin = row_argmin(c.m + (size_t) (h - 1) * stride, w, lr, s_val, s_idx);
     if (tid >= 64) return;                       // the chase is one wave
-    int x;
-    {
-        // liblqr starts from m = 2^29: a candidate must beat it (or tie it when lr == 1)
-        const float lim = 536870912.0f;
-        float v = s_val[0]; int i = s_idx[0];
-        bool ok = (i >= 0) && (v < lim || (v == lim && lr));
-        x = __builtin_amdgcn_readfirstlane(ok ? i : 0);
-    }
+    int x = __builtin_amdgcn_readfirstlane(max(xmin, 0));
 
     // ---- backtrack
     const int lane = tid;
@@ -612,7 +611,7 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, i
     constexpr int R = VP1_ROWS, NB = VP1_AHEAD + 1, RL = VP1_ROWS / 4;      // RL loads per chunk, four rows each
     // window [base, base + 256) with base in [cx - 135, cx - 120]: the 64 columns around a start column that has moved up to
     // 88 either way since the load are inside
-    static_assert(VP1_ROWS % 4 == 0 && VP1_AHEAD * VP1_ROWS + 32 <= 120 && VP1_AHEAD * VP1_ROWS + 31 <= 120, "window margin");
+    static_assert(VP1_ROWS % 4 == 0 && VP1_ROWS * DELTA <= 28 && VP1_AHEAD * VP1_ROWS * DELTA + 32 <= 120, "window margin");
     u32x4 regs[NB][RL];                          // ring of packed windows: chunk k lives in regs[k % NB]
     int xa[NB];                                  // their base columns
     auto window_base = [&](int cx) { return (cx - 120) & ~15; };     // multiple of 16: a lane's 16 columns never straddle column 0
@@ -649,7 +648,7 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, i
 #pragma unroll
         for (int k = 0; k < R / 2; k++) e2[k] = e[2 * k] + __builtin_amdgcn_ds_bpermute((lane + e[2 * k]) << 2, e[2 * k + 1]);
         int o = 32, path = 0;
-        vp1_chase(e2, o, path, std::make_integer_sequence<int, R / 2>{});          // lane k <- window offset at row y_top - 2k
+        vp1_chase<R / 2>(e2, o, path, std::make_integer_sequence<int, R / 2>{});          // lane k <- window offset at row y_top - 2k
         // the odd rows, all at once: lane k looks its even row's displacement up at the column it stands on
         const int odd = path + s_win[min(lane, R / 2 - 1) * 512 + relbase + path];
         __builtin_amdgcn_wave_barrier();
@@ -3370,7 +3369,9 @@ extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, 
     {
         ProfScope ps("vpath", b->stream, 0);
         if (p->delta_x == 1)
-            hipLaunchKernelGGL(k_vpath1, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index);
+            hipLaunchKernelGGL(k_vpath1<1>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index);
+        else if (p->delta_x == 2)
+            hipLaunchKernelGGL(k_vpath1<2>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index);
         else
             hipLaunchKernelGGL(k_vpath, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, p->delta_x,
                                log_index);
