@@ -2153,8 +2153,8 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
     // issues no memory instruction (the two stores and their address updates were 50 of a 2-px row's 194 cycles).  ONE
     // instantiation of the loop (it rewrites the staging registers; a second copy makes the compiler keep two sets of
     // them): a batch that runs past the image computes its surplus rows from re-read copies of the last row and does
-    // not store them; pixels outside the image get an energy of +inf once per batch, which makes their m +inf on
-    // every row (inf + best; and |m_old - inf| is inf or NaN: never "keep" unless m_old is inf already).
+    // not store them; pixels outside the image get an energy AND an old value of +inf once per batch, which makes their
+    // m +inf on every row (see the call site).
     auto batch_u = [&](int ybase) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -2271,10 +2271,15 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                 TT(2);
                 if constexpr (UPDATE) {
                     if (!interior) {
+                        // outside the image both the energy and the OLD value become +inf: m = inf + best = inf, and the keep
+                        // rule sees |inf - inf| = NaN -> "unchanged" -> keeps the old +inf.  Masking the energy alone is not
+                        // enough: the plane's columns beyond the image hold whatever the block held before (the carve's vector
+                        // moves shift that along), and a stale NaN there is "unchanged" too -- it stayed, and reached the image's
+                        // last column through the min of the row below (found by scripts/fuzz_parity.py under LQRHIP_POISON=r3)
 #pragma unroll
                         for (int r = 0; r < R; r++)
 #pragma unroll
-                            for (int k = 0; k < PX; k++) q_e[r][k] = in[k] ? q_e[r][k] : INF;
+                            for (int k = 0; k < PX; k++) { q_e[r][k] = in[k] ? q_e[r][k] : INF; q_mo[r][k] = in[k] ? q_mo[r][k] : INF; }
                     }
                     batch_u(yb);
                 } else {
@@ -2690,6 +2695,60 @@ static std::map<void *, size_t> g_pool_size;
 static size_t g_pool_cached = 0;
 static const size_t POOL_MAX_CACHED = (size_t) 24 << 30;
 
+// LQRHIP_POISON=<byte> in the environment (debugging aid, scripts/fuzz_parity.py): every block handed out is first filled
+// with that byte and the device synchronised, so that a kernel that reads memory nothing wrote yet fails the same way every
+// time instead of depending on what the block held before
+// LQRHIP_POISON=r1 / r2 / r3: pseudo-random words that look like what a recycled block holds -- floats in [0, 100),
+// integers in [0, 2048), arbitrary bits
+__global__ void k_poison_random(unsigned *p, size_t n, int mode, int stride, int c0, int c1, int r0, int r1)
+{
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+        if (stride > 0) {       // LQRHIP_POISON_WINDOW=stride:c0:c1:r0:r1 -- only that window of a plane, zero elsewhere
+            const int col = (int) (i % stride), row = (int) (i / stride);
+            if (col < c0 || col >= c1 || row < r0 || row >= r1) { p[i] = 0; continue; }
+        }
+        unsigned hsh = (unsigned) i * 2654435761u + 0x9e3779b9u;
+        hsh ^= hsh >> 15; hsh *= 0x85ebca6bu; hsh ^= hsh >> 13; hsh *= 0xc2b2ae35u; hsh ^= hsh >> 16;
+        p[i] = mode == 1 ? __float_as_uint((float) (hsh >> 8) * (100.0f / 16777216.0f)) : mode == 2 ? (hsh >> 21) : hsh;
+    }
+}
+static const char *g_alloc_name = "";      // what the allocation is for (LQRHIP_POISON_LOG)
+static int g_poison = -2;
+static unsigned g_poison32 = 0;
+static int pool_poison(void *p, size_t sz)
+{
+    if (g_poison == -2) {
+        const char *e = getenv("LQRHIP_POISON");
+        g_poison = -1;
+        if (e && e[0] == '0' && e[1] == 'x') { g_poison = 256; g_poison32 = (unsigned) strtoul(e, nullptr, 16); }     // a 32-bit word
+        else if (e && e[0] == 'r') g_poison = 256 + atoi(e + 1);
+        else if (e && *e) g_poison = atoi(e) & 255;
+    }
+    if (g_poison < 0) return 0;
+    {   // LQRHIP_POISON_RANGE=a:b poisons only the allocations numbered a .. b-1 of the process (LQRHIP_POISON_LOG lists them)
+        static long seq = 0, lo = 0, hi = -1;
+        static int logit = -1;
+        if (logit < 0) {
+            logit = getenv("LQRHIP_POISON_LOG") != nullptr;
+            const char *r = getenv("LQRHIP_POISON_RANGE");
+            if (r) sscanf(r, "%ld:%ld", &lo, &hi);
+        }
+        const long me = seq++;
+        if (logit) fprintf(stderr, "alloc %ld %zu %s\n", me, sz, g_alloc_name);
+        if (hi >= 0 && (me < lo || me >= hi)) { HIPCK(hipMemset(p, 0, sz)); HIPCK(hipDeviceSynchronize()); return 0; }
+    }
+    if (g_poison > 256) {
+        static int win[5] = {0, 0, 0, 0, 0};
+        static bool once = false;
+        if (!once) { once = true; const char *wv = getenv("LQRHIP_POISON_WINDOW"); if (wv) sscanf(wv, "%d:%d:%d:%d:%d", win, win + 1, win + 2, win + 3, win + 4); }
+        hipLaunchKernelGGL(k_poison_random, dim3(1024), dim3(256), 0, 0, (unsigned *) p, sz / 4, g_poison - 256, win[0], win[1], win[2], win[3], win[4]);
+    }
+    else if (g_poison == 256) HIPCK(hipMemsetD32((hipDeviceptr_t) p, (int) g_poison32, sz / 4));
+    else HIPCK(hipMemset(p, g_poison, sz));
+    HIPCK(hipDeviceSynchronize());
+    return 0;
+}
+
 static int pool_alloc(void **p, size_t bytes)
 {
     const size_t sz = (bytes + ((size_t) 1 << 20) - 1) & ~(((size_t) 1 << 20) - 1);      // 1 MiB classes
@@ -2698,7 +2757,7 @@ static int pool_alloc(void **p, size_t bytes)
         *p = it->second;
         g_pool_free.erase(it);
         g_pool_cached -= sz;
-        return 0;
+        return pool_poison(*p, sz);
     }
     hipError_t e = hipMalloc(p, sz);
     if (e == hipErrorOutOfMemory && !g_pool_free.empty()) {       // give the cache back and retry once
@@ -2710,7 +2769,7 @@ static int pool_alloc(void **p, size_t bytes)
     }
     HIPCK(e);
     g_pool_size[*p] = sz;
-    return 0;
+    return pool_poison(*p, sz);
 }
 static void pool_free(void *p)
 {
@@ -2726,11 +2785,13 @@ static void pool_free(void *p)
 }
 
 template <typename T>
-static int dmalloc(T **p, size_t n)
+static int dmalloc_(T **p, size_t n, const char *name)
 {
     *p = nullptr;
+    g_alloc_name = name;
     return pool_alloc((void **) p, (n ? n : 1) * sizeof(T));
 }
+#define dmalloc(p, n) dmalloc_((p), (n), #p)
 template <typename T>
 static void dfree(T *&p)
 {
@@ -3256,8 +3317,12 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
             if (c->m2 && c->least2) continue;
             if (!grew) { HIPCK(hipStreamSynchronize(b->stream)); grew = true; }
             const size_t pe = (size_t) c->stride * (c->wk_h + 1) + 1024;
+            const bool fresh_m2 = !c->m2, fresh_l2 = !c->least2;
             if (!c->m2 && (rc = dmalloc(&c->m2, pe))) return rc;
             if (!c->least2 && (rc = dmalloc(&c->least2, pe))) return rc;
+            // like the first planes (ensure_working): nothing in them depends on what the block held before
+            if (fresh_m2) HIPCK(hipMemsetAsync(c->m2, 0, pe * sizeof(float), b->stream));
+            if (fresh_l2) HIPCK(hipMemsetAsync(c->least2, 0, pe, b->stream));
         }
         if (grew) {
             b->dirty = true;
@@ -3355,8 +3420,40 @@ static const long long g_tiled_update_px = 8LL * 3840 * 2160;
 
 // One seam of a lock-step batch: k_vpath* (pick + backtrack, publishes the side to move) -> k_carve ->
 // k_emap_update -> one form of update_mmap (or the full DP after a side switch), all on the batch's stream.
+static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
+                          int full_rebuild, int leftright_next);
+// LQRHIP_DUMP=<prefix> (debugging aid): after every seam step the first image's seam, flags and DP planes go to
+// <prefix>_<call>.bin -- header {w, h, stride, log_index, FLAG_COUNT}, flags, seam_x[h], m[stride * h], least[stride * h]
 extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
                                 int full_rebuild, int leftright_next)
+{
+    const int rc = seam_step_impl(b, p, w, h, log_index, leftright_pick, full_rebuild, leftright_next);
+    static const char *dump = getenv("LQRHIP_DUMP");
+    if (rc == 0 && dump) {
+        static int call = 0;
+        LqrHipCarver *c = b->cs[0];
+        HIPCK(hipStreamSynchronize(b->stream));
+        const size_t np = (size_t) c->stride * h;
+        std::vector<int> hdr = {w, h, c->stride, log_index, FLAG_COUNT}, flags(FLAG_COUNT), seam(h);
+        std::vector<float> m(np);
+        std::vector<int8_t> least(np);
+        HIPCK(hipMemcpy(flags.data(), c->flags, FLAG_COUNT * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(seam.data(), c->seam_x, (size_t) h * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(m.data(), c->m, np * sizeof(float), hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(least.data(), c->least, np, hipMemcpyDeviceToHost));
+        char path[512];
+        snprintf(path, sizeof path, "%s_%04d.bin", dump, call++);
+        if (FILE *f = fopen(path, "wb")) {
+            fwrite(hdr.data(), sizeof(int), hdr.size(), f); fwrite(flags.data(), sizeof(int), flags.size(), f);
+            fwrite(seam.data(), sizeof(int), seam.size(), f); fwrite(m.data(), sizeof(float), np, f); fwrite(least.data(), 1, np, f);
+            fclose(f);
+        }
+    }
+    return rc;
+}
+
+static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
+                          int full_rebuild, int leftright_next)
 {
     int rc;
     LqrHipCarver *c0 = b->cs[0];

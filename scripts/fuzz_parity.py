@@ -1,7 +1,10 @@
 """Randomised parity run (engine vs oracle through the C ABI) for a fixed wall-clock budget, cycling
 through the three update_mmap paths (cases: tests/fuzz_cases.py).
 
-    python scripts/fuzz_parity.py [seconds] [seed]
+    python scripts/fuzz_parity.py [seconds] [seed] [verbose] [general]
+
+`general` (4th argument) bends every case towards the tiled kernels' general instantiations: delta_x 2 in half the
+cases, a rigidity mask with rigidity in half, and only the engine's own choice of update kernel.
 """
 import ctypes
 import sys
@@ -16,7 +19,15 @@ import lqr_ctypes as L
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-verbose = len(sys.argv) > 3
+verbose = len(sys.argv) > 3 and sys.argv[3] not in ("0", "")
+general = len(sys.argv) > 4
+# FUZZ_ONLY=i,j,...: draw every case (so the random stream stays the same) but run only these indices, each
+# FUZZ_REPEAT times, in every update mode listed in FUZZ_MODES (default: the one the index would have had)
+import os
+only = set(int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x)
+repeat = int(os.environ.get("FUZZ_REPEAT", "1"))
+force_modes = [int(x) for x in os.environ.get("FUZZ_MODES", "").split(",") if x]
+import datasets as D
 rng = np.random.default_rng(seed)
 o = L.oracle_api()
 e = L.engine_api()
@@ -26,17 +37,41 @@ n = fails = 0
 while time.time() < t_end:
     img, nw, nh, kw, what = F.draw_case(rng)
     name, mode = list(F.MODES.items())[n % 3]
-    e.lib.lqrhip_set_update_mode(mode)
+    if general:
+        name, mode = "auto", -1
+        h_, w_ = img.shape[:2]
+        if rng.random() < 0.5:
+            kw["delta_x"] = 2
+        else:
+            kw.pop("delta_x", None)
+        if rng.random() < 0.5:
+            kw["rigmask"] = D.top_half_mask(w_, h_) if rng.random() < 0.5 else D.ellipse_mask(w_, h_)
+            kw["rigidity"] = float(rng.choice([0.5, 3.0, 40.0]))
+        elif rng.random() < 0.5:
+            kw["rigidity"] = float(rng.choice([1.0, 8.0]))
+        what += " general:%s" % {k: v for k, v in kw.items() if k in ("delta_x", "rigidity")} + (" +rigmask" if "rigmask" in kw else "")
+    if only and n not in only:
+        n += 1
+        if n > max(only):
+            break
+        continue
     what = name + " " + what
     if verbose:
         print("case", n, what, flush=True)
-    try:
-        a = H.run_case(o, img, nw, nh, **kw)
-        b = H.run_case(e, img, nw, nh, **kw)
-        H.assert_same(a, b, what)
-    except AssertionError as ex:
-        fails += 1
-        print("FAIL", what, str(ex)[:200], flush=True)
+    a = None
+    for m in (force_modes or [mode]):
+        e.lib.lqrhip_set_update_mode(m)
+        for rep in range(repeat):
+            try:
+                if a is None:
+                    a = H.run_case(o, img, nw, nh, **kw)
+                b = H.run_case(e, img, nw, nh, **kw)
+                H.assert_same(a, b, what)
+                if only:
+                    print("ok   case %d mode %d rep %d" % (n, m, rep), flush=True)
+            except AssertionError as ex:
+                fails += 1
+                print("FAIL case %d mode %d rep %d" % (n, m, rep), what, str(ex)[-120:], flush=True)
     n += 1
 e.lib.lqrhip_set_update_mode(-1)
 print("fuzz: %d cases, %d failures, seed %d" % (n, fails, seed), flush=True)
