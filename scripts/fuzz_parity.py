@@ -27,6 +27,7 @@ import os
 only = set(int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x)
 repeat = int(os.environ.get("FUZZ_REPEAT", "1"))
 force_modes = [int(x) for x in os.environ.get("FUZZ_MODES", "").split(",") if x]
+max_cases = int(os.environ.get("FUZZ_COUNT", "0"))       # stop after this many cases (a deterministic run for the tests)
 import datasets as D
 rng = np.random.default_rng(seed)
 o = L.oracle_api()
@@ -34,7 +35,7 @@ e = L.engine_api()
 e.lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]
 t_end = time.time() + budget
 n = fails = 0
-while time.time() < t_end:
+while time.time() < t_end and not (max_cases and n >= max_cases):
     img, nw, nh, kw, what = F.draw_case(rng)
     name, mode = list(F.MODES.items())[n % 3]
     if general:

@@ -21,10 +21,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_fuzz(poison, seconds, seed, extra=(), only=None):
+def run_fuzz(poison, seconds, seed, extra=(), only=None, count=0):
     env = dict(os.environ, LQRHIP_POISON=poison)
     if only:
         env["FUZZ_ONLY"] = only
+    if count:
+        env["FUZZ_COUNT"] = str(count)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), str(seconds), str(seed), *extra],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
@@ -38,10 +40,10 @@ def test_the_cases_that_found_it():
 
 @pytest.mark.parametrize("poison", ["r3", "r1", "255"])
 def test_seeded_cases_on_poisoned_blocks(poison):
-    out = run_fuzz(poison, 25, 4242)
+    out = run_fuzz(poison, 600, 4242, count=200)
     assert " 0 failures" in out, out[-2000:]
 
 
 def test_general_kernels_on_poisoned_blocks():
-    out = run_fuzz("r3", 25, 4243, extra=("0", "general"))
+    out = run_fuzz("r3", 600, 4243, extra=("0", "general"), count=300)
     assert " 0 failures" in out, out[-2000:]
