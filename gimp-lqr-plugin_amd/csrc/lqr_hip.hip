@@ -715,7 +715,9 @@ __device__ __forceinline__ void store_sc1_x4(gu32 *p, u32x4 v) { asm volatile("g
 // all planes of a group loaded first with CG = 1 (77 VGPRs, 6 waves) 495, 2 (100, 4) 486, 3 (120, 4) 509, 4 (142 VGPRs,
 // 3 waves per SIMD) 470-485, 6 552; CG = 4 squeezed into 128 VGPRs (11 spilled) 531.  Bytes in flight per wave beat
 // occupancy: a row's mean moved part (a quarter of 3840) fits one group of 1024.
+#ifndef CG
 #define CG 4
+#endif
 #define CGPX (CG * 256)
 struct G32 { u32x4 a[CG]; uint32_t edge; };     // 4-byte planes: en, m, rigidity mask
 struct G8 { uint32_t a[CG]; uint32_t edge; };   // the back-pointer bytes, 4 px per dword
