@@ -1678,8 +1678,9 @@ template <bool LR, bool RIG, bool UPDATE, bool MASK>
 __device__ __forceinline__ void dp_row4(const float (&mp)[4], const float left, const float right, const f32x4 e, const f32x4 mo, const uint32_t lo4,
                                         const bool (&in)[4], const float rig_l, const float rig_r, float (&mc)[4], uint32_t &lnew, bool (&ch)[4])
 {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const float INF = __int_as_float(0x7f800000);
-    float nm[4];
+    float best[4];
     uint32_t sel[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1688,25 +1689,33 @@ __device__ __forceinline__ void dp_row4(const float (&mp)[4], const float left, 
         float rr = (k == 3) ? right : mp[k < 3 ? k + 1 : 0];
         if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
         // ascending scan with strict < (LR=0: the leftmost minimum wins) or <= (LR=1: the rightmost)
-        const float best = fminf(fminf(l, cc), rr);
+        best[k] = fminf(fminf(l, cc), rr);
         const uint32_t minus = 0xffu << (8 * k), plus = 0x01u << (8 * k);
-        if (LR) { sel[k] = (cc == best) ? 0u : minus; sel[k] = (rr == best) ? plus : sel[k]; }
-        else { sel[k] = (cc == best) ? 0u : plus; sel[k] = (l == best) ? minus : sel[k]; }
-        nm[k] = __fadd_rn(e[k], best);
+        if (LR) { sel[k] = (cc == best[k]) ? 0u : minus; sel[k] = (rr == best[k]) ? plus : sel[k]; }
+        else { sel[k] = (cc == best[k]) ? 0u : plus; sel[k] = (l == best[k]) ? minus : sel[k]; }
     }
+    // the four sums and the four differences as two packed operations each on the pixel pairs (0, 1) and (2, 3): e and mo
+    // sit in aligned register pairs as loaded, so v_pk_add_f32 takes them where they are (left to itself the compiler pairs
+    // pixels 1 and 2 and pays four v_mov per row for it).  Individually rounded IEEE adds, as __fadd_rn / __fsub_rn.
+    const f32x2 nm01 = (f32x2) {e[0], e[1]} + (f32x2) {best[0], best[1]}, nm23 = (f32x2) {e[2], e[3]} + (f32x2) {best[2], best[3]};
+    const float nm[4] = {nm01[0], nm01[1], nm23[0], nm23[1]};
     lnew = (sel[0] | sel[1]) | (sel[2] | sel[3]);
-    const uint32_t diff = lo4 ^ lnew;
+    if (UPDATE) {
+        const uint32_t diff = lo4 ^ lnew;
+        const f32x2 d01 = (f32x2) {mo[0], mo[1]} - nm01, d23 = (f32x2) {mo[2], mo[3]} - nm23;
+        const float dd[4] = {d01[0], d01[1], d23[0], d23[1]};
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        float v = nm[k];
-        if (UPDATE) {
+        for (int k = 0; k < 4; k++) {
             // keep the stale value iff same parent and (double) fabsf(d) < 1e-5, i.e. fabsf(d) <= 1e-5f
-            float d = fabsf(__fsub_rn(mo[k], v));
+            float d = fabsf(dd[k]);
             d = ((diff >> (8 * k)) & 0xffu) ? INF : d;
             ch[k] = d > 1e-5f;
-            v = ch[k] ? v : mo[k];
+            const float v = ch[k] ? nm[k] : mo[k];
+            mc[k] = (!MASK || in[k]) ? v : INF;
         }
-        mc[k] = (!MASK || in[k]) ? v : INF;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) mc[k] = (!MASK || in[k]) ? nm[k] : INF;
     }
 }
 
@@ -1717,8 +1726,10 @@ __device__ __forceinline__ void dp_row(const float (&mp)[PX], const float left, 
                                        const uint32_t lo, const bool (&in)[PX], const float rig_l, const float rig_r, float (&mc)[PX],
                                        uint32_t &lnew, bool (&ch)[PX])
 {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    static_assert(PX % 2 == 0, "pixel pairs");
     const float INF = __int_as_float(0x7f800000);
-    float nm[PX];
+    float best[PX], nm[PX], dd[PX];
     uint32_t sel[PX];
 #pragma unroll
     for (int k = 0; k < PX; k++) {
@@ -1726,11 +1737,20 @@ __device__ __forceinline__ void dp_row(const float (&mp)[PX], const float left, 
         const float cc = mp[k];
         float rr = (k == PX - 1) ? right : mp[k < PX - 1 ? k + 1 : 0];
         if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
-        const float best = fminf(fminf(l, cc), rr);
+        best[k] = fminf(fminf(l, cc), rr);
         const uint32_t minus = 0xffu << (8 * k), plus = 0x01u << (8 * k);
-        if (LR) { sel[k] = (cc == best) ? 0u : minus; sel[k] = (rr == best) ? plus : sel[k]; }
-        else { sel[k] = (cc == best) ? 0u : plus; sel[k] = (l == best) ? minus : sel[k]; }
-        nm[k] = __fadd_rn(e[k], best);
+        if (LR) { sel[k] = (cc == best[k]) ? 0u : minus; sel[k] = (rr == best[k]) ? plus : sel[k]; }
+        else { sel[k] = (cc == best[k]) ? 0u : plus; sel[k] = (l == best[k]) ? minus : sel[k]; }
+    }
+    // sums and differences as packed operations on the pixel pairs (2j, 2j + 1), as dp_row4
+#pragma unroll
+    for (int j = 0; j < PX / 2; j++) {
+        const f32x2 s2 = (f32x2) {e[2 * j], e[2 * j + 1]} + (f32x2) {best[2 * j], best[2 * j + 1]};
+        nm[2 * j] = s2[0]; nm[2 * j + 1] = s2[1];
+        if (UPDATE) {
+            const f32x2 d2 = (f32x2) {mo[2 * j], mo[2 * j + 1]} - s2;
+            dd[2 * j] = d2[0]; dd[2 * j + 1] = d2[1];
+        }
     }
     lnew = sel[0];
 #pragma unroll
@@ -1741,7 +1761,7 @@ __device__ __forceinline__ void dp_row(const float (&mp)[PX], const float left, 
         float v = nm[k];
         if (UPDATE) {
             // keep the stale value iff same parent and (double) fabsf(d) < 1e-5, i.e. fabsf(d) <= 1e-5f
-            float d = fabsf(__fsub_rn(mo[k], v));
+            float d = fabsf(dd[k]);
             d = ((diff >> (8 * k)) & 0xffu) ? INF : d;
             ch[k] = d > 1e-5f;
             v = ch[k] ? v : mo[k];
