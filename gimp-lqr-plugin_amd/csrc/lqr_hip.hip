@@ -61,6 +61,7 @@
 #define FLAG_ROWS_BASE 64
 #define SF_RW 32
 #define DEVERR_FUSED_TIMEOUT 3
+#define PATCH_DW 16            /* dwords of a row's energy patch: xmin, xmax, up to 14 values */
 #define DP_THREADS 1024
 #define VPATH_THREADS 256
 #define BAND_PXL 4
@@ -84,6 +85,7 @@ struct DevCarver {
     int32_t *seam_x;
     int32_t *seam_log;
     int32_t *flags;
+    float *patch;           // per row: the energies k_emap_update<PATCH> computed for k_carve_pub to apply (PATCH_DW dwords)
 };
 
 // Pointers fetched from a descriptor in memory are "generic" to the compiler, which then
@@ -108,6 +110,7 @@ struct GCarver {
     gi8 *least, *least2;
     gf32 *bias, *rig;
     gi32 *seam_x, *seam_log, *flags;
+    gf32 *patch;
 };
 
 // physical view: plane pointers as allocated (row y starts at y * stride); what the carve and the one-off
@@ -120,6 +123,7 @@ __device__ __forceinline__ GCarver gview_phys(const DevCarver &d)
     g.m2 = (gf32 *) d.m2; g.least2 = (gi8 *) d.least2;
     g.bias = (gf32 *) d.bias; g.rig = (gf32 *) d.rig;
     g.seam_x = (gi32 *) d.seam_x; g.seam_log = (gi32 *) d.seam_log; g.flags = (gi32 *) d.flags;
+    g.patch = (gf32 *) d.patch;
     return g;
 }
 // logical view: the carved planes advanced by the image's current origin, so that x = 0 is the first pixel of
@@ -813,6 +817,7 @@ __device__ __forceinline__ void ld_left_8(const gu32 *row32, int base, int pend,
     }
     g.edge = (lane == 63 && base + CGPX <= pend) ? row32[(base + CGPX) >> 2] : 0u;
 }
+template <bool SC1 = false>
 __device__ __forceinline__ void st_left_8(gu32 *row32, int base, int org, int start, int v, int vprev, int y, int wnew, int lane, const G8 &g)
 {
     const int pend = org + wnew;
@@ -837,7 +842,8 @@ __device__ __forceinline__ void st_left_8(gu32 *row32, int base, int org, int st
                 }
                 o |= (uint32_t) (uint8_t) (int8_t) dx << (8 * j);
             }
-            __builtin_nontemporal_store(o, row32 + (x >> 2));
+            if (SC1) __hip_atomic_store(row32 + (x >> 2), o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through
+            else __builtin_nontemporal_store(o, row32 + (x >> 2));
         }
     }
 }
@@ -855,6 +861,7 @@ __device__ __forceinline__ void ld_right_8(const gu32 *row32, int gbase, int org
     }
     g.edge = (lane == 0 && gbase - 1 >= org) ? row32[(gbase - 4) >> 2] : 0u;
 }
+template <bool SC1 = false>
 __device__ __forceinline__ void st_right_8(gu32 *row32, int gbase, int org, int end_l, int v, int vprev, int y, int lane, const G8 &g)
 {
     const int pfirst = org + 1, ptop = org + 1 + end_l;
@@ -879,13 +886,15 @@ __device__ __forceinline__ void st_right_8(gu32 *row32, int gbase, int org, int 
                 }
                 o |= (uint32_t) (uint8_t) (int8_t) dx << (8 * j);
             }
-            __builtin_nontemporal_store(o, row32 + (x >> 2));
+            if (SC1) __hip_atomic_store(row32 + (x >> 2), o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through
+            else __builtin_nontemporal_store(o, row32 + (x >> 2));
         }
     }
 }
 
 // one row of the carve, by one wave (the body of k_carve's row loop; k_seam_fused's workers run it too).  c = the
 // PHYSICAL view, org / side = what k_vpath* published for this seam, w = the width before the carve.
+template <bool SC1 = false>
 __device__ __forceinline__ void carve_row(const GCarver &c, int org, int side, int y, int w, int stride, int delta, int move_dp, int lane)
 {
     const int wnew = w - 1;
@@ -905,11 +914,11 @@ __device__ __forceinline__ void carve_row(const GCarver &c, int org, int side, i
             G8 L;
             ld_left_u32(en, base, pend, lane, E);
             if (move_dp) { ld_left_u32(mm, base, pend, lane, M); ld_left_8(l32, base, pend, lane, L); }
-            st_left_u32(en, base, pv, pend, lane, E);
-            if (move_dp) { st_left_u32(mm, base, pv, pend, lane, M); st_left_8(l32, base, org, start, v, vprev, y, wnew, lane, L); }
+            st_left_u32<SC1>(en, base, pv, pend, lane, E);
+            if (move_dp) { st_left_u32<SC1>(mm, base, pv, pend, lane, M); st_left_8<SC1>(l32, base, org, start, v, vprev, y, wnew, lane, L); }
         }
         if (rg)
-            for (int base = pv & ~3; base < pend; base += CGPX) { G32 R; ld_left_u32(rg, base, pend, lane, R); st_left_u32(rg, base, pv, pend, lane, R); }
+            for (int base = pv & ~3; base < pend; base += CGPX) { G32 R; ld_left_u32(rg, base, pend, lane, R); st_left_u32<SC1>(rg, base, pv, pend, lane, R); }
     } else {
         const int pv = org + v;
         const int end_l = (y > 0) ? min(wnew, max(v, vprev + delta)) : min(wnew, v);      // back pointers' job: new columns [0, end_l)
@@ -921,11 +930,11 @@ __device__ __forceinline__ void carve_row(const GCarver &c, int org, int side, i
             G8 L;
             ld_right_u32(en, gbase, org, pv, lane, E);
             if (move_dp) { ld_right_u32(mm, gbase, org, pv, lane, M); ld_right_8(l32, gbase, org, ptop, lane, L); }
-            st_right_u32(en, gbase, org, pv, lane, E);
-            if (move_dp) { st_right_u32(mm, gbase, org, pv, lane, M); st_right_8(l32, gbase, org, max(end_l, 0), v, vprev, y, lane, L); }
+            st_right_u32<SC1>(en, gbase, org, pv, lane, E);
+            if (move_dp) { st_right_u32<SC1>(mm, gbase, org, pv, lane, M); st_right_8<SC1>(l32, gbase, org, max(end_l, 0), v, vprev, y, lane, L); }
         }
         if (rg)
-            for (int top = top_u; top > org + 1; top -= CGPX) { G32 R; ld_right_u32(rg, top - CGPX, org, pv, lane, R); st_right_u32(rg, top - CGPX, org, pv, lane, R); }
+            for (int top = top_u; top > org + 1; top -= CGPX) { G32 R; ld_right_u32(rg, top - CGPX, org, pv, lane, R); st_right_u32<SC1>(rg, top - CGPX, org, pv, lane, R); }
     }
 }
 
@@ -973,7 +982,7 @@ __device__ __forceinline__ void carve_rows(const GCarver &c, int org, int side, 
                 if (base[r] < pend) {
                     st_left_u32<CARVE_SC1>(en[r], base[r], pv[r], pend, lane, E[r]);
                     st_left_u32<CARVE_SC1>(mm[r], base[r], pv[r], pend, lane, M[r]);
-                    st_left_8(l32[r], base[r], org, start[r], v[r], vprev[r], ys[r], wnew, lane, L[r]);
+                    st_left_8<CARVE_SC1>(l32[r], base[r], org, start[r], v[r], vprev[r], ys[r], wnew, lane, L[r]);
                     base[r] += CGPX;
                 }
         }
@@ -1008,7 +1017,7 @@ __device__ __forceinline__ void carve_rows(const GCarver &c, int org, int side, 
                     const int gbase = top[r] - CGPX;
                     st_right_u32<CARVE_SC1>(en[r], gbase, org, pv[r], lane, E[r]);
                     st_right_u32<CARVE_SC1>(mm[r], gbase, org, pv[r], lane, M[r]);
-                    st_right_8(l32[r], gbase, org, max(end_l[r], 0), v[r], vprev[r], ys[r], lane, L[r]);
+                    st_right_8<CARVE_SC1>(l32[r], gbase, org, max(end_l[r], 0), v[r], vprev[r], ys[r], lane, L[r]);
                     top[r] -= CGPX;
                 }
         }
@@ -1029,6 +1038,38 @@ __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h
     const int org = c.flags[FLAG_ORG_PREV], side = c.flags[FLAG_SIDE];      // published by k_vpath* for this seam
     const int lane = threadIdx.x & 63;
     for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < h; y += gridDim.x * 4) carve_row(c, org, side, y, w, stride, delta, move_dp, lane);
+}
+
+// k_carve that announces its rows (lqrhip_set_fused(3)): every store write-through, then the
+// row's new energies from the patch k_emap_update<PATCH> left (PATCH_DW dwords per row: xmin, xmax, the values), then the
+// wave counts its row into the 32-row chunk; the wave that completes a chunk resets the counter and stores the launch's tag
+// into the chunk word k_band_update_tw_f polls.  Write-through stores that have completed (s_waitcnt vmcnt(0)) are visible
+// device-wide, so no L2 write-back (release fence) is needed before the count.
+__global__ __launch_bounds__(256) void k_carve_pub(const DevCarver *cs, int w, int h, int stride, int delta, int tag)
+{
+    const GCarver c = gview_phys(cs[blockIdx.y]);
+    const int org = c.flags[FLAG_ORG_PREV], side = c.flags[FLAG_SIDE];      // published by k_vpath* for this seam
+    const int lane = threadIdx.x & 63;
+    const int nchunks = (h + SF_RW - 1) / SF_RW;
+    for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < h; y += gridDim.x * 4) {
+        const gi32 *pt = (const gi32 *) c.patch + (size_t) y * PATCH_DW;
+        const int xmin = pt[0], xmax = pt[1];
+        const int x = xmin + lane;
+        const int pv = (x <= xmax) ? pt[2 + min(lane, PATCH_DW - 3)] : 0;
+        carve_row<true>(c, org, side, y, w, stride, delta, 1, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the row's stores first: the patch lands on top of them
+        if (x <= xmax) __hip_atomic_store((gi32 *) c.en + (size_t) y * stride + (org + side) + x, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const int ch = y / SF_RW;
+            gi32 *cnt = c.flags + FLAG_ROWS_BASE + nchunks + 64 + ch;
+            const int rows = min(SF_RW, h - ch * SF_RW);
+            if (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == rows - 1) {
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(c.flags + FLAG_ROWS_BASE + ch, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // changed-energy interval of row y after carving (liblqr update_emap), w = new width
@@ -1070,7 +1111,9 @@ __device__ __forceinline__ int block_rank_256(bool flag, int *s_wave, int &total
 // seam moves at most delta_x per row: at most max(4*delta_x + 2, 2*delta_x + 4) columns.  EU_NT is a template
 // parameter chosen by the launch from delta_x: 12 (delta_x <= 2), 36 (<= 8), 68 (<= 16 = LQRHIP_MAX_DELTA).
 #define EU_ROWS 62          // rows per block (+2 halo rows)
-template <int NRG, int EU_NT>
+// PATCH: the energies go to the row's patch (k_carve_pub applies them once it has moved the row) instead of `en`, so that
+// this kernel can run BEFORE the carve; rows without a changed interval get an empty one
+template <int NRG, int EU_NT, bool PATCH = false>
 __global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, int w, int h, int stride, int k, int epoch)
 {
     const GCarver c = gview(cs[blockIdx.y]);
@@ -1122,10 +1165,15 @@ __global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, 
     slo[tid] = lo;
     __syncthreads();
     if (!row_ok || tid == 0 || tid == 63) return;
+    if (PATCH) {
+        gi32 *pt = (gi32 *) c.patch + (size_t) y * PATCH_DW;
+        pt[0] = xmin; pt[1] = min(xmax, xmin + PATCH_DW - 3);          // (an interval is at most 6 columns where this form runs)
+    }
     for (int x = xmin; x <= xmax; x++) {
         float e = grad_energy_f<NRG>([&](int xx, int yy) { const int t = tid + (yy - y); return bt[t][xx - slo[t]]; }, x, y, w, h);
         if (c.bias) e = __fadd_rn(e, __fdiv_rn(bb[tid][x - lo], (float) p.w_start));
-        c.en[(size_t) y * stride + x] = e;
+        if (PATCH) { if (x - xmin < PATCH_DW - 2) c.patch[(size_t) y * PATCH_DW + 2 + (x - xmin)] = e; }
+        else c.en[(size_t) y * stride + x] = e;
     }
 }
 
@@ -2935,6 +2983,7 @@ struct LqrHipCarver {
     float *en = nullptr, *m = nullptr, *m2 = nullptr, *bias = nullptr, *rig = nullptr;
     int8_t *least = nullptr, *least2 = nullptr;
     int32_t *seam_x = nullptr, *seam_log = nullptr, *flags = nullptr;
+    float *patch = nullptr;          // energy patches of lqrhip_set_fused(3), allocated with its first launch
     int log_cap = 0, log_h = 0;
     int frozen_epoch = 0;           // pix / bias are in the frame before seam `frozen_epoch` of the session
     LqrHipCarver *root = nullptr;
@@ -3243,7 +3292,7 @@ extern "C" LqrHipCarver *lqrhip_carver_create(const unsigned char *rgb, int w, i
 static void free_working(LqrHipCarver *c)
 {
     dfree(c->pix); dfree(c->en); dfree(c->m); dfree(c->least); dfree(c->m2); dfree(c->least2); dfree(c->bias); dfree(c->rig);
-    dfree(c->seam_x); dfree(c->seam_log); dfree(c->flags);
+    dfree(c->seam_x); dfree(c->seam_log); dfree(c->flags); dfree(c->patch);
     c->log_cap = 0;
 }
 
@@ -3288,7 +3337,7 @@ static int ensure_working(LqrHipCarver *c, int w, int h)
     size_t n = (size_t) stride * (h + 1) + 1024;
     int rc;
     if ((rc = dmalloc(&c->pix, n)) || (rc = dmalloc(&c->en, n)) || (rc = dmalloc(&c->m, n)) || (rc = dmalloc(&c->least, n)) ||
-        (rc = dmalloc(&c->seam_x, (size_t) h + 8)) || (rc = dmalloc(&c->flags, (size_t) FLAG_ROWS_BASE + (h + SF_RW - 1) / SF_RW + 64)) ||
+        (rc = dmalloc(&c->seam_x, (size_t) h + 8)) || (rc = dmalloc(&c->flags, (size_t) FLAG_ROWS_BASE + 2 * ((h + SF_RW - 1) / SF_RW + 64))) ||
         (need_bias && (rc = dmalloc(&c->bias, n))) || (need_rig && (rc = dmalloc(&c->rig, n)))) {
         free_working(c);            // never leave a half-allocated set behind: a retry must not pass the early-out above
         return rc;
@@ -3298,7 +3347,7 @@ static int ensure_working(LqrHipCarver *c, int w, int h)
     if (e == hipSuccess) e = hipMemsetAsync(c->m, 0, n * sizeof(float), g_stream0);
     if (e == hipSuccess) e = hipMemsetAsync(c->en, 0, n * sizeof(float), g_stream0);
     if (e == hipSuccess) e = hipMemsetAsync(c->pix, 0, n * sizeof(uint32_t), g_stream0);
-    if (e == hipSuccess) e = hipMemsetAsync(c->flags, 0, ((size_t) FLAG_ROWS_BASE + (h + SF_RW - 1) / SF_RW + 64) * sizeof(int32_t), g_stream0);
+    if (e == hipSuccess) e = hipMemsetAsync(c->flags, 0, ((size_t) FLAG_ROWS_BASE + 2 * ((h + SF_RW - 1) / SF_RW + 64)) * sizeof(int32_t), g_stream0);
     if (e == hipSuccess) e = hipStreamSynchronize(g_stream0);
     if (e != hipSuccess) { free_working(c); HIPCK(e); }
     c->stride = stride; c->wk_h = h;
@@ -3451,7 +3500,7 @@ static DevCarver make_desc(const LqrHipCarver *c)
     DevCarver d;
     d.rgb0 = c->rgb0; d.vs = c->vs; d.bias0 = c->bias0; d.rig0 = c->rig0;
     d.pix = c->pix; d.en = c->en; d.m = c->m; d.least = c->least; d.m2 = c->m2; d.least2 = c->least2; d.bias = c->bias; d.rig = c->rig;
-    d.seam_x = c->seam_x; d.seam_log = c->seam_log; d.flags = c->flags;
+    d.seam_x = c->seam_x; d.seam_log = c->seam_log; d.flags = c->flags; d.patch = c->patch;
     return d;
 }
 
@@ -3500,8 +3549,9 @@ struct ProfScope {
 extern "C" void lqrhip_prof_enable(int on) { g_prof = on; }
 static int g_update_mode = -1;
 // wherever k_band_update_tw would run -- 0 (default): k_carve, k_emap_update, k_band_update_tw; 1: k_seam_work (carve + energy
-// update, publishing its progress) then k_band_update_tw_f on the batch's stream; 2: the two on two streams, side by side.
-// 1 and 2 are parity-green and SLOWER (64 x 4K: 391 k / 396 k against 540 k; DESIGN.md section 4.14 has the accounting), so
+// update, publishing its progress) then k_band_update_tw_f on the batch's stream; 2: the two on two streams, side by side;
+// 3: k_emap_update<PATCH> + k_carve_pub on the second stream, k_band_update_tw_f next to them on the batch's.
+// 1, 2 and 3 are parity-green and SLOWER (64 x 4K: 391 k / 396 k / 392 k against 540 k), so
 // they stay opt-in: lqrhip_set_fused, or LQRHIP_FUSED in the environment.
 static int g_fused = getenv("LQRHIP_FUSED") ? atoi(getenv("LQRHIP_FUSED")) : 0;
 extern "C" void lqrhip_set_fused(int mode) { g_fused = mode; }
@@ -3857,7 +3907,17 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
             const int epoch = c0->frozen_epoch;
             b->fuse_tag = b->fuse_tag % 0x3fffffff + 1;                 // never 0 (the chunk words start cleared)
             const int nchunks = (h + SF_RW - 1) / SF_RW;
-            const bool two = g_fused == 2;
+            const bool two = g_fused >= 2, pub = g_fused == 3;
+            if (pub) {
+                // the patch planes, allocated with the first such launch
+                bool grew = false;
+                for (auto *c : b->cs)
+                    if (!c->patch) {
+                        if (!grew) { HIPCK(hipStreamSynchronize(b->stream)); grew = true; }
+                        if ((rc = dmalloc(&c->patch, (size_t) c->wk_h * PATCH_DW + 64))) return rc;
+                    }
+                if (grew) { b->dirty = true; if ((rc = batch_upload(b))) return rc; }
+            }
             if (two && !b->stream_w) {
                 HIPCK(hipStreamCreateWithFlags(&b->stream_w, hipStreamNonBlocking));
                 HIPCK(hipEventCreateWithFlags(&b->ev_seam, hipEventDisableTiming));
@@ -3869,7 +3929,18 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
                 HIPCK(hipEventRecord(b->ev_seam, b->stream));
                 HIPCK(hipStreamWaitEvent(sw, b->ev_seam, 0));
             }
-            {
+            if (pub) {
+                // the energies first, into the rows' patches (they need the seam, not the carved planes) ...
+                {
+                    ProfScope ps("emap_update", sw, 0);
+#define LAUNCH_EPATCH(N) hipLaunchKernelGGL((k_emap_update<N, 12, true>), dim3((h + EU_ROWS - 1) / EU_ROWS, n), dim3(64), 0, sw, b->d_desc, k, wnew, h, stride, log_index, epoch)
+                    NRG_DISPATCH(p->nrg_func, LAUNCH_EPATCH)
+#undef LAUNCH_EPATCH
+                }
+                // ... then the carve that applies them and announces its rows
+                ProfScope ps("carve", sw, 4.0 * (double) w * h * n);
+                hipLaunchKernelGGL(k_carve_pub, dim3((h + 3) / 4, n), dim3(256), 0, sw, b->d_desc, w, h, stride, p->delta_x, b->fuse_tag);
+            } else {
                 // "carve": the roofline kernel's scope -- the launch that contains the carve (bench.py names the kernel)
                 ProfScope ps("carve", sw, 4.0 * (double) w * h * n);
 #define LAUNCH_WORK(N) hipLaunchKernelGGL((k_seam_work<N>), dim3(n, nchunks), dim3(512), 0, sw, b->d_desc, k, w, h, stride, log_index, epoch, b->fuse_tag)

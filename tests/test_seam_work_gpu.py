@@ -1,6 +1,6 @@
 """The progress-publishing carve (k_seam_work) and the band update that waits for it (k_band_update_tw_f), -m gpu.
 
-DESIGN.md section 4.14: opt-in forms of the seam round (lqrhip_set_fused 1: one stream, 2: two streams).  They are slower
+DESIGN.md section 4.14: opt-in forms of the seam round (lqrhip_set_fused 1: one stream, 2: two streams, 3: k_carve_pub).  They are slower
 than the default and stay in the library as the measured record of that experiment -- and must stay bit-identical to the
 oracle: seeded cases of tests/fuzz_cases.py in child processes (LQRHIP_FUSED is read when the library is loaded), and a
 batch on two streams compared with the default path in this process."""
@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("mode", ["1", "2", "3"])
 def test_seeded_cases(mode):
     env = dict(os.environ, LQRHIP_FUSED=mode, FUZZ_COUNT="150", GPU_MAX_HW_QUEUES="16")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "600", "5150"], cwd=ROOT, env=env,
@@ -28,7 +28,7 @@ def test_seeded_cases(mode):
     assert r.returncode == 0 and " 0 failures" in r.stdout, (r.stdout[-3000:], r.stderr[-1000:])
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_batch_matches_default_path(engine, mode):
     lib = engine.lib
     lib.lqrhip_set_fused.argtypes = [ctypes.c_int]
