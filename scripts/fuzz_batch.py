@@ -1,0 +1,72 @@
+"""Randomised parity run for lock-step BATCHES (lqrx_carver_resize_batch): groups of 2-9 images of one size with different
+contents and common parameters, engine as one batch vs oracle image by image; sub-batch streams, update modes and the
+opt-in seam-round forms vary with the case.
+
+    python scripts/fuzz_batch.py [seconds] [seed]
+"""
+import ctypes
+import os
+import sys
+import time
+
+sys.path.insert(0, "tests")
+import numpy as np
+
+import datasets as D
+import harness as H
+import lqr_ctypes as L
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+max_cases = int(os.environ.get("FUZZ_COUNT", "0"))
+rng = np.random.default_rng(seed)
+o = L.oracle_api()
+e = L.engine_api()
+lib = e.lib
+for f in ("lqrhip_set_update_mode", "lqrhip_set_sub_batches", "lqrhip_set_fused"):
+    getattr(lib, f).argtypes = [ctypes.c_int]
+t_end = time.time() + budget
+n = fails = 0
+while time.time() < t_end and not (max_cases and n >= max_cases):
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        w, h = int(rng.integers(900, 2400)), int(rng.integers(40, 160))
+    elif kind == 1:
+        w, h = int(rng.integers(300, 1000)), int(rng.integers(100, 400))
+    else:
+        w, h = int(rng.integers(16, 300)), int(rng.integers(8, 150))
+    nimg = int(rng.integers(2, 10))
+    ch = int(rng.integers(1, 5))
+    gens = [D.noise, D.photo_like, D.flat_blocks]
+    imgs = [gens[int(rng.integers(0, 3))](w, h, int(rng.integers(0, 1 << 30)), channels=ch) for _ in range(nimg)]
+    dw = int(rng.integers(-min(w - 2, 60), 40))
+    dh = int(rng.integers(-min(h - 2, 30), 15)) if rng.random() < 0.4 else 0
+    kw = dict(nrg_func=int(rng.integers(0, 7)), switch_freq=int(rng.choice([0, 1, 2, 3, 9])), res_order=int(rng.integers(0, 2)))
+    if rng.random() < 0.2:
+        kw.update(rigidity=float(rng.choice([1.0, 8.0])))
+    if rng.random() < 0.2:
+        kw.update(delta_x=int(rng.choice([2, 3])))
+    masks = rng.random() < 0.2
+    mode = int(rng.choice([-1, 0, 1, 2]))
+    sub = int(rng.choice([1, 1, 2, 3]))
+    fused = int(rng.choice([0, 0, 1, 2, 3]))
+    what = "%d x %dx%d ch%d -> %dx%d %s%s mode %d sub %d fused %d" % (nimg, w, h, ch, w + dw, h + dh, kw, " +masks" if masks else "", mode, sub, fused)
+    lib.lqrhip_set_update_mode(mode); lib.lqrhip_set_sub_batches(sub); lib.lqrhip_set_fused(fused)
+    mk = dict(pres=D.ellipse_mask(w, h), disc=D.band_mask(w, h, w // 5, w // 3)) if masks else {}
+    try:
+        cs = [H.init_carver(e, im, w + dw, h + dh, **kw, **mk)[0] for im in imgs]
+        assert L.resize_batch(e, cs, w + dw, h + dh) == L.LQR_OK, "resize_batch failed: %s" % lib.lqrhip_last_error().decode()
+        for i, (im, c) in enumerate(zip(imgs, cs)):
+            ref = H.run_case(o, im, w + dw, h + dh, **kw, **mk)
+            got_img, got_map = c.read_image(), c.vmap_dump()["data"]
+            assert np.array_equal(got_map, ref["vmap"]["data"]), "image %d: seam maps differ" % i
+            assert np.array_equal(got_img, ref["image"]), "image %d: pixels differ" % i
+        for c in cs:
+            c.destroy()
+    except AssertionError as ex:
+        fails += 1
+        print("FAIL case %d" % n, what, str(ex)[:160], flush=True)
+    n += 1
+lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_sub_batches(0); lib.lqrhip_set_fused(0)
+print("batch fuzz: %d cases, %d failures, seed %d" % (n, fails, seed), flush=True)
+sys.exit(1 if fails else 0)

@@ -1,0 +1,22 @@
+"""Randomised lock-step batches (-m gpu): scripts/fuzz_batch.py with a fixed number of seeded cases -- groups of 2-9 images,
+sub-batch streams 1-3, every update mode, every form of the seam round -- each image compared with the oracle's result
+for it; once on plain device memory, once on recycled blocks filled with arbitrary bits (LQRHIP_POISON=r3)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("poison", ["", "r3"])
+def test_seeded_batches(poison):
+    env = dict(os.environ, FUZZ_COUNT="160", GPU_MAX_HW_QUEUES="16")
+    if poison:
+        env["LQRHIP_POISON"] = poison
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_batch.py"), "600", "7700"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " 0 failures" in r.stdout, (r.stdout[-3000:], r.stderr[-1000:])
