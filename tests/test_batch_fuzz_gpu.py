@@ -20,3 +20,12 @@ def test_seeded_batches(poison):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_batch.py"), "600", "7700"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " 0 failures" in r.stdout, (r.stdout[-3000:], r.stderr[-1000:])
+
+
+def test_seeded_interactive_sequences():
+    """scripts/fuzz_interactive.py: persistent carvers, random sequences of resizes (inside and beyond the cached map,
+    both directions) and flattens; getters, image and dumped map compared with the oracle after every call"""
+    env = dict(os.environ, FUZZ_COUNT="400")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_interactive.py"), "600", "7701"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " 0 failures" in r.stdout, (r.stdout[-3000:], r.stderr[-1000:])
