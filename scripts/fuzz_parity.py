@@ -28,6 +28,9 @@ only = set(int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x)
 repeat = int(os.environ.get("FUZZ_REPEAT", "1"))
 force_modes = [int(x) for x in os.environ.get("FUZZ_MODES", "").split(",") if x]
 max_cases = int(os.environ.get("FUZZ_COUNT", "0"))       # stop after this many cases (a deterministic run for the tests)
+# FUZZ_EXTRAS=1: the plug-in's other switches too, drawn from a second stream (the cases themselves stay the same): seam-map
+# output, attached mask layers resized along, LqR-back, discard masks kept on enlargement, the enlargement step
+extras = np.random.default_rng(seed + 1000003) if os.environ.get("FUZZ_EXTRAS") else None
 import datasets as D
 rng = np.random.default_rng(seed)
 o = L.oracle_api()
@@ -51,6 +54,11 @@ while time.time() < t_end and not (max_cases and n >= max_cases):
         elif rng.random() < 0.5:
             kw["rigidity"] = float(rng.choice([1.0, 8.0]))
         what += " general:%s" % {k: v for k, v in kw.items() if k in ("delta_x", "rigidity")} + (" +rigmask" if "rigmask" in kw else "")
+    if extras is not None:
+        ex = dict(output_seams=bool(extras.random() < 0.3), resize_aux_layers=bool(extras.random() < 0.3), scaleback=bool(extras.random() < 0.25),
+                  no_disc_on_enlarge=bool(extras.random() < 0.7), enl_step=float(extras.choice([150.0, 110.0, 200.0])))
+        kw.update(ex)
+        what += " extras:%s" % {k: v for k, v in ex.items() if v not in (False, 150.0)}
     if only and n not in only:
         n += 1
         if n > max(only):

@@ -29,3 +29,12 @@ def test_seeded_interactive_sequences():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_interactive.py"), "600", "7701"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " 0 failures" in r.stdout, (r.stdout[-3000:], r.stderr[-1000:])
+
+
+def test_seeded_cases_with_the_plugins_other_switches():
+    """scripts/fuzz_parity.py with FUZZ_EXTRAS: seam-map output, attached layers resized along, LqR-back, discard masks kept
+    on enlargement, other enlargement steps -- on top of the usual seeded cases"""
+    env = dict(os.environ, FUZZ_COUNT="150", FUZZ_EXTRAS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "600", "7702"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " 0 failures" in r.stdout, (r.stdout[-3000:], r.stderr[-1000:])
