@@ -3810,7 +3810,9 @@ extern "C" int lqrhip_mmap_build(LqrHipBatch *b, const LqrHipDpParams *p, int w,
     return launch_dp<false>(b, make_dpk(p, b->cs[0]->ch), w, h, leftright);
 }
 
+#ifndef FROZEN_LAG_MAX
 #define FROZEN_LAG_MAX 128      // seams the frozen planes may lag behind before they are compacted
+#endif
 
 // remove seams [epoch, to) from the frozen planes of every carver of the batch
 static int frozen_catchup(LqrHipBatch *b, int to, int w_at_to, int h)
