@@ -1111,6 +1111,9 @@ __device__ __forceinline__ int block_rank_256(bool flag, int *s_wave, int &total
 // seam moves at most delta_x per row: at most max(4*delta_x + 2, 2*delta_x + 4) columns.  EU_NT is a template
 // parameter chosen by the launch from delta_x: 12 (delta_x <= 2), 36 (<= 8), 68 (<= 16 = LQRHIP_MAX_DELTA).
 #define EU_ROWS 62          // rows per block (+2 halo rows)
+#ifndef EU_LOGB
+#define EU_LOGB 8            // log entries fetched per round of the walk back to the frozen frame
+#endif
 // PATCH: the energies go to the row's patch (k_carve_pub applies them once it has moved the row) instead of `en`, so that
 // this kernel can run BEFORE the carve; rows without a changed interval get an empty one
 template <int NRG, int EU_NT, bool PATCH = false>
@@ -1142,12 +1145,12 @@ __global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, 
         // below `epoch` are clamped and their values replaced by one that moves nothing), so that a row does not wait
         // for one global load per logged seam
         const gi32 *lg = c.seam_log + y;
-        for (int j = k; j >= epoch; j -= 8) {
-            int v[8];
+        for (int j = k; j >= epoch; j -= EU_LOGB) {
+            int v[EU_LOGB];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = lg[(size_t) max(j - u, epoch) * h];
+            for (int u = 0; u < EU_LOGB; u++) v[u] = lg[(size_t) max(j - u, epoch) * h];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < EU_LOGB; u++) {
                 const int vu = (j - u >= epoch) ? v[u] : 0x7fffffff;
 #pragma unroll
                 for (int i = 0; i < EU_NT; i++) pos[i] += (vu <= pos[i]) ? 1 : 0;
