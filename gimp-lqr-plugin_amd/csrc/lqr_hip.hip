@@ -2473,6 +2473,9 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
 #pragma unroll
     for (int k = 0; k < PX; k++) in[k] = lane_in && x0 + k < w;
 
+#ifndef DPP_RIGM32
+#define DPP_RIGM32 1          // the rigidity-mask instantiation too (256 VGPRs, no spill): config 5 with a mask 46.8 -> 50.2 k
+#endif
 #ifndef DPP_R2
 #define DPP_R2 32
 #endif
@@ -2480,7 +2483,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
     // block, as the delta_x = 2 instantiations do with their 16-row blocks): half the hand-overs, barriers and loop
     // iterations of 16-row batches for 80 more staging registers (193 VGPRs, no spill; the residency bound is queried per
     // instantiation).  Measured on one box: 4K 20.0 -> 21.85 k, FHD 12.3 -> 13.1 k, config 5 50.9 -> 55.9 k.
-    constexpr int R = (PX == 2 && DELTA == 1 && !RIGM) ? DPP_R2 : DPP_R;
+    constexpr int R = (PX == 2 && DELTA == 1 && (!RIGM || DPP_RIGM32)) ? DPP_R2 : DPP_R;
     FV q_e[R], q_mo[R], q_rf[RIGM ? R : 1];
     LV q_lo[R];
     constexpr int RB = HALO / DELTA, NBB = RB / R;          // rows, batches per block
