@@ -2426,6 +2426,7 @@ constexpr int DPP_BLK_BITS = 12;                // bits of the block index in a 
 // co-residency bound for the spin waits, set from the occupancy query in lqrhip_init (dpp_resident_workgroups)
 static int g_dpp_max_wgs = 0;
 static int g_dpp_max_wgs_plain = 0, g_dpp_max_wgs_general = 0;      // ... of the plain / the delta_x = 2, rigidity-mask instantiations
+static int g_dpp_max_wgs_px4 = 0;                                   // ... of the plain 4-px instantiations alone (fewer registers than the 2-px ones)
 
 
 // DELTA = delta_x (1 or 2: errors move DELTA columns per row, so a block is HALO / DELTA rows); RIGM = a rigidity mask
@@ -3047,6 +3048,9 @@ static int dpp_resident_workgroups(int dev)
     };
     q(k_dp_tile_p<4, false, false, false>); q(k_dp_tile_p<4, false, true, false>); q(k_dp_tile_p<4, true, false, false>); q(k_dp_tile_p<4, true, true, false>);
     q(k_dp_tile_p<4, false, false, true>); q(k_dp_tile_p<4, false, true, true>); q(k_dp_tile_p<4, true, false, true>); q(k_dp_tile_p<4, true, true, true>);
+    // the 2-px instantiations stage a whole 32-row block (193 VGPRs): their bound is lower, and a grid that is too large for
+    // them but fits the 4-px ones must not be sent to k_dp_tile for it
+    g_dpp_max_wgs_px4 = std::max(0, per_cu - 1) * prop.multiProcessorCount;
     q(k_dp_tile_p<2, false, false, false>); q(k_dp_tile_p<2, false, true, false>); q(k_dp_tile_p<2, true, false, false>); q(k_dp_tile_p<2, true, true, false>);
     q(k_dp_tile_p<2, false, false, true>); q(k_dp_tile_p<2, false, true, true>); q(k_dp_tile_p<2, true, false, true>); q(k_dp_tile_p<2, true, true, true>);
     g_dpp_max_wgs_plain = std::max(0, per_cu - 1) * prop.multiProcessorCount;
@@ -3700,7 +3704,8 @@ static int dp_persistent_px(const LqrHipBatch *b, int w, bool general = false, i
     const int hh = b->cs[0]->wk_h;                            // the block index is DPP_BLK_BITS bits of the granule tag
     const int maxblk = (1 << DPP_BLK_BITS) - 1;
     if ((general || g_dpp_px_override != 4) && hh <= maxblk * (dpp_halo(2) / delta) && (size_t) ((w + dpp_own(2) - 1) / dpp_own(2)) * n <= (size_t) limit) return 2;
-    if (!general && g_dpp_px_override != 2 && hh <= maxblk * dpp_halo(4) && (size_t) ((w + dpp_own(4) - 1) / dpp_own(4)) * n <= (size_t) limit) return 4;
+    const int limit4 = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_px4) : g_dpp_max_wgs_px4;
+    if (!general && g_dpp_px_override != 2 && hh <= maxblk * dpp_halo(4) && (size_t) ((w + dpp_own(4) - 1) / dpp_own(4)) * n <= (size_t) limit4) return 4;
     return 0;
 }
 static bool dp_persistent_ok(const LqrHipBatch *b, int w) { return dp_persistent_px(b, w) != 0; }
