@@ -52,6 +52,24 @@
  * (DESIGN.md spec delta 4), i.e. a float difference d is kept iff d <= 1e-5f (0x3727C5AC) */
 #define UPDATE_TOLERANCE (1e-5)
 
+/* How a float expression is evaluated.  Default: every operation rounded to float (FLT_EVAL_METHOD 0: any x86-64 / SSE2
+ * build of liblqr -- the platform this repository's "bit-exact" refers to).  -DLQR_ORACLE_X87=64 (or 53) restates the
+ * reference author's own i386 build (gimp-lqr-plugin.exe inside windows_installer_files/lqr-pack4win/.zip: x87 code,
+ * control word 0x37f from its CRT's fninit; 53 = the 0x27f other Windows CRTs set): the DP candidate
+ * m[parent] + r_fact * rigidity_map[dx], the comparisons among candidates and en + best stay in x87 registers and are
+ * rounded to float once, at the store into m[] (genuine lqr_carver_build_mmap 0x410ccb-0x410d66: flds/fmul/fadds ...
+ * fucom ... fadds/fstps).  Built by `make x87`; only scripts/ref_engine/ loads those builds. */
+#if defined(LQR_ORACLE_X87) && LQR_ORACLE_X87 == 64
+typedef long double acc_t;
+#define ACC_ABS(x) fabsl(x)
+#elif defined(LQR_ORACLE_X87) && LQR_ORACLE_X87 == 53
+typedef double acc_t;
+#define ACC_ABS(x) fabs(x)
+#else
+typedef float acc_t;
+#define ACC_ABS(x) fabsf(x)
+#endif
+
 struct _LqrProgress {
     gfloat update_step;
     LqrProgressFuncInit init;
@@ -691,17 +709,17 @@ static LqrRetVal update_emap(LqrCarver *r)
 /* ======================= cumulative-min DP (E5, E9) ====================== */
 /* best predecessor of carved-frame pixel (x,y): scan dx ascending, first is the
  * incumbent, replace on strict < (or on == when leftright == 1) */
-static float best_parent(const LqrCarver *r, int x, int y, int data, int *least_out)
+static acc_t best_parent(const LqrCarver *r, int x, int y, int data, int *least_out)
 {
     int x1_min = MAXI(-x, -r->delta_x), x1_max = MINI(r->w - 1 - x, r->delta_x), x1;
     int data_down = r->raw[y - 1][x + x1_min], least = data_down;
-    float m, m1;
+    acc_t m, m1;
     if (r->rigidity) {
-        float r_fact = r->rigidity_mask ? r->rigidity_mask[data] : 1;
-        m = r->m[data_down] + r_fact * r->rigidity_map[x1_min];
+        acc_t r_fact = r->rigidity_mask ? r->rigidity_mask[data] : 1;
+        m = (acc_t) r->m[data_down] + r_fact * (acc_t) r->rigidity_map[x1_min];
         for (x1 = x1_min + 1; x1 <= x1_max; x1++) {
             data_down = r->raw[y - 1][x + x1];
-            m1 = r->m[data_down] + r_fact * r->rigidity_map[x1];
+            m1 = (acc_t) r->m[data_down] + r_fact * (acc_t) r->rigidity_map[x1];
             if (m1 < m || (m1 == m && r->leftright == 1)) { m = m1; least = data_down; }
         }
     } else {
@@ -723,11 +741,11 @@ static LqrRetVal build_mmap(LqrCarver *r)
     for (x = 0; x < r->w; x++) { data = r->raw[0][x]; r->m[data] = r->en[data]; }
     for (y = 1; y < r->h; y++) {
         for (x = 0; x < r->w; x++) {
-            float m;
+            acc_t m;
             data = r->raw[y][x];
             m = best_parent(r, x, y, data, &least);
             r->least[data] = least;
-            r->m[data] = r->en[data] + m;
+            r->m[data] = (float) ((acc_t) r->en[data] + m);
         }
     }
     return LQR_OK;
@@ -771,25 +789,25 @@ static LqrRetVal update_mmap(LqrCarver *r)
         }
         stop = 0; x_stop = 0;
         for (x = x_min; x <= x_max; x++) {
-            float m, new_m;
+            acc_t m, new_m;
             data = r->raw[y][x];
             m = best_parent(r, x, y, data, &least);
-            new_m = r->en[data] + m;
+            new_m = (acc_t) r->en[data] + m;
             /* shrink the band where nothing (relevant) changed: the stale
              * value is KEPT when the change is below tolerance */
             if (r->least[data] == least) {
-                if ((double) fabsf(r->m[data] - new_m) < UPDATE_TOLERANCE) {
+                if ((double) ACC_ABS((acc_t) r->m[data] - new_m) < UPDATE_TOLERANCE) {
                     if (stop == 0) x_stop = x;
                     stop = 1;
                     new_m = r->m[data];
                 } else {
                     stop = 0;
-                    r->m[data] = new_m;
+                    r->m[data] = (float) new_m;
                 }
                 if (x == x_min && stop) x_min++;
             } else {
                 stop = 0;
-                r->m[data] = new_m;
+                r->m[data] = (float) new_m;
             }
             r->least[data] = least;
             if (x == x_max && stop) x_max = x_stop;

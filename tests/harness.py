@@ -30,7 +30,7 @@ def init_carver(api, img, new_w, new_h, pres=None, disc=None, rigmask=None, prog
     v = dict(DEFAULTS); v.update(kw)
     h, w = img.shape[:2]
     rigidity = 3 * v["rigidity"] if rigmask is not None else v["rigidity"]      # render.c:781-792
-    c = L.Carver(api, img, delta_x=v["delta_x"], rigidity=rigidity)
+    c = getattr(api, "carver_class", L.Carver)(api, img, delta_x=v["delta_x"], rigidity=rigidity)
     if pres is not None and v["pres_coeff"]:
         assert c.bias_add(pres, v["pres_coeff"]) == L.LQR_OK
     if disc is not None and v["disc_coeff"] and not compute_ignore_disc_mask(v, w, h, new_w, new_h):
