@@ -1080,17 +1080,17 @@ static LqrRetVal resize_dir(LqrCarver *r, int w1, int want_transposed)
 
     if (r->transposed == want_transposed) {
         delta = w1 - r->w_start; gamma = w1 - r->w;
-        delta_max = (int) ((r->enl_step - 1) * r->w_start) - 1;
+        delta_max = (int) (((acc_t) r->enl_step - 1) * (acc_t) r->w_start) - 1;
     } else {
         delta = w1 - r->h_start; gamma = w1 - r->h;
-        delta_max = (int) ((r->enl_step - 1) * r->h_start) - 1;
+        delta_max = (int) (((acc_t) r->enl_step - 1) * (acc_t) r->h_start) - 1;
     }
     if (delta_max < 1) delta_max = 1;
     if (delta < 0) { delta = -delta; delta_max = delta; }
 
     r->session_rescale_total = gamma > 0 ? gamma : -gamma;
     r->session_rescale_current = 0;
-    r->session_update_step = (int) MAXI(r->session_rescale_total * r->progress->update_step, 1);
+    r->session_update_step = (int) MAXI((acc_t) r->session_rescale_total * (acc_t) r->progress->update_step, 1);      /* x87: 200 * 0.02f = 3.9999999 -> 3 */
     if (r->session_rescale_total) progress_init(r->progress, init_msg);
 
     while (gamma) {
@@ -1105,7 +1105,7 @@ static LqrRetVal resize_dir(LqrCarver *r, int w1, int want_transposed)
         if (r->dump_vmaps) LQR_CATCH(vmap_internal_dump(r));
         if (new_w < w1) {
             LQR_CATCH(lqr_carver_flatten(r));
-            delta_max = (int) ((r->enl_step - 1) * r->w_start) - 1;
+            delta_max = (int) (((acc_t) r->enl_step - 1) * (acc_t) r->w_start) - 1;
             if (delta_max < 1) delta_max = 1;
         }
     }

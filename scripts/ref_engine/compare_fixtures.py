@@ -12,7 +12,7 @@ cw = int(sys.argv[1], 0) if len(sys.argv) > 1 else 0x37f
 variant = os.environ.get("ORACLE_VARIANT")          # x87_64 / x87_53: `make -C oracle x87`
 orc = L.Api(os.path.join(ROOT, "oracle", "liblqr_oracle_%s.so" % variant), "o") if variant else L.oracle_api()
 for name, (img, nw, nh, kw) in G.cases().items():
-    api = R.RefApi(cw)
+    api = R.RefApi(cw & 0xffff, float24=bool(cw & 0x10000))          # cw 0x1027f = 'sse' mode
     try:
         a = H.run_case(api, img, nw, nh, progress=True, **kw)
         hc = api.r.heap_check()

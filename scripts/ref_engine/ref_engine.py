@@ -21,7 +21,7 @@ EXE_IN_ZIP = "lib/gimp/2.0/plug-ins/gimp-lqr-plugin.exe"
 SCRATCH = os.environ.get("REF_ENGINE_SCRATCH", "/tmp/ref_engine")
 
 (OP_WRITE, OP_READ, OP_ALLOC, OP_FREE, OP_CALL, OP_INFO, OP_SETCW, OP_EVENTS, OP_HEAPCHECK, OP_SCANALL, OP_POISON,
- OP_PROGRET, OP_QUIT) = range(1, 14)
+ OP_PROGRET, OP_QUIT, OP_WRAP) = range(1, 15)
 
 LQR_ERROR, LQR_OK, LQR_NOMEM, LQR_USRCANCEL = 0, 1, 2, 3
 
@@ -112,8 +112,18 @@ class PE:
         raise ValueError(hex(rva))
 
 
+# float-only functions of the engine (no double arithmetic inside): run under a 24-bit control word in "sse" mode
+FLOAT_ONLY = ("lqr_carver_build_mmap", "lqr_carver_update_mmap", "lqr_carver_init", "lqr_carver_transpose", "lqr_carver_inflate")
+
+
 class Runner:
-    def __init__(self, cw=0x37f, poison=None):
+    """cw: the x87 control word the engine's code runs under.
+         0x37f  what the exe's own CRT leaves (fninit, 64-bit mantissa): the build as shipped
+         0x27f  53-bit mantissa: double arithmetic as an SSE2 build performs it
+       float24: additionally run the FLOAT_ONLY functions under 0x07f (24-bit mantissa), i.e. float arithmetic as an SSE2
+       build performs it ("sse" mode = cw 0x27f + float24)"""
+
+    def __init__(self, cw=0x37f, poison=None, float24=False):
         self.pe = PE(exe_bytes())
         self.proc = subprocess.Popen([build_runner()], stdin=subprocess.PIPE, stdout=subprocess.PIPE, bufsize=0)
         pe = self.pe
@@ -131,6 +141,10 @@ class Runner:
         for name, addr in stubs.items():
             self.write(pe.imports[name], struct.pack("<I", addr))
         self.set_cw(cw)
+        self.wrapped = {}
+        if float24:
+            for k, name in enumerate(FLOAT_ONLY):
+                self.wrap(k, name, 0x07f)
         if poison is not None:
             self._cmd(OP_POISON, poison)
             self._read(4)
@@ -179,13 +193,37 @@ class Runner:
         self._cmd(OP_SETCW, cw)
         self._read(4)
 
+    def wrap(self, slot, name, cw):
+        """retarget every `call rel32` to `name` inside the exe's code at a stub that runs it under control word `cw`"""
+        pe = self.pe
+        target = pe.symbols[name]
+        self._cmd(OP_WRAP, slot, target, cw)
+        stub = struct.unpack("<I", self._read(4))[0]
+        text = next(s for s in pe.sections if s[0] == ".text")
+        base = pe.image_base + text[1]
+        code = pe.data[text[3]:text[3] + text[2]]
+        lo, hi = pe.symbols["lqr_carver_set_image_type"] - base, pe.symbols["lqr_grad_xabs"] + 0x40 - base   # the engine's code
+        n = 0
+        i = code.find(b"\xe8", lo)
+        while 0 <= i < hi:
+            rel = struct.unpack_from("<i", code, i + 1)[0]
+            if base + i + 5 + rel == target:
+                self.write(base + i + 1, struct.pack("<i", stub - (base + i + 5)))
+                n += 1
+            i = code.find(b"\xe8", i + 1)
+        self.wrapped[name] = stub
+        return n
+
     def set_progress_return(self, v):
         self._cmd(OP_PROGRET, v)
         self._read(4)
 
     def call(self, name_or_addr, *args, fp=False):
         """cdecl call.  ints/pointers -> one word; ('f', x) -> float word; ('d', x) -> two words"""
-        addr = self.pe.symbols[name_or_addr] if isinstance(name_or_addr, str) else name_or_addr
+        if isinstance(name_or_addr, str):
+            addr = self.wrapped.get(name_or_addr) or self.pe.symbols[name_or_addr]
+        else:
+            addr = name_or_addr
         words = b""
         for a in args:
             if isinstance(a, tuple):
@@ -250,8 +288,8 @@ class RefApi:
     """stands where binding.Api stands in tests/harness.py (api.carver_class picks RefCarver)"""
     has_ext = False
 
-    def __init__(self, cw=0x37f, poison=None):
-        self.r = Runner(cw, poison)
+    def __init__(self, cw=0x37f, poison=None, float24=False):
+        self.r = Runner(cw, poison, float24)
         self.carver_class = RefCarver
         self.cw = cw
 

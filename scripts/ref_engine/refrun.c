@@ -223,9 +223,30 @@ __asm__(
 extern u32 tramp_i(u32 fn, const u32 *words, u32 n);
 extern double tramp_f(u32 fn, const u32 *words, u32 n);
 
+/* ---------------- control-word wrappers ----------------
+ * The exe is x87 code: a float expression is evaluated at the precision the control word selects and rounded to float
+ * only when stored.  To make the genuine code evaluate its float-ONLY functions (the DP: build_mmap / update_mmap; init's
+ * rigidity table; transpose's rescaling of it; inflate's averages) the way an SSE2 build of the same source does (every
+ * operation rounded to float), the driver retargets the call sites of such a function to one of these stubs, which
+ * runs the original under another control word (0x07f: 24-bit mantissa) and restores the caller's.  Not re-entrant per
+ * slot, which the wrapped functions do not need. */
+#define N_WRAP 8
+u32 wrap_orig[N_WRAP], wrap_ret[N_WRAP];
+unsigned short wrap_cw[N_WRAP], wrap_saved[N_WRAP];
+#define WRAP_STUB(k) \
+    __asm__(".text\n.globl wrap_stub" #k "\nwrap_stub" #k ":\n" \
+            "  popl wrap_ret+4*" #k "\n" \
+            "  fnstcw wrap_saved+2*" #k "\n" \
+            "  fldcw wrap_cw+2*" #k "\n" \
+            "  call *wrap_orig+4*" #k "\n" \
+            "  fldcw wrap_saved+2*" #k "\n" \
+            "  jmp *wrap_ret+4*" #k "\n"); \
+    extern void wrap_stub##k(void);
+WRAP_STUB(0) WRAP_STUB(1) WRAP_STUB(2) WRAP_STUB(3) WRAP_STUB(4) WRAP_STUB(5) WRAP_STUB(6) WRAP_STUB(7)
+
 /* ---------------- protocol ---------------- */
 enum { OP_WRITE = 1, OP_READ, OP_ALLOC, OP_FREE, OP_CALL, OP_INFO, OP_SETCW, OP_EVENTS, OP_HEAPCHECK, OP_SCANALL, OP_POISON,
-       OP_PROGRET, OP_QUIT };
+       OP_PROGRET, OP_QUIT, OP_WRAP };
 #define IMAGE_BASE 0x400000u
 #define IMAGE_SIZE 0x100000u
 
@@ -286,6 +307,15 @@ void _start_c(void)
         } break;
         case OP_POISON: { u32 ok = 1; poison = (int) hdr[1]; wr(&ok, 4); } break;
         case OP_PROGRET: { u32 ok = 1; prog_ret = (int) hdr[1]; wr(&ok, 4); } break;
+        case OP_WRAP: {       /* hdr[1] slot, hdr[2] original function, hdr[3] control word; reply: the stub's address */
+            static void (*const stubs[N_WRAP])(void) = { wrap_stub0, wrap_stub1, wrap_stub2, wrap_stub3, wrap_stub4, wrap_stub5,
+                                                         wrap_stub6, wrap_stub7 };
+            u32 a;
+            if (hdr[1] >= N_WRAP) die(86);
+            wrap_orig[hdr[1]] = hdr[2]; wrap_cw[hdr[1]] = (unsigned short) hdr[3];
+            a = (u32) stubs[hdr[1]];
+            wr(&a, 4);
+        } break;
         case OP_QUIT: die(0);
         default: die(85);
         }
