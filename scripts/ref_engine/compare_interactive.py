@@ -9,43 +9,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, HERE)
 import numpy as np
 import harness as H, lqr_ctypes as L, datasets as D
 import ref_engine as R
-
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-cw = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0x1027f
-orc = L.oracle_api()
-
-
-def draw(rng):
-    big = rng.random() < 0.3
-    w, h = (int(rng.integers(900, 1500)), int(rng.integers(60, 160))) if big else (int(rng.integers(24, 260)), int(rng.integers(16, 160)))
-    ch = int(rng.integers(1, 5))
-    img = [D.noise, D.photo_like, D.flat_blocks][int(rng.integers(0, 3))](w, h, int(rng.integers(0, 1 << 30)), channels=ch)
-    kw = dict(nrg_func=int(rng.integers(0, 7)), switch_freq=int(rng.choice([0, 1, 2, 3])), res_order=int(rng.integers(0, 2)),
-              enl_step=float(rng.choice([150.0, 120.0, 200.0])))
-    if rng.random() < 0.2:
-        kw.update(rigidity=float(rng.choice([1.0, 8.0])))
-    if rng.random() < 0.15:
-        kw.update(delta_x=int(rng.choice([2, 3])))
-    mk = dict(pres=D.ellipse_mask(w, h), disc=D.band_mask(w, h, w // 5, w // 3)) if rng.random() < 0.2 else {}
-    steps = []
-    cw_, ch_ = w, h
-    for _ in range(int(rng.integers(2, 7))):
-        if rng.random() < 0.2:
-            steps.append(("f",))
-            continue
-        span = 40 if not big else 25
-        nw = int(np.clip(cw_ + rng.integers(-span, span // 2 + 1), 4, int(cw_ * 1.4)))
-        nh = int(np.clip(ch_ + (rng.integers(-20, 11) if rng.random() < 0.4 else 0), 4, int(ch_ * 1.4)))
-        steps.append(("r", nw, nh)); cw_, ch_ = nw, nh
-    return img, kw, mk, steps, "%dx%d ch%d %s%s steps %s" % (w, h, ch, kw, " +masks" if mk else "", steps)
+import ref_cases as C
 
 
 if __name__ == "__main__":
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    cw = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0x1027f
+    orc = L.oracle_api()
     same = differ = calls = 0
     t0 = time.time()
     for seed in range(first, first + count):
-        img, kw, mk, steps, what = draw(np.random.default_rng(seed))
+        img, kw, mk, steps, what = C.interactive_case(np.random.default_rng(seed))
         h, w = img.shape[:2]
         api = R.RefApi(cw & 0xffff, float24=bool(cw & 0x10000))
         try:

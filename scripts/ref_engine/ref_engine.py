@@ -113,7 +113,11 @@ class PE:
 
 
 # float-only functions of the engine (no double arithmetic inside): run under a 24-bit control word in "sse" mode
-FLOAT_ONLY = ("lqr_carver_build_mmap", "lqr_carver_update_mmap", "lqr_carver_init", "lqr_carver_transpose", "lqr_carver_inflate")
+FLOAT_ONLY = ("lqr_carver_build_mmap", "lqr_carver_update_mmap", "lqr_carver_init", "lqr_carver_transpose", "lqr_carver_inflate",
+              # enl_step and progress-step arithmetic (float x int): 200 * 0.02f is 4 in float, 3.9999999 at 53 bits
+              "lqr_carver_resize_width", "lqr_carver_resize_height")
+# ... which call this one, whose callees compute energies in double: back to the 53-bit control word inside it
+DOUBLE_INSIDE = ("lqr_carver_build_maps",)
 
 
 class Runner:
@@ -145,6 +149,8 @@ class Runner:
         if float24:
             for k, name in enumerate(FLOAT_ONLY):
                 self.wrap(k, name, 0x07f)
+            for k, name in enumerate(DOUBLE_INSIDE):
+                self.wrap(len(FLOAT_ONLY) + k, name, cw)
         if poison is not None:
             self._cmd(OP_POISON, poison)
             self._read(4)
