@@ -6,28 +6,38 @@
  * cpu_baseline leg may load it.  The product (liblqr-hip.so) never links,
  * loads or calls anything in oracle/.
  *
- * *** PARITY UNPINNED ***  The arithmetic restated here lives in the third
- * party library liblqr-1 (pkg-config module lqr-1 >= 0.4.0, reference
- * configure.ac:67-70; 0.4.1 is what windows_installer_files/lqr-pack4win/
- * winpack.sh:8 bundles).  Its source is NOT in the reference tree, is not
- * installed in the build container and cannot be fetched (no network); the
- * reference has no tests, golden vectors or fixtures for this path
- * (SURVEY.md section 4, 8(c)).  This file restates liblqr 0.4.x's published
- * algorithm from its documented behaviour and is anchored on the reference's
- * call sites only:
+ * *** PARITY PINNED against the reference author's own build (round 4) ***  The arithmetic restated
+ * here lives in the third-party library liblqr-1 (pkg-config module lqr-1 >= 0.4.0, reference
+ * configure.ac:67-70).  Its SOURCE is not in the reference tree -- but its compiled form is:
+ * windows_installer_files/lqr-pack4win/.zip holds gimp-lqr-plugin.exe, a PE32/i386 build of the
+ * plug-in statically linked with liblqr 0.4.1 (winpack.sh:8,52-57), symbols and stabs intact.
+ * scripts/ref_engine/ executes that machine code in a seccomp-strict i386 child (build container
+ * only) and oracle/REF_CHECK.md records the comparison, function by function and by address:
+ *   - this restatement == the genuine engine, evaluated as an SSE2 build evaluates ("sse" mode), on
+ *     16/17 fixtures, 2 385/2 400 seeded cases, 299/300 interactive sessions, 233/233 plane checks
+ *     (energies 0 ULP, m and back pointers after 40 incremental updates), BASELINE configs 1-3 at
+ *     full size, all 64 images of config 4; every remaining case is an input on which the genuine
+ *     engine itself produces an invalid seam map or writes past a heap block (spec delta 6);
+ *   - the vectors the genuine engine produced are committed as DATA (tests/golden/ref/) and
+ *     tests/test_ref_golden.py checks this file (CPU) and the HIP engine (-m gpu) against them;
+ *   - the prototypes and enums of include/lqr.h are diffed against the exe's debug information
+ *     (tests/test_ref_abi.py).
+ * PLATFORM: "bit-exact vs liblqr" means vs liblqr built for x86-64 (SSE2: every float operation rounded to
+ * float, FLT_EVAL_METHOD 0).  The exe itself is x87 code under control word 0x37f (FLT_EVAL_METHOD 2):
+ * with rigidity != 0 its DP keeps excess precision and its results differ from ANY SSE2 build's;
+ * -DLQR_ORACLE_X87 (acc_t below, `make x87`) restates that evaluation for the comparison.
+ * Anchors in the plug-in (the call sites of the path):
  *   src/render.c:220-248 (construction/configuration order), :318,:328,:529
  *   (resize), :325,:636 (flatten), :725 (vmap dump), :547-551 (getters);
  *   src/io_functions.c:94-95,125-126 (mask areas), :155-164 (scan_line /
  *   scan_by_row), :216-219 (vmap accessors), :312 (vmap list foreach).
- * and on the prose semantics in help/en/index.wiki:48,83,85,130-133.
- * "bit-exact vs liblqr" in this repository therefore means "bit-exact vs this
- * restatement".  The exported ABI is identical to liblqr-1's, so a genuine
- * liblqr-1.so.0 can be loaded by tests/lqr_ctypes.py as a second oracle
- * wherever one exists.
+ * The exported ABI is identical to liblqr-1's, so a genuine liblqr-1.so.0 can also be loaded by
+ * tests/lqr_ctypes.py as a further oracle wherever one exists (tests/test_real_liblqr.py).
  *
- * Where this restatement deliberately departs from SURVEY.md Appendix A (itself
- * flagged "unverified recollection"), DESIGN.md section "Spec deltas" lists the
- * delta and why:  (1) side-switch "frequency" = number of switches per
+ * Where this restatement departs from SURVEY.md Appendix A (itself flagged
+ * "unverified recollection"), DESIGN.md section "Spec deltas" lists the delta; deltas 1-5
+ * are CONFIRMED by the genuine code (REF_CHECK.md section 4), delta 6 is a deliberate
+ * departure from a defect of the genuine code (REF_CHECK.md section 5):  (1) side-switch "frequency" = number of switches per
  * rescale operation (interval schedule), not "every 2nd seam";  (2) every
  * build of the visibility map ends with the inflate step that makes the
  * multi-size image symmetric (shrink AND enlarge), which is what makes

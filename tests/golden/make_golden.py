@@ -1,6 +1,7 @@
 """Generates tests/golden/*.npz: small inputs + the outputs the CPU oracle produces
-for them through the C ABI.  PARITY UNPINNED: the reference holds no golden vectors
-for this path; these fixtures freeze the oracle's behaviour so
+for them through the C ABI.  These are the ORACLE's outputs (regression protection); the same 17
+cases run through the genuine liblqr are tests/golden/ref/fixtures_*.npz (scripts/ref_engine/) -- identical
+on 16, the 17th is spec delta 6.  These fixtures freeze the oracle's behaviour so
 that (a) an oracle regression is caught on CPU and (b) the GPU engine is checked
 against committed data as well as against the live oracle.
 
