@@ -97,6 +97,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phases", action="store_true", help="skip the upload / read-out phase measurement")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the extra legs after the headline: BASELINE configs 2, 3 and 5 (fhd, single4k, config5), 3 steps each")
+    ap.add_argument("--no-kernel-breakdown", action="store_true", help="skip the extra untimed step that HIP-event times every kernel")
     ap.add_argument("--switch-freq", type=int, default=2, help="lqr side switch frequency (plug-in: 2, render.c:237)")
     return ap.parse_args()
 
@@ -177,6 +180,36 @@ def config5_masks(w, h, rigmask):
     return pres, disc, rig
 
 
+# the engine's profiling names -> the kernels behind them (large batch, small batch / single image): for the PMC look-up
+KERNEL_NAMES = {
+    "carve": (["k_carve"], ["k_carve"]),
+    "vpath": (["k_vpath1", "k_vpath"], ["k_vpath1", "k_vpath"]),
+    "band_update": (["k_band_update_tw", "k_band_update_mw", "k_band_update"], ["k_band_update_tw", "k_band_update"]),
+    "dp_update": (["k_dp_sweep"], ["k_dp_sweep"]),
+    "dp_update_tiled": (["k_dp_tile_p"], ["k_dp_tile_p"]),
+    "dp_sweep": (["k_dp_tile", "k_dp_sweep"], ["k_dp_tile_p", "k_dp_tile", "k_dp_sweep"]),
+    "emap_update": (["k_emap_update"], ["k_emap_update"]),
+}
+_PMC = None
+
+
+def pmc_traffic(workload, kernels, nimg, streams):
+    """HBM bytes per launch of the first of `kernels` found in profiles/pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE and
+    WRITE_SIZE in separate passes over this command, (2 * FETCH + WRITE) * 1024 per MI355X_MICROARCH.md), scaled from the
+    profiled images per launch to this run's; None when there is no committed profile for this workload"""
+    global _PMC
+    if _PMC is None:
+        path = os.path.join(ROOT, "profiles", "pmc_kernels.json")
+        _PMC = json.load(open(path)) if os.path.exists(path) else {}
+    wl = _PMC.get(workload)
+    if not wl:
+        return None
+    for k in kernels:
+        if k in wl["kernels"]:
+            return round(wl["kernels"][k]["traffic_bytes_per_launch"] / wl["images_per_launch"] * nimg / max(streams, 1))
+    return None
+
+
 def spawn_command(gpus, argv):
     """the launcher line the driver uses for N > 1: one rank per GPU of one node, rendezvous on 127.0.0.1"""
     s = socket.socket()
@@ -255,269 +288,325 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    W, H, NW, NH = WORKLOADS[args.workload]
-    batch = args.workload == "batch4k"
-    nimg = args.images_per_gpu if batch else 1
-    if batch and args.strong:
-        nimg = strong_images_per_gpu(world)
-    if args.seams is not None:
-        NW = W - args.seams
-    rigidity = args.rigidity if args.rigidity is not None else (10.0 if args.workload == "config5" else 0.0)
-    pres = disc = rigm = None
-    if args.workload == "config5":
-        pres, disc, rigm = config5_masks(W, H, args.rigmask)
-        if rigm is not None:
-            rigidity *= 3           # render.c:784-787
-
-    def sync():
-        rc = lib.lqrhip_device_sync()
-        assert rc == 0, "device error: %s" % lib.lqrhip_last_error().decode()
-        torch.cuda.synchronize()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    def mem_used_gb():
-        f, t, c = C.c_ulonglong(0), C.c_ulonglong(0), C.c_ulonglong(0)
-        lib.lqrhip_mem_info(C.byref(f), C.byref(t), C.byref(c))
-        return (t.value - f.value) / 1e9, t.value / 1e9
-
-    def max_over_ranks(x):
-        if dist is None:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    # ---- phase "read" (render.c:214-217, 220-224): inputs generated on the GPU and kept in HBM for the timed steps; the
-    # carvers are created from HOST copies of them, as the plug-in creates its carver from a host buffer -- that is the
-    # measured upload phase (lqr_carver_new uploads, lqr_carver_init allocates the working planes)
-    t_setup = time.perf_counter()
-    images = make_images(nimg, W, H, 100 + rank * nimg, dev)
-    torch.cuda.synchronize()
-    host_imgs = [images[i].cpu().numpy() for i in range(nimg)]
-    ptrs = [images[i].data_ptr() for i in range(nimg)]
-    bufs = [L._malloc_copy(im) for im in host_imgs]      # liblqr takes ownership of a malloc'ed buffer (render.c:222)
-    sync()
-    tu = time.perf_counter()
-    carvers = [L.Carver.from_buffer(eng, bufs[i], W, H, 4, delta_x=args.delta, rigidity=rigidity) for i in range(nimg)]
-    sync()
-    upload_ms = (time.perf_counter() - tu) * 1e3
-    for c in carvers:
-        c.configure(switch_freq=args.switch_freq, enl_step=1.5)                          # plug-in defaults, main.c:62-87
-    img0_host = host_imgs[0]
-    host_keep = host_imgs[:min(nimg, os.cpu_count() or 1)]      # for the all-cores CPU baseline
-    del host_imgs
-    sync()
-    t_setup = time.perf_counter() - t_setup
-
-    def add_masks(cs):
-        # render.c:225-233 (pres_coeff / disc_coeff defaults 1000, main.c:62-87)
-        for c in cs:
-            if pres is not None:
-                assert c.bias_add(pres, 1000) == L.LQR_OK
-            if disc is not None:
-                assert c.bias_add(disc, -1000) == L.LQR_OK
+    def measure(wl, steps, warmup, headline):
+        """one workload: set-up, `warmup` untimed + exactly `steps` timed steps, per-kernel breakdown, phases, CPU baseline;
+        `headline`: also the gather / strong / all-cores legs.  Returns the JSON object of the workload."""
+        W, H, NW, NH = WORKLOADS[wl]
+        batch = wl == "batch4k"
+        nimg = args.images_per_gpu if batch else 1
+        if batch and args.strong:
+            nimg = strong_images_per_gpu(world)
+        if args.seams is not None:
+            NW = W - args.seams
+        rigidity = args.rigidity if args.rigidity is not None else (10.0 if wl == "config5" else 0.0)
+        pres = disc = rigm = None
+        if wl == "config5":
+            pres, disc, rigm = config5_masks(W, H, args.rigmask)
             if rigm is not None:
-                assert c.rigmask_add(rigm) == L.LQR_OK
+                rigidity *= 3           # render.c:784-787
 
-    def run_step(cs, ps):
-        ret = L.reload_device_batch(eng, cs, ps)
-        assert ret == L.LQR_OK, "reload failed: %d (%s)" % (ret, lib.lqrhip_last_error().decode())
-        add_masks(cs)
-        if len(cs) == 1:
-            ret = cs[0].resize(NW, NH)
-        else:
-            ret = L.resize_batch(eng, cs, NW, NH)
-        assert ret == L.LQR_OK, "resize failed: %d (%s)" % (ret, lib.lqrhip_last_error().decode())
+        def sync():
+            rc = lib.lqrhip_device_sync()
+            assert rc == 0, "device error: %s" % lib.lqrhip_last_error().decode()
+            torch.cuda.synchronize()
 
-    def timed(cs, ps, steps, warmup, prof_mode):
-        for _ in range(warmup):
-            run_step(cs, ps)
-        lib.lqrhip_prof_reset()
-        lib.lqrhip_prof_enable(prof_mode)
-        barrier(); sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            run_step(cs, ps)
-        sync(); barrier()
-        t1 = time.perf_counter()
-        lib.lqrhip_prof_enable(0)
-        return max_over_ranks(t1 - t0)
+        def barrier():
+            if dist is not None:
+                dist.barrier()
 
-    # ---- phase "resize" (render.c:314-316): W warm-up steps, then exactly K timed steps
-    elapsed = timed(carvers, ptrs, args.steps, args.warmup, 1 if args.kernel_times else 2)
-    used_gb, total_gb = mem_used_gb()
-    streams = lib.lqrhip_sub_batches(nimg) if nimg > 1 else 1
+        def mem_used_gb():
+            f, t, c = C.c_ulonglong(0), C.c_ulonglong(0), C.c_ulonglong(0)
+            lib.lqrhip_mem_info(C.byref(f), C.byref(t), C.byref(c))
+            return (t.value - f.value) / 1e9, t.value / 1e9
 
-    # ---- per-kernel HIP-event times collected inside the timed region
-    def prof(name):
-        ms, n, by = C.c_double(0), C.c_longlong(0), C.c_double(0)
-        lib.lqrhip_prof_get(name.encode(), C.byref(ms), C.byref(n), C.byref(by))
-        return ms.value, n.value, by.value
-    kern = {k: prof(k) for k in ("carve", "vpath", "band_update", "dp_update", "dp_update_tiled", "dp_sweep", "emap_update")}
-    c_ms, c_n, c_bytes = kern["carve"]
-    work_rank = work_seam_px(W, H, NW, NH) * nimg * args.steps       # seam*px per rank
-    value = work_rank * world / elapsed / 1e6
-    roofline = None
-    if c_n:
-        un = C.c_double(0)
-        lib.lqrhip_prof_get_union.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
-        lib.lqrhip_prof_get_union(b"carve", C.byref(un))
-        active_ms = un.value if un.value > 0 else c_ms
-        achieved = c_bytes / (active_ms * 1e-3) / 1e9
-        # HBM traffic of k_carve per launch from the committed rocprofv3 PMC passes of this command
-        # (separate FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
-        # note), scaled from the profiled images per launch to this run's; null if the profile is missing
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_k_carve.json")
-        if os.path.exists(pmc) and batch and args.seams is None:
-            pj = json.load(open(pmc))
-            traffic = round((2 * pj["fetch_size_kb_mean"] + pj["write_size_kb_mean"]) * 1024 / pj["images_per_launch"] * nimg / streams)
-        b_alg = alg_bytes_per_seam_px(W, H, NW, NH, args.switch_freq)
-        roofline = {"bound": "hbm", "kernel": "k_carve", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                    "carve_active_ms": round(active_ms, 3), "sum_of_launches_ms": round(c_ms, 3),
-                    "avg_launch_us": round(c_ms * 1e3 / c_n, 2), "launches": c_n, "streams": streams,
-                    "alg_bytes_per_launch": round(c_bytes / c_n),
-                    "end_to_end": {"bytes_per_seam_px": round(b_alg, 4), "achieved": round(value * b_alg * 1e-3 / max(world, 1), 1),
-                                   "unit": "GB/s per GPU", "frac": round(value * b_alg * 1e-3 / max(world, 1) / 8000.0, 4)}}
-        if rank == 0:
-            # this device's own ceiling: 16-B streaming copy of 2 GiB (read + write), outside the timed region
-            g = C.c_double(0)
-            lib.lqrhip_copy_bandwidth.argtypes = [C.c_ulonglong, C.c_int, C.POINTER(C.c_double)]
-            if lib.lqrhip_copy_bandwidth(2 << 30, 10, C.byref(g)) == 0 and g.value > 0:
-                roofline["measured_copy_peak"] = round(g.value, 1)
-                roofline["frac_of_measured"] = round(achieved / g.value, 4)
+        def max_over_ranks(x):
+            if dist is None:
+                return x
+            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
 
-    # ---- phase "write" (render.c:358-362, io_functions.c:134-182): every result of the last step back to host memory
-    # (device compaction of the visible pixels + D2H; the scan-line loop of io_functions.c:155-164 is served from that
-    # host copy), then -- N > 1 -- the gather to rank 0 over RCCL
-    readout_ms = None
-    if not args.no_phases:
+        # ---- phase "read" (render.c:214-217, 220-224): inputs generated on the GPU and kept in HBM for the timed steps; the
+        # carvers are created from HOST copies of them, as the plug-in creates its carver from a host buffer -- that is the
+        # measured upload phase (lqr_carver_new uploads, lqr_carver_init allocates the working planes)
+        t_setup = time.perf_counter()
+        images = make_images(nimg, W, H, 100 + rank * nimg, dev)
+        torch.cuda.synchronize()
+        host_imgs = [images[i].cpu().numpy() for i in range(nimg)]
+        ptrs = [images[i].data_ptr() for i in range(nimg)]
+        bufs = [L._malloc_copy(im) for im in host_imgs]      # liblqr takes ownership of a malloc'ed buffer (render.c:222)
         sync()
-        tr = time.perf_counter()
-        host_out = [c.read_image() for c in carvers]
-        readout_ms = max_over_ranks((time.perf_counter() - tr) * 1e3)
-        assert host_out[0].shape == (NH, NW, 4)
-        del host_out
-        upload_ms = max_over_ranks(upload_ms)
-    gather_ms = None
-    outs = torch.empty((nimg, NH, NW, 4), dtype=torch.uint8, device=dev)
-    if carvers[0].getters()["orientation"] == 0:
-        for i, c in enumerate(carvers):
-            assert eng.lqrx_carver_read_image_device(c.p, outs[i].data_ptr()) == L.LQR_OK
-    else:       # transposed carver frame: go through the host image-orientation read-out
-        for i, c in enumerate(carvers):
-            outs[i].copy_(torch.from_numpy(c.read_image()))
-    if dist is not None and not args.no_gather:
-        sync(); barrier()
-        tg = time.perf_counter()
-        gathered = [torch.empty_like(outs) for _ in range(world)] if rank == 0 else None
-        dist.gather(outs, gathered, dst=0)
+        tu = time.perf_counter()
+        carvers = [L.Carver.from_buffer(eng, bufs[i], W, H, 4, delta_x=args.delta, rigidity=rigidity) for i in range(nimg)]
         sync()
-        gather_ms = (time.perf_counter() - tg) * 1e3
-        del gathered
-    checksum = int(outs.to(torch.int64).sum().item())
-    g = carvers[0].getters()
-    assert (g["width"], g["height"]) == (NW, NH), g
+        upload_ms = (time.perf_counter() - tu) * 1e3
+        for c in carvers:
+            c.configure(switch_freq=args.switch_freq, enl_step=1.5)                          # plug-in defaults, main.c:62-87
+        img0_host = host_imgs[0]
+        host_keep = host_imgs      # for the all-cores CPU baseline and the warm upload leg
+        sync()
+        t_setup = time.perf_counter() - t_setup
 
-    ms_per_step = elapsed * 1e3 / args.steps
-    mode = "strong" if (batch and args.strong) else "weak"
-    variant = ""
-    if args.workload == "config5":
-        variant = ", preservation ellipse +1000, discard band -1000, rigidity %g, delta_x %d%s" % (
-            rigidity, args.delta, ", rigidity mask (top half)" if rigm is not None else "")
-    elif args.delta != 1 or rigidity:
-        variant = ", rigidity %g, delta_x %d" % (rigidity, args.delta)
-    result = {
-        "metric": "Mseams*pixels/sec on 4K RGBA", "value": round(value, 1), "unit": "Mseams*px/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": mode,
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d x %dx%d RGBA per GPU, resize to %dx%d (%d vertical%s seams each), side-switch %d%s" % (
-                       args.workload, nimg, W, H, NW, NH, W - NW, (" + %d horizontal" % (H - NH)) if NH != H else "",
-                       args.switch_freq, variant),
-                   "images_per_gpu": nimg, "width": W, "height": H, "new_width": NW, "new_height": NH,
-                   "parallelism": "images sharded i mod N, no data-path collective", "streams_per_gpu": streams},
-        "roofline": roofline,
-        "kernels_ms": {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in kern.items() if v[1]},
-        "gather_ms": None if gather_ms is None else round(gather_ms, 2),
-        "setup_s": round(t_setup, 2),
-        "hbm_used_gb": round(used_gb, 1), "hbm_total_gb": round(total_gb, 1),
-        "output_checksum": checksum,
-    }
-    if readout_ms is not None:
-        e2e_ms = upload_ms + ms_per_step + readout_ms
-        result["phases"] = {
-            "upload_ms": round(upload_ms, 2), "resize_ms": round(ms_per_step, 3), "readout_ms": round(readout_ms, 2),
-            "value_end_to_end": round(work_rank / args.steps * world / (e2e_ms * 1e-3) / 1e6, 1),
-            "note": "upload = lqr_carver_new + lqr_carver_init of every image from pageable host memory (render.c:222-224), "
-                    "readout = every result into host memory (io_functions.c:134-182); value_end_to_end = the metric over "
-                    "upload + resize + readout; `value` itself is the HBM-resident rate"}
+        def add_masks(cs):
+            # render.c:225-233 (pres_coeff / disc_coeff defaults 1000, main.c:62-87)
+            for c in cs:
+                if pres is not None:
+                    assert c.bias_add(pres, 1000) == L.LQR_OK
+                if disc is not None:
+                    assert c.bias_add(disc, -1000) == L.LQR_OK
+                if rigm is not None:
+                    assert c.rigmask_add(rigm) == L.LQR_OK
 
-    # ---- config 4 as stated, on the same line when N > 1: 64 images in total = 64 // N per GPU (strong scaling)
-    if batch and world > 1 and not args.strong:
-        ns = strong_images_per_gpu(world)
-        el = timed(carvers[:ns], ptrs[:ns], args.steps, 1, 0)
-        result["strong"] = {"images_total": ns * world, "images_per_gpu": ns, "scaling": "strong",
-                            "ms_per_step": round(el * 1e3 / args.steps, 3),
-                            "value": round(work_seam_px(W, H, NW, NH) * ns * args.steps * world / el / 1e6, 1),
-                            "streams_per_gpu": lib.lqrhip_sub_batches(ns) if ns > 1 else 1}
+        def run_step(cs, ps):
+            ret = L.reload_device_batch(eng, cs, ps)
+            assert ret == L.LQR_OK, "reload failed: %d (%s)" % (ret, lib.lqrhip_last_error().decode())
+            add_masks(cs)
+            if len(cs) == 1:
+                ret = cs[0].resize(NW, NH)
+            else:
+                ret = L.resize_batch(eng, cs, NW, NH)
+            assert ret == L.LQR_OK, "resize failed: %d (%s)" % (ret, lib.lqrhip_last_error().decode())
 
-    # ---- CPU baseline: the oracle (a port of the algorithm; test infrastructure, loaded here only as the
-    # reported baseline and the spot checker) on this host's cores
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from concurrent.futures import ThreadPoolExecutor
-        orc = L.Api(os.path.join(ROOT, "oracle", "liblqr_oracle.so"), "o")
-        ncores = os.cpu_count() or 1
-        cw, chh, cnw, cnh = W, H, NW, NH
-        sample = "1 image of the workload (%dx%d -> %dx%d), 1 core" % (cw, chh, cnw, cnh)
-        if args.workload in ("single4k", "8k", "config5"):     # bound the sample: 100 (+100) seams instead of 500+500 / 1000
-            cnw, cnh = W - 100, (H - 100 if NH != H else H)
-            sample = "1 image %dx%d -> %dx%d (first %d seams of the workload), 1 core" % (cw, chh, cnw, cnh, (W - cnw) + (H - cnh))
+        def timed(cs, ps, steps, warmup, prof_mode):
+            for _ in range(warmup):
+                run_step(cs, ps)
+            lib.lqrhip_prof_reset()
+            lib.lqrhip_prof_enable(prof_mode)
+            barrier(); sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run_step(cs, ps)
+            sync(); barrier()
+            t1 = time.perf_counter()
+            lib.lqrhip_prof_enable(0)
+            return max_over_ranks(t1 - t0)
 
-        def oracle_carver(im):
-            o = L.Carver(orc, im, delta_x=args.delta, rigidity=rigidity).configure(switch_freq=args.switch_freq, enl_step=1.5)
-            add_masks([o])
-            return o
-        oc = oracle_carver(img0_host)
-        tc = time.perf_counter()
-        assert oc.resize(cnw, cnh) == L.LQR_OK
-        tc = time.perf_counter() - tc
-        cpu_val = work_seam_px(cw, chh, cnw, cnh) / tc / 1e6
-        result["cpu_baseline"] = {"value": round(cpu_val, 1), "unit": "Mseams*px/s", "cores": 1, "kind": "port",
-                                  "sample": sample, "seconds": round(tc, 2), "nproc": ncores, "cpu": cpu_model()}
-        # parity spot check of the timed workload's first image against the oracle
-        if (cnw, cnh) == (NW, NH):
-            ref = oc.read_image()
-            got = carvers[0].read_image()
-            result["parity_vs_oracle"] = bool(np.array_equal(ref, got))
-        oc.destroy()
-        if nimg > 1:
-            # for the batch, one image per core over all host cores (liblqr itself is single-threaded;
-            # ctypes releases the GIL inside the C call, so threads run the oracle truly in parallel)
-            nt = min(ncores, nimg, len(host_keep))
+        # ---- phase "resize" (render.c:314-316): W warm-up steps, then exactly K timed steps
+        elapsed = timed(carvers, ptrs, steps, warmup, 1 if args.kernel_times else 2)
+        used_gb, total_gb = mem_used_gb()
+        streams = lib.lqrhip_sub_batches(nimg) if nimg > 1 else 1
 
-            def one(im):
-                o = oracle_carver(im)
-                r = o.resize(NW, NH)
-                o.destroy()
-                return r
-            ta = time.perf_counter()
-            with ThreadPoolExecutor(max_workers=nt) as ex:
-                rets = list(ex.map(one, host_keep[:nt]))
-            ta = time.perf_counter() - ta
-            assert all(r == L.LQR_OK for r in rets)
-            result["cpu_baseline"]["all_cores"] = {
-                "value": round(work_seam_px(W, H, NW, NH) * nt / ta / 1e6, 1), "unit": "Mseams*px/s", "cores": nt,
-                "sample": "%d images of the workload, one per core, concurrently" % nt, "seconds": round(ta, 2)}
+        # ---- per-kernel HIP-event times collected inside the timed region
+        def prof(name):
+            ms, n, by = C.c_double(0), C.c_longlong(0), C.c_double(0)
+            lib.lqrhip_prof_get(name.encode(), C.byref(ms), C.byref(n), C.byref(by))
+            return ms.value, n.value, by.value
+        kern = {k: prof(k) for k in KERNEL_NAMES}
+        c_ms, c_n, c_bytes = kern["carve"]
+        work_rank = work_seam_px(W, H, NW, NH) * nimg * steps       # seam*px per rank
+        value = work_rank * world / elapsed / 1e6
+        roofline = None
+        if c_n:
+            un = C.c_double(0)
+            lib.lqrhip_prof_get_union.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
+            lib.lqrhip_prof_get_union(b"carve", C.byref(un))
+            active_ms = un.value if un.value > 0 else c_ms
+            avg_us = c_ms * 1e3 / c_n
+            alg_launch = c_bytes / c_n
+            achieved = alg_launch / (avg_us * 1e-6) / 1e9                    # algorithmic bytes per launch / average launch duration
+            while_active = c_bytes / (active_ms * 1e-3) / 1e9                # ... / the time during which at least one carve was running
+            # HBM traffic per launch from the committed rocprofv3 PMC passes of this command (separate FETCH_SIZE / WRITE_SIZE
+            # runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note; scripts/profile_r04.sh), null if missing
+            traffic = pmc_traffic(wl, ["k_carve"], nimg, streams)
+            b_alg = alg_bytes_per_seam_px(W, H, NW, NH, args.switch_freq)
+            roofline = {"bound": "hbm", "kernel": "k_carve", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                        "avg_launch_us": round(avg_us, 2), "launches": c_n, "streams": streams,
+                        "alg_bytes_per_launch": round(alg_launch),
+                        "achieved_while_active": round(while_active, 1), "frac_while_active": round(while_active / 8000.0, 4),
+                        "carve_active_ms": round(active_ms, 3), "sum_of_launches_ms": round(c_ms, 3),
+                        "note": "frac = alg_bytes_per_launch / avg_launch_us / peak for k_carve, the HBM-bound kernel; launches of the "
+                                "sub-batch streams overlap, frac_while_active divides by the union of their intervals instead; "
+                                "`kernels` lists every kernel of the step, `end_to_end` is the whole step against the roof",
+                        "end_to_end": {"bytes_per_seam_px": round(b_alg, 4), "achieved": round(value * b_alg * 1e-3 / max(world, 1), 1),
+                                       "unit": "GB/s per GPU", "frac": round(value * b_alg * 1e-3 / max(world, 1) / 8000.0, 4)}}
+            if rank == 0 and headline:
+                # this device's own ceiling: 16-B streaming copy of 2 GiB (read + write), outside the timed region
+                g = C.c_double(0)
+                lib.lqrhip_copy_bandwidth.argtypes = [C.c_ulonglong, C.c_int, C.POINTER(C.c_double)]
+                if lib.lqrhip_copy_bandwidth(2 << 30, 10, C.byref(g)) == 0 and g.value > 0:
+                    roofline["measured_copy_peak"] = round(g.value, 1)
+                    roofline["frac_of_measured"] = round(achieved / g.value, 4)
 
+        # ---- where the step's time goes: ONE extra, untimed step with every kernel of the seam loop HIP-event timed (the
+        # events cost queue time, which is why the timed region times k_carve only)
+        if not args.no_kernel_breakdown and not args.kernel_times:
+            timed(carvers, ptrs, 1, 0, 1)
+            kern = {k: prof(k) for k in KERNEL_NAMES}
+        tot_ms = sum(v[0] for v in kern.values()) or 1.0
+        if roofline is not None:
+            roofline["kernels"] = []
+            for k, (ms, n, by) in sorted(kern.items(), key=lambda kv: -kv[1][0]):
+                if not n:
+                    continue
+                cand = KERNEL_NAMES[k][0 if nimg > 8 else 1]
+                pmc = pmc_traffic(wl, cand, nimg, streams)
+                alg = by / n if by else None
+                basis = alg if alg else pmc
+                roofline["kernels"].append({
+                    "name": k, "kernel": cand[0], "launches": n, "avg_us": round(ms * 1e3 / n, 2), "share_of_kernel_time": round(ms / tot_ms, 4),
+                    "alg_bytes": None if alg is None else round(alg), "pmc_bytes": pmc,
+                    "frac": None if not basis else round(basis / (ms * 1e-3 / n) / 8e12, 4),
+                    "frac_basis": None if not basis else ("alg_bytes" if alg else "pmc_bytes")})
+
+        # ---- phase "write" (render.c:358-362, io_functions.c:134-182): every result of the last step back to host memory
+        # (device compaction of the visible pixels + D2H; the scan-line loop of io_functions.c:155-164 is served from that
+        # host copy), then -- N > 1 -- the gather to rank 0 over RCCL
+        readout_ms = None
+        if not args.no_phases:
+            sync()
+            tr = time.perf_counter()
+            host_out = [c.read_image() for c in carvers]
+            readout_ms = max_over_ranks((time.perf_counter() - tr) * 1e3)
+            assert host_out[0].shape == (NH, NW, 4)
+            del host_out
+            upload_ms = max_over_ranks(upload_ms)
+        gather_ms = None
+        outs = torch.empty((nimg, NH, NW, 4), dtype=torch.uint8, device=dev)
+        if carvers[0].getters()["orientation"] == 0:
+            for i, c in enumerate(carvers):
+                assert eng.lqrx_carver_read_image_device(c.p, outs[i].data_ptr()) == L.LQR_OK
+        else:       # transposed carver frame: go through the host image-orientation read-out
+            for i, c in enumerate(carvers):
+                outs[i].copy_(torch.from_numpy(c.read_image()))
+        if dist is not None and not args.no_gather:
+            sync(); barrier()
+            tg = time.perf_counter()
+            gathered = [torch.empty_like(outs) for _ in range(world)] if rank == 0 else None
+            dist.gather(outs, gathered, dst=0)
+            sync()
+            gather_ms = (time.perf_counter() - tg) * 1e3
+            del gathered
+        checksum = int(outs.to(torch.int64).sum().item())
+        g = carvers[0].getters()
+        assert (g["width"], g["height"]) == (NW, NH), g
+
+        ms_per_step = elapsed * 1e3 / steps
+        mode = "strong" if (batch and args.strong) else "weak"
+        variant = ""
+        if wl == "config5":
+            variant = ", preservation ellipse +1000, discard band -1000, rigidity %g, delta_x %d%s" % (
+                rigidity, args.delta, ", rigidity mask (top half)" if rigm is not None else "")
+        elif args.delta != 1 or rigidity:
+            variant = ", rigidity %g, delta_x %d" % (rigidity, args.delta)
+        result = {
+            "metric": "Mseams*pixels/sec on 4K RGBA", "value": round(value, 1), "unit": "Mseams*px/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": mode,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d x %dx%d RGBA per GPU, resize to %dx%d (%d vertical%s seams each), side-switch %d%s" % (
+                           wl, nimg, W, H, NW, NH, W - NW, (" + %d horizontal" % (H - NH)) if NH != H else "",
+                           args.switch_freq, variant),
+                       "images_per_gpu": nimg, "width": W, "height": H, "new_width": NW, "new_height": NH,
+                       "parallelism": "images sharded i mod N, no data-path collective", "streams_per_gpu": streams},
+            "roofline": roofline,
+            "kernels_ms": {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in kern.items() if v[1]},
+            "gather_ms": None if gather_ms is None else round(gather_ms, 2),
+            "setup_s": round(t_setup, 2),
+            "hbm_used_gb": round(used_gb, 1), "hbm_total_gb": round(total_gb, 1),
+            "output_checksum": checksum,
+        }
+        if readout_ms is not None:
+            e2e_ms = upload_ms + ms_per_step + readout_ms
+            result["phases"] = {
+                "upload_ms": round(upload_ms, 2), "resize_ms": round(ms_per_step, 3), "readout_ms": round(readout_ms, 2),
+                "value_end_to_end": round(work_rank / steps * world / (e2e_ms * 1e-3) / 1e6, 1),
+                "note": "upload = lqr_carver_new + lqr_carver_init of every image from pageable host memory (render.c:222-224), "
+                        "readout = every result into host memory (io_functions.c:134-182); value_end_to_end = the metric over "
+                        "upload + resize + readout; `value` itself is the HBM-resident rate"}
+
+        # ---- config 4 as stated, on the same line when N > 1: 64 images in total = 64 // N per GPU (strong scaling)
+        if headline and batch and world > 1 and not args.strong:
+            ns = strong_images_per_gpu(world)
+            el = timed(carvers[:ns], ptrs[:ns], steps, 1, 0)
+            result["strong"] = {"images_total": ns * world, "images_per_gpu": ns, "scaling": "strong",
+                                "ms_per_step": round(el * 1e3 / steps, 3),
+                                "value": round(work_seam_px(W, H, NW, NH) * ns * steps * world / el / 1e6, 1),
+                                "streams_per_gpu": lib.lqrhip_sub_batches(ns) if ns > 1 else 1}
+
+        # ---- CPU baseline: the oracle (a port of the algorithm; test infrastructure, loaded here only as the
+        # reported baseline and the spot checker) on this host's cores
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from concurrent.futures import ThreadPoolExecutor
+            orc = L.Api(os.path.join(ROOT, "oracle", "liblqr_oracle.so"), "o")
+            ncores = os.cpu_count() or 1
+            cw, chh, cnw, cnh = W, H, NW, NH
+            sample = "1 image of the workload (%dx%d -> %dx%d), 1 core" % (cw, chh, cnw, cnh)
+            if wl in ("single4k", "8k", "config5"):     # bound the sample: 100 (+100) seams instead of 500+500 / 1000
+                cnw, cnh = W - 100, (H - 100 if NH != H else H)
+                sample = "1 image %dx%d -> %dx%d (first %d seams of the workload), 1 core" % (cw, chh, cnw, cnh, (W - cnw) + (H - cnh))
+
+            def oracle_carver(im):
+                o = L.Carver(orc, im, delta_x=args.delta, rigidity=rigidity).configure(switch_freq=args.switch_freq, enl_step=1.5)
+                add_masks([o])
+                return o
+            oc = oracle_carver(img0_host)
+            tc = time.perf_counter()
+            assert oc.resize(cnw, cnh) == L.LQR_OK
+            tc = time.perf_counter() - tc
+            cpu_val = work_seam_px(cw, chh, cnw, cnh) / tc / 1e6
+            result["cpu_baseline"] = {"value": round(cpu_val, 1), "unit": "Mseams*px/s", "cores": 1, "kind": "port",
+                                      "sample": sample, "seconds": round(tc, 2), "nproc": ncores, "cpu": cpu_model()}
+            # parity spot check of the timed workload's first image against the oracle
+            if (cnw, cnh) == (NW, NH):
+                ref = oc.read_image()
+                got = carvers[0].read_image()
+                result["parity_vs_oracle"] = bool(np.array_equal(ref, got))
+            oc.destroy()
+            if nimg > 1 and headline:
+                # SURVEY 8(d): for the batch, one image per core over all host cores (liblqr itself is single-threaded;
+                # ctypes releases the GIL inside the C call, so threads run the oracle truly in parallel)
+                nt = min(ncores, nimg, len(host_keep))
+
+                def one(im):
+                    o = oracle_carver(im)
+                    r = o.resize(NW, NH)
+                    o.destroy()
+                    return r
+                ta = time.perf_counter()
+                with ThreadPoolExecutor(max_workers=nt) as ex:
+                    rets = list(ex.map(one, host_keep[:nt]))
+                ta = time.perf_counter() - ta
+                assert all(r == L.LQR_OK for r in rets)
+                result["cpu_baseline"]["all_cores"] = {
+                    "value": round(work_seam_px(W, H, NW, NH) * nt / ta / 1e6, 1), "unit": "Mseams*px/s", "cores": nt,
+                    "sample": "%d images of the workload, one per core, concurrently" % nt, "seconds": round(ta, 2)}
+
+        for c in carvers:
+            c.destroy()
+        if "phases" in result:
+            # the upload phase again with the device blocks of the carvers just destroyed recycled by the engine's block cache
+            # (a host that carves image after image; the first measurement above also pays hipMalloc for 12 GB)
+            bufs = [L._malloc_copy(im) for im in host_keep]
+            sync()
+            tu = time.perf_counter()
+            cs2 = [L.Carver.from_buffer(eng, bufs[i], W, H, 4, delta_x=args.delta, rigidity=rigidity) for i in range(nimg)]
+            sync()
+            warm = max_over_ranks((time.perf_counter() - tu) * 1e3)
+            for c in cs2:
+                c.destroy()
+            ph = result["phases"]
+            ph["upload_cold_ms"] = ph["upload_ms"]
+            ph["upload_ms"] = round(warm, 2)
+            ph["value_end_to_end_cold"] = ph["value_end_to_end"]
+            ph["value_end_to_end"] = round(work_rank / steps * world / ((warm + ms_per_step + ph["readout_ms"]) * 1e-3) / 1e6, 1)
+            ph["note"] += "; upload_cold_ms = the first creation in the process (hipMalloc of every block), upload_ms = the same calls with the engine's block cache warm, as the timed steps are"
+        del images, outs
+        torch.cuda.empty_cache()
+        return result
+
+    result = measure(args.workload, args.steps, args.warmup, True)
+    # ---- BASELINE configs 2, 3 and 5 -- the plug-in's own call shape, one carver (render.c:318) -- on the same line
+    if args.workload == "batch4k" and world == 1 and not args.no_configs and args.seams is None:
+        result["configs"] = {}
+        for name in ("fhd", "single4k", "config5"):
+            r = measure(name, 3, 1, False)
+            result["configs"][name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernels_ms", "phases",
+                                                          "cpu_baseline", "parity_vs_oracle", "hbm_used_gb") if k in r}
+    if dist is not None:
+        result["rccl_ranks"] = dist.get_world_size()
     if rank == 0:
         print(json.dumps(result), flush=True)
-    for c in carvers:
-        c.destroy()
     if dist is not None:
         dist.destroy_process_group()
 

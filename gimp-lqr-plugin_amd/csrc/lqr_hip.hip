@@ -39,6 +39,10 @@
 #include <vector>
 #include <algorithm>
 #include <map>
+#include <deque>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 
 #include "../../include/lqr_hip.h"
 
@@ -56,12 +60,7 @@
 #define FLAG_ORG_PREV 4         // origin of the frame the seam in seam_x was found in (carve)
 #define FLAG_SIDE 5             // 0: the part right of the seam moves left; 1: the part left of it moves right
 #define FLAG_COUNT 8
-// k_seam_fused: after the scalar flags, one word per SF_RW rows = the tag of the last launch whose workers finished
-// carving those rows and updating their energies
-#define FLAG_ROWS_BASE 64
-#define SF_RW 32
-#define DEVERR_FUSED_TIMEOUT 3
-#define PATCH_DW 16            /* dwords of a row's energy patch: xmin, xmax, up to 14 values */
+#define FLAG_WORDS 64           // size of a carver's flag block
 #define DP_THREADS 1024
 #define VPATH_THREADS 256
 #define BAND_PXL 4
@@ -85,7 +84,6 @@ struct DevCarver {
     int32_t *seam_x;
     int32_t *seam_log;
     int32_t *flags;
-    float *patch;           // per row: the energies k_emap_update<PATCH> computed for k_carve_pub to apply (PATCH_DW dwords)
 };
 
 // Pointers fetched from a descriptor in memory are "generic" to the compiler, which then
@@ -110,7 +108,6 @@ struct GCarver {
     gi8 *least, *least2;
     gf32 *bias, *rig;
     gi32 *seam_x, *seam_log, *flags;
-    gf32 *patch;
 };
 
 // physical view: plane pointers as allocated (row y starts at y * stride); what the carve and the one-off
@@ -123,7 +120,6 @@ __device__ __forceinline__ GCarver gview_phys(const DevCarver &d)
     g.m2 = (gf32 *) d.m2; g.least2 = (gi8 *) d.least2;
     g.bias = (gf32 *) d.bias; g.rig = (gf32 *) d.rig;
     g.seam_x = (gi32 *) d.seam_x; g.seam_log = (gi32 *) d.seam_log; g.flags = (gi32 *) d.flags;
-    g.patch = (gf32 *) d.patch;
     return g;
 }
 // logical view: the carved planes advanced by the image's current origin, so that x = 0 is the first pixel of
@@ -738,8 +734,8 @@ __device__ __forceinline__ void ld_left_u32(const gu32 *row, int base, int pend,
     }
     g.edge = (lane == 63 && base + CGPX <= pend) ? row[base + CGPX] : 0u;
 }
-// SC1: write-through stores (k_seam_fused's workers: the rows are read by another workgroup of the same launch, and a
-// write-through store needs no L2 write-back before the flag that announces it)
+// SC1: write-through stores instead of non-temporal ones (no kernel of this build asks for them: round 3's carve that
+// announced its rows did; the switch stays for A/B runs)
 template <bool SC1 = false>
 __device__ __forceinline__ void st_left_u32(gu32 *row, int base, int pv, int pend, int lane, const G32 &g)
 {
@@ -892,7 +888,7 @@ __device__ __forceinline__ void st_right_8(gu32 *row32, int gbase, int org, int 
     }
 }
 
-// one row of the carve, by one wave (the body of k_carve's row loop; k_seam_fused's workers run it too).  c = the
+// one row of the carve, by one wave (the body of k_carve's row loop).  c = the
 // PHYSICAL view, org / side = what k_vpath* published for this seam, w = the width before the carve.
 template <bool SC1 = false>
 __device__ __forceinline__ void carve_row(const GCarver &c, int org, int side, int y, int w, int stride, int delta, int move_dp, int lane)
@@ -938,98 +934,6 @@ __device__ __forceinline__ void carve_row(const GCarver &c, int org, int side, i
     }
 }
 
-#ifndef CARVE_SC1
-#define CARVE_SC1 true
-#endif
-// NR rows by one wave, their loads in flight together (k_seam_fused's workers, which have registers to spare and few
-// waves per CU): rows ys[r] (>= h: none) with their seam pixels v[r] and the row above's vprev[r]; the DP planes always
-// move (move_dp = 1); en and m by write-through stores.  Same helpers, same bytes as carve_row.
-template <int NR>
-__device__ __forceinline__ void carve_rows(const GCarver &c, int org, int side, const int (&ys)[NR], const int (&v)[NR], const int (&vprev)[NR],
-                                           int w, int h, int stride, int delta, int lane)
-{
-    const int wnew = w - 1;
-    gu32 *en[NR], *mm[NR], *l32[NR], *rg[NR];
-    bool on[NR];
-#pragma unroll
-    for (int r = 0; r < NR; r++) {
-        on[r] = ys[r] < h;
-        const size_t ro = (size_t) (on[r] ? ys[r] : 0) * stride;
-        en[r] = (gu32 *) (c.en + ro); mm[r] = (gu32 *) (c.m + ro); l32[r] = (gu32 *) (c.least + ro);
-        rg[r] = c.rig ? (gu32 *) (c.rig + ro) : (gu32 *) nullptr;
-    }
-    G32 E[NR], M[NR];
-    G8 L[NR];
-    if (side == 0) {
-        const int pend = org + wnew;
-        int pv[NR], start[NR], base[NR];
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            pv[r] = org + v[r];
-            start[r] = max((ys[r] > 0) ? min(v[r], vprev[r] - delta) : v[r], 0);
-            base[r] = on[r] ? ((org + start[r]) & ~3) : pend;
-        }
-        while (true) {
-            bool any = false;
-#pragma unroll
-            for (int r = 0; r < NR; r++) any |= base[r] < pend;
-            if (!any) break;
-#pragma unroll
-            for (int r = 0; r < NR; r++)
-                if (base[r] < pend) { ld_left_u32(en[r], base[r], pend, lane, E[r]); ld_left_u32(mm[r], base[r], pend, lane, M[r]); ld_left_8(l32[r], base[r], pend, lane, L[r]); }
-#pragma unroll
-            for (int r = 0; r < NR; r++)
-                if (base[r] < pend) {
-                    st_left_u32<CARVE_SC1>(en[r], base[r], pv[r], pend, lane, E[r]);
-                    st_left_u32<CARVE_SC1>(mm[r], base[r], pv[r], pend, lane, M[r]);
-                    st_left_8<CARVE_SC1>(l32[r], base[r], org, start[r], v[r], vprev[r], ys[r], wnew, lane, L[r]);
-                    base[r] += CGPX;
-                }
-        }
-#pragma unroll
-        for (int r = 0; r < NR; r++)
-            if (on[r] && rg[r])
-                for (int bs = pv[r] & ~3; bs < pend; bs += CGPX) { G32 R; ld_left_u32(rg[r], bs, pend, lane, R); st_left_u32<CARVE_SC1>(rg[r], bs, pv[r], pend, lane, R); }
-    } else {
-        int pv[NR], end_l[NR], ptop[NR], top[NR];
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            pv[r] = org + v[r];
-            end_l[r] = (ys[r] > 0) ? min(wnew, max(v[r], vprev[r] + delta)) : min(wnew, v[r]);
-            ptop[r] = org + 1 + max(end_l[r], 0);
-            const int top_u = (pv[r] | 3) + 1;
-            top[r] = on[r] ? max(top_u, (ptop[r] + 3) & ~3) : org + 1;
-        }
-        while (true) {
-            bool any = false;
-#pragma unroll
-            for (int r = 0; r < NR; r++) any |= top[r] > org + 1;
-            if (!any) break;
-#pragma unroll
-            for (int r = 0; r < NR; r++)
-                if (top[r] > org + 1) {
-                    const int gbase = top[r] - CGPX;
-                    ld_right_u32(en[r], gbase, org, pv[r], lane, E[r]); ld_right_u32(mm[r], gbase, org, pv[r], lane, M[r]); ld_right_8(l32[r], gbase, org, ptop[r], lane, L[r]);
-                }
-#pragma unroll
-            for (int r = 0; r < NR; r++)
-                if (top[r] > org + 1) {
-                    const int gbase = top[r] - CGPX;
-                    st_right_u32<CARVE_SC1>(en[r], gbase, org, pv[r], lane, E[r]);
-                    st_right_u32<CARVE_SC1>(mm[r], gbase, org, pv[r], lane, M[r]);
-                    st_right_8<CARVE_SC1>(l32[r], gbase, org, max(end_l[r], 0), v[r], vprev[r], ys[r], lane, L[r]);
-                    top[r] -= CGPX;
-                }
-        }
-#pragma unroll
-        for (int r = 0; r < NR; r++)
-            if (on[r] && rg[r]) {
-                const int top_u = (pv[r] | 3) + 1;
-                for (int tp = top_u; tp > org + 1; tp -= CGPX) { G32 R; ld_right_u32(rg[r], tp - CGPX, org, pv[r], lane, R); st_right_u32<CARVE_SC1>(rg[r], tp - CGPX, org, pv[r], lane, R); }
-            }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h, int stride, int delta, int move_dp)
 {
     // blockIdx.x = row block (fastest): consecutive workgroups take consecutive rows of one image (2.5 % faster than
@@ -1038,38 +942,6 @@ __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h
     const int org = c.flags[FLAG_ORG_PREV], side = c.flags[FLAG_SIDE];      // published by k_vpath* for this seam
     const int lane = threadIdx.x & 63;
     for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < h; y += gridDim.x * 4) carve_row(c, org, side, y, w, stride, delta, move_dp, lane);
-}
-
-// k_carve that announces its rows (lqrhip_set_fused(3)): every store write-through, then the
-// row's new energies from the patch k_emap_update<PATCH> left (PATCH_DW dwords per row: xmin, xmax, the values), then the
-// wave counts its row into the 32-row chunk; the wave that completes a chunk resets the counter and stores the launch's tag
-// into the chunk word k_band_update_tw_f polls.  Write-through stores that have completed (s_waitcnt vmcnt(0)) are visible
-// device-wide, so no L2 write-back (release fence) is needed before the count.
-__global__ __launch_bounds__(256) void k_carve_pub(const DevCarver *cs, int w, int h, int stride, int delta, int tag)
-{
-    const GCarver c = gview_phys(cs[blockIdx.y]);
-    const int org = c.flags[FLAG_ORG_PREV], side = c.flags[FLAG_SIDE];      // published by k_vpath* for this seam
-    const int lane = threadIdx.x & 63;
-    const int nchunks = (h + SF_RW - 1) / SF_RW;
-    for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < h; y += gridDim.x * 4) {
-        const gi32 *pt = (const gi32 *) c.patch + (size_t) y * PATCH_DW;
-        const int xmin = pt[0], xmax = pt[1];
-        const int x = xmin + lane;
-        const int pv = (x <= xmax) ? pt[2 + min(lane, PATCH_DW - 3)] : 0;
-        carve_row<true>(c, org, side, y, w, stride, delta, 1, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the row's stores first: the patch lands on top of them
-        if (x <= xmax) __hip_atomic_store((gi32 *) c.en + (size_t) y * stride + (org + side) + x, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) {
-            const int ch = y / SF_RW;
-            gi32 *cnt = c.flags + FLAG_ROWS_BASE + nchunks + 64 + ch;
-            const int rows = min(SF_RW, h - ch * SF_RW);
-            if (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == rows - 1) {
-                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(c.flags + FLAG_ROWS_BASE + ch, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
 }
 
 // changed-energy interval of row y after carving (liblqr update_emap), w = new width
@@ -1114,9 +986,7 @@ __device__ __forceinline__ int block_rank_256(bool flag, int *s_wave, int &total
 #ifndef EU_LOGB
 #define EU_LOGB 8            // log entries fetched per round of the walk back to the frozen frame
 #endif
-// PATCH: the energies go to the row's patch (k_carve_pub applies them once it has moved the row) instead of `en`, so that
-// this kernel can run BEFORE the carve; rows without a changed interval get an empty one
-template <int NRG, int EU_NT, bool PATCH = false>
+template <int NRG, int EU_NT>
 __global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, int w, int h, int stride, int k, int epoch)
 {
     const GCarver c = gview(cs[blockIdx.y]);
@@ -1168,97 +1038,10 @@ __global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, 
     slo[tid] = lo;
     __syncthreads();
     if (!row_ok || tid == 0 || tid == 63) return;
-    if (PATCH) {
-        gi32 *pt = (gi32 *) c.patch + (size_t) y * PATCH_DW;
-        pt[0] = xmin; pt[1] = min(xmax, xmin + PATCH_DW - 3);          // (an interval is at most 6 columns where this form runs)
-    }
     for (int x = xmin; x <= xmax; x++) {
         float e = grad_energy_f<NRG>([&](int xx, int yy) { const int t = tid + (yy - y); return bt[t][xx - slo[t]]; }, x, y, w, h);
         if (c.bias) e = __fadd_rn(e, __fdiv_rn(bb[tid][x - lo], (float) p.w_start));
-        if (PATCH) { if (x - xmin < PATCH_DW - 2) c.patch[(size_t) y * PATCH_DW + 2 + (x - xmin)] = e; }
-        else c.en[(size_t) y * stride + x] = e;
-    }
-}
-
-// k_emap_update's rows, by one WAVE for NR rows (k_seam_fused's workers: the wave that carves rows also refreshes their
-// energies).  Per row: lane rr * 12 + i stages the brightness of column L + i of row y - 1 + rr (L = xmin - 1: the gradient
-// of x in [xmin, xmax] asks for [xmin - 1, xmax + 1] on the three rows, at most 6 columns for delta_x = 1, radius 1), mapped
-// back to the frozen frame through that row's seam log exactly as k_emap_update does; lanes 0 .. xmax - xmin then evaluate
-// the same grad_energy_f on the same doubles.  Built as a pipeline over the wave's rows so that a wave pays two memory
-// round trips for all of them: the log entries of the three rows (<= FROZEN_LAG_MAX each, adjacent in memory: the log is
-// seam-major) are fetched by all lanes BEFORE the wave carves (emap_log_issue), walked newest-first from LDS after it
-// (emap_undo), then all rows' pixels are fetched (emap_fetch) and the energies stored (emap_store).
-#define EW_NT 12
-#define EW_LOG 128              // >= FROZEN_LAG_MAX
-#define EW_ROWS 2
-struct EmapLog { int v[2][3]; };    // [64-entry round][row y-1 .. y+1]
-struct __attribute__((aligned(16))) EmapLds { int lg[3][EW_LOG]; double bt[EW_ROWS][3 * EW_NT]; float bb[EW_ROWS][EW_NT]; };
-struct EmapRow { int y, xmin, xmax, L, pos; bool ok; uint32_t px; float bi; };
-__device__ __forceinline__ void emap_log_issue(const GCarver &c, int y, int h, int k, int epoch, int lane, EmapLog &g)
-{
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int j = epoch + 64 * t + lane;
-#pragma unroll
-        for (int rr = 0; rr < 3; rr++) {
-            const int row = min(max(y - 1 + rr, 0), h - 1);
-            g.v[t][rr] = (y < h && j <= k) ? c.seam_log[(size_t) j * h + row] : 0x7fffffff;
-        }
-    }
-}
-// frozen-frame position of this lane's sample of row e.y (e.xmin / e.xmax / e.L set by the caller; xmax < xmin: nothing)
-__device__ __forceinline__ void emap_undo(int w, int h, int k, int epoch, int lane, const EmapLog &g, EmapLds &s, EmapRow &e)
-{
-    const int cnt = k - epoch + 1;                // logged seams to undo (<= EW_LOG by the catch-up rule)
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int rr = 0; rr < 3; rr++) s.lg[rr][64 * t + lane] = g.v[t][rr];        // beyond cnt: a value that moves nothing
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int rr = min(lane / EW_NT, 2), i = lane - rr * EW_NT;
-    const int row = e.y - 1 + rr;
-    const bool act = lane < 3 * EW_NT && row >= 0 && row < h && e.L + i <= w - 1 && e.xmax >= e.xmin;
-    int pos = e.L + i;
-    {
-        typedef int i32x4 __attribute__((ext_vector_type(4)));
-        const i32x4 *lg4 = (const i32x4 *) s.lg[rr];
-#pragma unroll 4
-        for (int j4 = (cnt - 1) >> 2; j4 >= 0; j4--) {           // newest first, four entries per LDS read
-            const i32x4 q = lg4[j4];
-            pos += (q.w <= pos) ? 1 : 0; pos += (q.z <= pos) ? 1 : 0; pos += (q.y <= pos) ? 1 : 0; pos += (q.x <= pos) ? 1 : 0;
-        }
-    }
-    const int wf = w + (k - epoch) + 1;           // width of the frozen frame
-    e.ok = act && pos < wf;
-    e.pos = pos;
-    __builtin_amdgcn_wave_barrier();              // s.lg is reused for the wave's next row
-}
-__device__ __forceinline__ void emap_fetch(const GCarver &c, int stride, int lane, EmapRow &e)
-{
-    const int rr = min(lane / EW_NT, 2);
-    const size_t o = (size_t) (e.ok ? e.y - 1 + rr : 0) * stride + (e.ok ? e.pos : 0);
-    e.px = e.ok ? c.pix[o] : 0u;
-    e.bi = (e.ok && c.bias && rr == 1) ? c.bias[o] : 0.0f;
-}
-template <int NRG>
-__device__ __forceinline__ void emap_stage(const DpK &p, int lane, int r, EmapLds &s, const EmapRow &e, const double *n255)
-{
-    constexpr bool luma = (NRG >= 3);
-    const int rr = min(lane / EW_NT, 2), i = lane - rr * EW_NT;
-    const double b = e.ok ? px_bright(e.px, p.ch, luma, Norm255Lut{n255}) : 0.0;
-    if (lane < 3 * EW_NT) s.bt[r][lane] = b;
-    if (lane >= EW_NT && lane < 2 * EW_NT) s.bb[r][i] = e.bi;
-}
-template <int NRG>
-__device__ __forceinline__ void emap_store(const GCarver &c, const DpK &p, int w, int h, int stride, int lane, int r, const EmapLds &s, const EmapRow &e)
-{
-    if (lane <= e.xmax - e.xmin) {
-        const int x = e.xmin + lane, y = e.y, L = e.L;
-        float en = grad_energy_f<NRG>([&](int xx, int yy) { return s.bt[r][(yy - y + 1) * EW_NT + (xx - L)]; }, x, y, w, h);
-        if (c.bias) en = __fadd_rn(en, __fdiv_rn(s.bb[r][x - L], (float) p.w_start));
-        __hip_atomic_store(c.en + (size_t) y * stride + x, en, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through, like the carve's
+        c.en[(size_t) y * stride + x] = e;
     }
 }
 
@@ -1904,18 +1687,8 @@ constexpr int TW_OWN = 256 - 2 * TW_R;       // own columns per slot
 // and that path is this kernel's bound.
 constexpr int TW_LANE_MARGIN = 2 * TW_R + 8;
 
-#ifdef LQR_FUSED_TIMING
-// [0][c] worker: chunk c of image 0 published; [1][c] band wave 0 of image 0: first asked for chunk c; [2][c] got it;
-// [3][0] band start, [3][1] band end   (s_memrealtime, 100 MHz)
-__device__ unsigned long long g_fz[4][128];
-#define FZ(i, j) do { if (blockIdx.x == 0 && wv == 0 && lane == 0) g_fz[i][min(j, 127)] = wall_clock64(); } while (0)
-#else
-#define FZ(i, j) do { } while (0)
-#endif
-// FUSED: the rows are being carved (and their energies updated) by other workgroups of the same launch (k_seam_fused);
-// before a wave reads rows of the planes it makes sure their chunks carry this launch's tag (wait_rows).
-template <int NW, bool LR, bool RIG, bool FUSED>
-__device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const DpK &p, int w, int h, int stride, int *dev_err, int tag)
+template <int NW, bool LR, bool RIG>
+__device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const DpK &p, int w, int h, int stride, int *dev_err)
 {
     constexpr int R = TW_R, OWN = TW_OWN, WIN = NW * OWN, NT = 128 * NW;
     const GCarver c = gview(dc);
@@ -1932,34 +1705,6 @@ __device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const D
     const float INF = __int_as_float(0x7f800000);
     const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
 
-    // FUSED: rows [0, need) ready?  Per wave: `ready` rows are known to be; otherwise one relaxed poll of the next 64
-    // chunk words (a lane each), and after new ones showed up ONE agent-scope acquire before the plain loads that follow
-    // (MI355X_MICROARCH.md, inter-workgroup visibility).  Bounded: a worker that never arrives is reported, not waited for.
-    int ready = FUSED ? 0 : h;
-    if (FUSED) FZ(3, 0);
-    auto wait_rows = [&](int need) {
-        if constexpr (FUSED) {
-            need = min(need, h);
-            const int nchunks = (h + SF_RW - 1) / SF_RW;
-            int spins = 0;
-            if (ready < need) FZ(1, ready / SF_RW);
-            while (ready < need) {
-                const int ch0 = ready / SF_RW;
-                const int f = (ch0 + lane < nchunks) ? __hip_atomic_load(c.flags + FLAG_ROWS_BASE + ch0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
-                const unsigned long long bad = __ballot(f != tag);
-                const int nready = bad ? __builtin_ctzll(bad) : 64;
-                if (nready > 0) {
-                    ready = __builtin_amdgcn_readfirstlane(min(h, (ch0 + nready) * SF_RW));
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    FZ(2, ch0);
-                } else {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1 << 21)) { if (lane == 0) dev_fail(dev_err, DEVERR_FUSED_TIMEOUT); ready = h; }
-                }
-            }
-        }
-    };
-
     // pixels of row y whose inputs the carve changed (see k_band_update_mw), then the union over the
     // 16 rows of a batch starting at y
     for (int y = tid; y < h; y += NT) {
@@ -1967,7 +1712,6 @@ __device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const D
         const int t0 = max(min(min(v0, vm), vp) - 2, 0), t1 = min(max(max(v0, vm), vp) + 1, w - 1);
         s_touch[y] = t0 | (t1 << 16);
     }
-    wait_rows(1);
     {   // row 0: m = en on liblqr's interval
         const int v0 = c.seam_x[0], vp = c.seam_x[min(1, h - 1)];
         int lo = v0, hi = v0 - 1;
@@ -2040,9 +1784,7 @@ __device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const D
             nb = max(0, min(nb, (w - WIN + 3) & ~3));
             B = __builtin_amdgcn_readfirstlane(nb);
             have_window = true;
-            // rows < y were stored by this workgroup: make them visible, then reload the row above (FUSED: outside the old
-            // window it is as the carve left it)
-            wait_rows(y);
+            // rows < y were stored by this workgroup: make them visible, then reload the row above
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -2192,7 +1934,6 @@ __device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const D
             // already contain the R columns of the slot test)
             const int xl = B + OWN * slot - R + 4 * lane;
             lane_staged = issue_full && (lane_all || (xl + 3 >= plo_l && xl <= phi_l));
-            wait_rows(y_issue + R);
             issue(y_issue, lane_staged);
             loads_full = issue_full;
         }
@@ -2201,104 +1942,13 @@ __device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const D
             __syncthreads();
         }
     }
-    // FUSED: rows from `ovf` on are the full-width sweep's, in the next launch -- nothing of this one is left to wait for
-    if (FUSED) FZ(3, 1);
     if (tid == 0) c.flags[FLAG_OVF_ROW] = ovf;
 }
 
 template <int NW, bool LR, bool RIG>
 __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs, DpK p, int w, int h, int stride, int *dev_err)
 {
-    band_update_tw_body<NW, LR, RIG, false>(cs[blockIdx.x], p, w, h, stride, dev_err, 0);
-}
-
-// ---------------------------------------------------------------------------
-// Carve + energy update as ONE launch that publishes its progress, and a band update that can run next to it (delta_x = 1,
-// no rigidity mask that matters, rows up to 4200 px).
-//   k_seam_work: workgroup (image, chunk) carves rows [chunk * SF_RW, + SF_RW) of the image (a wave two rows at a time,
-//       carve_rows), refreshes those rows' energies (the emap_* pipeline: two memory round trips per pair of rows instead
-//       of a launch of its own) and publishes the chunk -- every wave drains its stores, barrier, ONE agent-scope release,
-//       the launch's tag into the image's chunk word (FLAG_ROWS_BASE + chunk);
-//   k_band_update_tw_f: band_update_tw_body<FUSED> -- before a wave reads rows it makes sure their chunks carry the tag
-//       (one relaxed poll, one agent-scope acquire when new chunks showed up).
-// On ONE stream (lqrhip_set_fused(1)) the second launch simply follows the first: k_emap_update's launch and its place in
-// the round's dependency chain are gone.  On TWO streams of the batch (2) the band update starts while the rows are still
-// being carved -- it walks down the image at ~0.27 us per row and needs a row only when it prefetches it -- and stalls for
-// the first chunk only.  The workers wait for nobody and are enqueued before the band update that waits for them, so
-// whatever hardware queues the streams land on nothing can deadlock (sharing one queue serialises them: slower, not
-// wrong); the band update's wait is bounded (DEVERR_FUSED_TIMEOUT).  DESIGN.md section 4.14.
-// ---------------------------------------------------------------------------
-template <int NRG>
-__global__ __launch_bounds__(512) void k_seam_work(const DevCarver *cs, DpK p, int w, int h, int stride, int k, int epoch, int tag)
-{
-    // w = the width BEFORE this seam's carve; blockIdx.x = image (fastest: all images' top rows first), blockIdx.y = chunk
-    __shared__ double s_n255[256];
-    __shared__ int s_seam[SF_RW + 4];                      // seam_x[y0 - 2 .. y0 + SF_RW + 1], clamped to the image
-    __shared__ EmapLds s_em[8];
-    const int chunk = blockIdx.y, img = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const GCarver cp = gview_phys(cs[img]);
-    const int y0 = chunk * SF_RW, yend = min(y0 + SF_RW, h);
-    fill_norm255(s_n255, tid, 512);
-    if (tid < SF_RW + 4) s_seam[tid] = cp.seam_x[min(max(y0 - 2 + tid, 0), h - 1)];
-    __syncthreads();
-    auto seam = [&](int y) { return s_seam[min(max(y, 0), h - 1) - (y0 - 2)]; };
-    const int org = cp.flags[FLAG_ORG_PREV], side = cp.flags[FLAG_SIDE];      // published by k_vpath* for this seam
-    const GCarver c = gview(cs[img]);
-    const int wnew = w - 1;
-#pragma unroll 1
-    for (int yb = y0 + wv; yb < yend; yb += 8 * EW_ROWS) {
-        // the wave's rows yb + 8 r: log entries and plane rows in flight together, then the pixels
-        int ys[EW_ROWS], v[EW_ROWS], vprev[EW_ROWS];
-        EmapLog g[EW_ROWS];
-        EmapRow e[EW_ROWS];
-#pragma unroll
-        for (int r = 0; r < EW_ROWS; r++) {
-            const int y = yb + 8 * r;
-            ys[r] = y < yend ? y : h;
-            v[r] = seam(y); vprev[r] = y > 0 ? seam(y - 1) : 0;
-            emap_log_issue(c, ys[r], h, k, epoch, lane, g[r]);
-            // changed-energy interval of the row (nrg_interval, on the staged seam)
-            int lo = v[r], hi = v[r] - 1;
-            for (int y1 = max(y - p.radius, 0); y1 <= min(y + p.radius, h - 1); y1++) { const int x = seam(y1); lo = min(lo, x - p.radius); hi = max(hi, x + p.radius - 1); }
-            e[r].y = y; e[r].xmin = max(0, lo); e[r].xmax = ys[r] < h ? min(wnew - 1, hi) : -1;
-            e[r].L = max(e[r].xmin - 1, 0);
-        }
-        carve_rows<EW_ROWS>(cp, org, side, ys, v, vprev, w, h, stride, p.delta, lane);
-#pragma unroll
-        for (int r = 0; r < EW_ROWS; r++) emap_undo(wnew, h, k, epoch, lane, g[r], s_em[wv], e[r]);
-#pragma unroll
-        for (int r = 0; r < EW_ROWS; r++) emap_fetch(c, stride, lane, e[r]);
-#pragma unroll
-        for (int r = 0; r < EW_ROWS; r++) emap_stage<NRG>(p, lane, r, s_em[wv], e[r], s_n255);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the carve's stores to these rows first
-#pragma unroll
-        for (int r = 0; r < EW_ROWS; r++) emap_store<NRG>(c, p, wnew, h, stride, lane, r, s_em[wv], e[r]);
-        __builtin_amdgcn_wave_barrier();                          // the LDS block is reused by the next pair of rows
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // restated: the compiler may drop the fence's own wait
-        __hip_atomic_store(cp.flags + FLAG_ROWS_BASE + chunk, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef LQR_FUSED_TIMING
-        if (img == 0) g_fz[0][min(chunk, 127)] = wall_clock64();
-#endif
-    }
-}
-#ifdef LQR_FUSED_TIMING
-extern "C" int lqrhip_fused_timing(unsigned long long *out) { (void) hipDeviceSynchronize(); return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fz), sizeof(unsigned long long) * 4 * 128) == hipSuccess ? 0 : -1; }
-#endif
-
-template <int NW, bool LR, bool RIG>
-__global__ __launch_bounds__(128 * NW) void k_band_update_tw_f(const DevCarver *cs, DpK p, int w, int h, int stride, int *dev_err, int tag)
-{
-    band_update_tw_body<NW, LR, RIG, true>(cs[blockIdx.x], p, w, h, stride, dev_err, tag);
+    band_update_tw_body<NW, LR, RIG>(cs[blockIdx.x], p, w, h, stride, dev_err);
 }
 
 #ifdef LQR_BAND_EXPERIMENTS
@@ -2997,7 +2647,6 @@ struct LqrHipCarver {
     float *en = nullptr, *m = nullptr, *m2 = nullptr, *bias = nullptr, *rig = nullptr;
     int8_t *least = nullptr, *least2 = nullptr;
     int32_t *seam_x = nullptr, *seam_log = nullptr, *flags = nullptr;
-    float *patch = nullptr;          // energy patches of lqrhip_set_fused(3), allocated with its first launch
     int log_cap = 0, log_h = 0;
     int frozen_epoch = 0;           // pix / bias are in the frame before seam `frozen_epoch` of the session
     LqrHipCarver *root = nullptr;
@@ -3013,9 +2662,6 @@ struct LqrHipBatch {
     size_t exch_elems = 0;
     int exch_ntiles = 0, exch_n = 0, exch_px = 0;      // geometry the exchange area was last laid out for
     int tile_epoch = 0;                     // launches of k_dp_tile_p on this batch (part of the granule tags)
-    int fuse_tag = 0;                       // tag of the last k_seam_work launch on this batch (the chunk words' value)
-    hipStream_t stream_w = nullptr;         // the workers' stream (two-stream mode; created with the first such launch)
-    hipEvent_t ev_seam = nullptr, ev_work = nullptr;
     bool dirty = true;
     bool shared = false;                    // other batches of the same group run concurrently on their own streams:
                                             // no persistent (spin-waiting, co-residency-dependent) kernels
@@ -3229,58 +2875,166 @@ static hipError_t dzero(void *p, size_t bytes)
 
 // Host <-> device copies of whole images.  The plug-in hands over and takes back PAGEABLE memory (a g_malloc'ed buffer at
 // lqr_carver_new, render.c:222; the scan-line buffer at read-out, io_functions.c:155-164); hipMemcpy on pageable memory
-// runs at ~1-2 GB/s here (it pins and unpins as it goes).  These go through two pinned bounce buffers instead: the CPU
-// copies chunk k + 1 into (out of) one while the DMA engine moves chunk k from (to) the other, on the shim's stream.
-// Both return with the transfer complete.
-static const size_t STAGE_BYTES = (size_t) 8 << 20;
-static uint8_t *g_stage[2] = {nullptr, nullptr};
-static hipEvent_t g_stage_ev[2] = {nullptr, nullptr};
+// runs at ~1-2 GB/s here (it pins and unpins as it goes).  These go through a ring of pinned bounce buffers instead, and
+// the CPU side of the bounce -- memcpy between the caller's pageable buffer and the ring, page faults of a freshly
+// allocated destination included -- is done by a few helper threads in parallel while the DMA engine moves other chunks
+// (round 3: one thread, two 8 MB buffers: 8.6 GB/s up, 4.2 GB/s down; a single core's memcpy and its page faults were
+// the limit, not PCIe).  The helpers touch host memory only; every HIP call stays on the caller's thread.
+// Both functions return with the transfer complete, also on error (the stream is drained before they return).
+static const size_t STAGE_BYTES = (size_t) 4 << 20;
+static const int STAGE_SLOTS = 16;
+static uint8_t *g_stage[STAGE_SLOTS];
+static hipEvent_t g_stage_ev[STAGE_SLOTS];
+static bool g_stage_ready = false;
+
+struct CopyPool {
+    struct Job { void *dst; const void *src; size_t n; };
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::deque<std::pair<int, Job>> q;      // (ticket, job)
+    std::vector<char> done;                 // per ticket of the current transfer
+    size_t pending = 0;                     // submitted and not finished
+    bool stop = false;
+    void start(int n)
+    {
+        for (int i = 0; i < n; i++) th.emplace_back([this] { run(); });
+    }
+    void run()
+    {
+        for (;;) {
+            std::pair<int, Job> j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [this] { return stop || !q.empty(); });
+                if (stop && q.empty()) return;
+                j = q.front(); q.pop_front();
+            }
+            memcpy(j.second.dst, j.second.src, j.second.n);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                done[j.first] = 1;
+                pending--;
+            }
+            cv_done.notify_all();
+        }
+    }
+    void begin(size_t tickets) { std::lock_guard<std::mutex> lk(mu); done.assign(tickets, 0); }
+    void submit(int ticket, void *dst, const void *src, size_t n)
+    {
+        { std::lock_guard<std::mutex> lk(mu); q.emplace_back(ticket, Job{dst, src, n}); pending++; }
+        cv_job.notify_one();
+    }
+    void drain()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [this] { return pending == 0; });
+    }
+    void wait(int ticket)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return done[ticket] != 0; });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_job.notify_all();
+        for (auto &t : th) t.join();
+    }
+};
+static CopyPool *g_copy_pool = nullptr;
+
 static int stage_init(void)
 {
-    if (g_stage[0]) return 0;
-    for (int i = 0; i < 2; i++) {
-        HIPCK(hipHostMalloc((void **) &g_stage[i], STAGE_BYTES, hipHostMallocDefault));
-        HIPCK(hipEventCreateWithFlags(&g_stage_ev[i], hipEventDisableTiming));
+    if (g_stage_ready) return 0;
+    // all or nothing: a partial set of buffers / events is released again, so a later call starts over
+    int made = 0;
+    hipError_t e = hipSuccess;
+    for (; made < STAGE_SLOTS; made++) {
+        g_stage[made] = nullptr; g_stage_ev[made] = nullptr;
+        if ((e = hipHostMalloc((void **) &g_stage[made], STAGE_BYTES, hipHostMallocDefault)) != hipSuccess) break;
+        if ((e = hipEventCreateWithFlags(&g_stage_ev[made], hipEventDisableTiming)) != hipSuccess) { (void) hipHostFree(g_stage[made]); break; }
     }
+    if (made < STAGE_SLOTS) {
+        for (int i = 0; i < made; i++) { (void) hipHostFree(g_stage[i]); (void) hipEventDestroy(g_stage_ev[i]); g_stage[i] = nullptr; }
+        g_err = std::string("staging buffers: ") + hipGetErrorString(e);
+        (void) hipGetLastError();
+        return e == hipErrorOutOfMemory ? LQRHIP_ENOMEM : LQRHIP_EHIP;
+    }
+    if (!g_copy_pool) {
+        unsigned hw = std::thread::hardware_concurrency();
+        g_copy_pool = new CopyPool();
+        g_copy_pool->start(hw >= 16 ? 8 : hw >= 4 ? (int) hw / 2 : 1);
+    }
+    g_stage_ready = true;
     return 0;
 }
 static int h2d_staged(void *dst, const void *src, size_t bytes)
 {
     int rc = stage_init();
     if (rc) return rc;
-    int k = 0;
-    for (size_t off = 0; off < bytes; off += STAGE_BYTES, k ^= 1) {
-        const size_t n = std::min(STAGE_BYTES, bytes - off);
-        HIPCK(hipEventSynchronize(g_stage_ev[k]));                 // the copy that last read this buffer is done
-        memcpy(g_stage[k], (const uint8_t *) src + off, n);
-        HIPCK(hipMemcpyAsync((uint8_t *) dst + off, g_stage[k], n, hipMemcpyHostToDevice, g_stream0));
-        HIPCK(hipEventRecord(g_stage_ev[k], g_stream0));
-    }
-    HIPCK(hipStreamSynchronize(g_stream0));
-    return 0;
+    const size_t nchunk = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
+    CopyPool &cp = *g_copy_pool;
+    cp.begin(nchunk);
+    auto body = [&]() -> int {
+        size_t submitted = 0;
+        for (size_t i = 0; i < nchunk; i++) {
+            // keep the helpers a ring ahead: chunk j goes into slot j % STAGE_SLOTS once the DMA that last read it is done
+            for (; submitted < nchunk && submitted < i + STAGE_SLOTS; submitted++) {
+                const int slot = (int) (submitted % STAGE_SLOTS);
+                HIPCK(hipEventSynchronize(g_stage_ev[slot]));
+                const size_t off = submitted * STAGE_BYTES;
+                cp.submit((int) submitted, g_stage[slot], (const uint8_t *) src + off, std::min(STAGE_BYTES, bytes - off));
+            }
+            const int slot = (int) (i % STAGE_SLOTS);
+            const size_t off = i * STAGE_BYTES;
+            cp.wait((int) i);
+            HIPCK(hipMemcpyAsync((uint8_t *) dst + off, g_stage[slot], std::min(STAGE_BYTES, bytes - off), hipMemcpyHostToDevice, g_stream0));
+            HIPCK(hipEventRecord(g_stage_ev[slot], g_stream0));
+        }
+        return 0;
+    };
+    rc = body();
+    cp.drain();         // whatever happened, nobody touches the caller's buffer or the ring after we return
+    hipError_t e = hipStreamSynchronize(g_stream0);
+    if (!rc && e != hipSuccess) { g_err = std::string("upload: ") + hipGetErrorString(e); rc = LQRHIP_EHIP; }
+    return rc;
 }
 static int d2h_staged(void *dst, const void *src, size_t bytes)
 {
     int rc = stage_init();
     if (rc) return rc;
-    // chunk k is copied out of its buffer while chunk k + 1 is in flight into the other
-    size_t off_prev = 0, n_prev = 0;
-    int k = 0;
-    for (size_t off = 0; off < bytes; off += STAGE_BYTES, k ^= 1) {
-        const size_t n = std::min(STAGE_BYTES, bytes - off);
-        HIPCK(hipMemcpyAsync(g_stage[k], (const uint8_t *) src + off, n, hipMemcpyDeviceToHost, g_stream0));
-        HIPCK(hipEventRecord(g_stage_ev[k], g_stream0));
-        if (n_prev) {
-            HIPCK(hipEventSynchronize(g_stage_ev[k ^ 1]));
-            memcpy((uint8_t *) dst + off_prev, g_stage[k ^ 1], n_prev);
+    const size_t nchunk = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
+    CopyPool &cp = *g_copy_pool;
+    cp.begin(nchunk);
+    size_t copied_out = 0;      // chunks handed to the helpers
+    auto hand_over = [&](size_t j) -> int {
+        const int slot = (int) (j % STAGE_SLOTS);
+        const size_t off = j * STAGE_BYTES;
+        HIPCK(hipEventSynchronize(g_stage_ev[slot]));
+        cp.submit((int) j, (uint8_t *) dst + off, g_stage[slot], std::min(STAGE_BYTES, bytes - off));
+        return 0;
+    };
+    auto body = [&]() -> int {
+        for (size_t i = 0; i < nchunk; i++) {
+            if (i >= (size_t) STAGE_SLOTS) {              // slot reuse: the helper must have emptied it
+                for (; copied_out <= i - STAGE_SLOTS; copied_out++) { int r = hand_over(copied_out); if (r) return r; }
+                cp.wait((int) (i - STAGE_SLOTS));
+            }
+            const int slot = (int) (i % STAGE_SLOTS);
+            const size_t off = i * STAGE_BYTES;
+            HIPCK(hipMemcpyAsync(g_stage[slot], (const uint8_t *) src + off, std::min(STAGE_BYTES, bytes - off), hipMemcpyDeviceToHost, g_stream0));
+            HIPCK(hipEventRecord(g_stage_ev[slot], g_stream0));
+            // hand over whatever has landed already, without waiting for it
+            while (copied_out < i && hipEventQuery(g_stage_ev[copied_out % STAGE_SLOTS]) == hipSuccess) { int r = hand_over(copied_out); if (r) return r; copied_out++; }
         }
-        off_prev = off; n_prev = n;
-    }
-    if (n_prev) {
-        HIPCK(hipEventSynchronize(g_stage_ev[k ^ 1]));
-        memcpy((uint8_t *) dst + off_prev, g_stage[k ^ 1], n_prev);
-    }
-    return 0;
+        for (; copied_out < nchunk; copied_out++) { int r = hand_over(copied_out); if (r) return r; }
+        return 0;
+    };
+    rc = body();
+    cp.drain();         // the helpers are done with the caller's buffer
+    if (rc) (void) hipStreamSynchronize(g_stream0);
+    return rc;
 }
 
 static int batch_sync_of(LqrHipCarver *c)
@@ -3309,7 +3063,7 @@ extern "C" LqrHipCarver *lqrhip_carver_create(const unsigned char *rgb, int w, i
 static void free_working(LqrHipCarver *c)
 {
     dfree(c->pix); dfree(c->en); dfree(c->m); dfree(c->least); dfree(c->m2); dfree(c->least2); dfree(c->bias); dfree(c->rig);
-    dfree(c->seam_x); dfree(c->seam_log); dfree(c->flags); dfree(c->patch);
+    dfree(c->seam_x); dfree(c->seam_log); dfree(c->flags);
     c->log_cap = 0;
 }
 
@@ -3354,7 +3108,7 @@ static int ensure_working(LqrHipCarver *c, int w, int h)
     size_t n = (size_t) stride * (h + 1) + 1024;
     int rc;
     if ((rc = dmalloc(&c->pix, n)) || (rc = dmalloc(&c->en, n)) || (rc = dmalloc(&c->m, n)) || (rc = dmalloc(&c->least, n)) ||
-        (rc = dmalloc(&c->seam_x, (size_t) h + 8)) || (rc = dmalloc(&c->flags, (size_t) FLAG_ROWS_BASE + 2 * ((h + SF_RW - 1) / SF_RW + 64))) ||
+        (rc = dmalloc(&c->seam_x, (size_t) h + 8)) || (rc = dmalloc(&c->flags, (size_t) FLAG_WORDS)) ||
         (need_bias && (rc = dmalloc(&c->bias, n))) || (need_rig && (rc = dmalloc(&c->rig, n)))) {
         free_working(c);            // never leave a half-allocated set behind: a retry must not pass the early-out above
         return rc;
@@ -3364,7 +3118,7 @@ static int ensure_working(LqrHipCarver *c, int w, int h)
     if (e == hipSuccess) e = hipMemsetAsync(c->m, 0, n * sizeof(float), g_stream0);
     if (e == hipSuccess) e = hipMemsetAsync(c->en, 0, n * sizeof(float), g_stream0);
     if (e == hipSuccess) e = hipMemsetAsync(c->pix, 0, n * sizeof(uint32_t), g_stream0);
-    if (e == hipSuccess) e = hipMemsetAsync(c->flags, 0, ((size_t) FLAG_ROWS_BASE + 2 * ((h + SF_RW - 1) / SF_RW + 64)) * sizeof(int32_t), g_stream0);
+    if (e == hipSuccess) e = hipMemsetAsync(c->flags, 0, (size_t) FLAG_WORDS * sizeof(int32_t), g_stream0);
     if (e == hipSuccess) e = hipStreamSynchronize(g_stream0);
     if (e != hipSuccess) { free_working(c); HIPCK(e); }
     c->stride = stride; c->wk_h = h;
@@ -3435,8 +3189,8 @@ extern "C" int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int c
 // 64 x 4K with 4 streams: +12 % throughput (424k vs 377k Mseams*px/s), but every kernel then shares the chip -- a carve
 // launch of 16 images takes 0.20 ms next to the others' kernels (2.6 TB/s algorithmic) instead of 0.13 ms alone -- and
 // it needs a hardware queue per stream: with the HIP runtime's default of 4 queues per process (GPU_MAX_HW_QUEUES) the
-// streams share queues and the same split is 30 % SLOWER.  So it is opt-in: lqrhip_set_sub_batches (bench.py
-// --sub-batches), default one stream.  DESIGN.md 4.11.
+// streams share queues and the same split is 30 % SLOWER.  lqrhip_set_sub_batches (bench.py --sub-batches) pins the
+// number of streams; the default is automatic (lqrhip_sub_batches below).  DESIGN.md 4.11.
 static int g_sub_batches = 0;           // 0: automatic (below)
 extern "C" void lqrhip_set_sub_batches(int n) { g_sub_batches = n > 0 ? n : 0; }
 // Streams a lock-step group of n carvers is split over.  Automatic: 4 for groups of 32 and more WHEN the process has the
@@ -3496,9 +3250,6 @@ extern "C" void lqrhip_batch_destroy(LqrHipBatch *b)
     if (!b) return;
     g_live_batches.erase(std::remove(g_live_batches.begin(), g_live_batches.end(), b), g_live_batches.end());
     if (b->stream) { (void) hipStreamSynchronize(b->stream); (void) hipStreamDestroy(b->stream); }
-    if (b->stream_w) { (void) hipStreamSynchronize(b->stream_w); (void) hipStreamDestroy(b->stream_w); }
-    if (b->ev_seam) (void) hipEventDestroy(b->ev_seam);
-    if (b->ev_work) (void) hipEventDestroy(b->ev_work);
     dfree(b->exch);
     for (auto *c : b->cs) if (c->batch == b) c->batch = nullptr;
     if (b->d_desc) (void) hipFree(b->d_desc);
@@ -3517,7 +3268,7 @@ static DevCarver make_desc(const LqrHipCarver *c)
     DevCarver d;
     d.rgb0 = c->rgb0; d.vs = c->vs; d.bias0 = c->bias0; d.rig0 = c->rig0;
     d.pix = c->pix; d.en = c->en; d.m = c->m; d.least = c->least; d.m2 = c->m2; d.least2 = c->least2; d.bias = c->bias; d.rig = c->rig;
-    d.seam_x = c->seam_x; d.seam_log = c->seam_log; d.flags = c->flags; d.patch = c->patch;
+    d.seam_x = c->seam_x; d.seam_log = c->seam_log; d.flags = c->flags;
     return d;
 }
 
@@ -3565,13 +3316,6 @@ struct ProfScope {
 
 extern "C" void lqrhip_prof_enable(int on) { g_prof = on; }
 static int g_update_mode = -1;
-// wherever k_band_update_tw would run -- 0 (default): k_carve, k_emap_update, k_band_update_tw; 1: k_seam_work (carve + energy
-// update, publishing its progress) then k_band_update_tw_f on the batch's stream; 2: the two on two streams, side by side;
-// 3: k_emap_update<PATCH> + k_carve_pub on the second stream, k_band_update_tw_f next to them on the batch's.
-// 1, 2 and 3 are parity-green and SLOWER (64 x 4K: 391 k / 396 k / 392 k against 540 k), so
-// they stay opt-in: lqrhip_set_fused, or LQRHIP_FUSED in the environment.
-static int g_fused = getenv("LQRHIP_FUSED") ? atoi(getenv("LQRHIP_FUSED")) : 0;
-extern "C" void lqrhip_set_fused(int mode) { g_fused = mode; }
 // -1: by batch size (g_tiled_update_px); 0: band kernel (k_band_update_tw); 1: tiled full-width update whenever its
 // grid fits; 2: the per-row-barrier band kernel (k_band_update_mw); 3: the generic one-wave band kernel + sweep
 // (what delta_x > 2 runs on), whatever the parameters
@@ -3910,83 +3654,6 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     const int move_dp = (wnew > 1 && !full_rebuild) ? 1 : 0;
     bool has_rigmask = false;
     for (auto *c : b->cs) has_rigmask |= (c->rig != nullptr);
-    // One launch for carve + energy update + band update (k_seam_fused) wherever the trapezoid-wave band kernel would run
-    // (the conditions below restate the dispatch further down) and the energy's reach is the builtin gradients' one row
-    {
-        const bool rigm0 = has_rigmask && p->use_rigidity;
-        const bool fast0 = p->delta_x == 1 && !rigm0 && g_update_mode != 3;
-        const bool tiled0 = fast0 && (g_update_mode < 0 ? (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px : g_update_mode == 1) && dp_persistent_ok(b, w);
-        const bool tw0 = fast0 && !tiled0 && (size_t) h * sizeof(int) <= 60 * 1024 && g_update_mode != 2 && wnew <= 4200 && (size_t) 2 * h * sizeof(int) <= 64 * 1024;
-        bool fused = g_fused && move_dp && tw0 && k.radius <= 1;
-#ifdef LQR_BAND_EXPERIMENTS
-        fused = fused && g_band_kernel == 0;
-#endif
-        if (fused) {
-            const int lag_max = n <= 4 ? FROZEN_LAG_MAX / 4 : FROZEN_LAG_MAX;
-            if (log_index + 1 - c0->frozen_epoch > lag_max && (rc = frozen_catchup(b, log_index + 1, wnew, h))) return rc;
-            const int epoch = c0->frozen_epoch;
-            b->fuse_tag = b->fuse_tag % 0x3fffffff + 1;                 // never 0 (the chunk words start cleared)
-            const int nchunks = (h + SF_RW - 1) / SF_RW;
-            const bool two = g_fused >= 2, pub = g_fused == 3;
-            if (pub) {
-                // the patch planes, allocated with the first such launch
-                bool grew = false;
-                for (auto *c : b->cs)
-                    if (!c->patch) {
-                        if (!grew) { HIPCK(hipStreamSynchronize(b->stream)); grew = true; }
-                        if ((rc = dmalloc(&c->patch, (size_t) c->wk_h * PATCH_DW + 64))) return rc;
-                    }
-                if (grew) { b->dirty = true; if ((rc = batch_upload(b))) return rc; }
-            }
-            if (two && !b->stream_w) {
-                HIPCK(hipStreamCreateWithFlags(&b->stream_w, hipStreamNonBlocking));
-                HIPCK(hipEventCreateWithFlags(&b->ev_seam, hipEventDisableTiming));
-                HIPCK(hipEventCreateWithFlags(&b->ev_work, hipEventDisableTiming));
-            }
-            hipStream_t sw = two ? b->stream_w : b->stream;
-            if (two) {
-                // the workers start when the seam is there (k_vpath* on the batch's stream) ...
-                HIPCK(hipEventRecord(b->ev_seam, b->stream));
-                HIPCK(hipStreamWaitEvent(sw, b->ev_seam, 0));
-            }
-            if (pub) {
-                // the energies first, into the rows' patches (they need the seam, not the carved planes) ...
-                {
-                    ProfScope ps("emap_update", sw, 0);
-#define LAUNCH_EPATCH(N) hipLaunchKernelGGL((k_emap_update<N, 12, true>), dim3((h + EU_ROWS - 1) / EU_ROWS, n), dim3(64), 0, sw, b->d_desc, k, wnew, h, stride, log_index, epoch)
-                    NRG_DISPATCH(p->nrg_func, LAUNCH_EPATCH)
-#undef LAUNCH_EPATCH
-                }
-                // ... then the carve that applies them and announces its rows
-                ProfScope ps("carve", sw, 4.0 * (double) w * h * n);
-                hipLaunchKernelGGL(k_carve_pub, dim3((h + 3) / 4, n), dim3(256), 0, sw, b->d_desc, w, h, stride, p->delta_x, b->fuse_tag);
-            } else {
-                // "carve": the roofline kernel's scope -- the launch that contains the carve (bench.py names the kernel)
-                ProfScope ps("carve", sw, 4.0 * (double) w * h * n);
-#define LAUNCH_WORK(N) hipLaunchKernelGGL((k_seam_work<N>), dim3(n, nchunks), dim3(512), 0, sw, b->d_desc, k, w, h, stride, log_index, epoch, b->fuse_tag)
-                NRG_DISPATCH(p->nrg_func, LAUNCH_WORK)
-#undef LAUNCH_WORK
-            }
-            if (two) HIPCK(hipEventRecord(b->ev_work, sw));
-            {
-                // ... the band update right away, next to them (two streams) or behind them (one)
-                ProfScope ps("band_update", b->stream, 0);
-#define LAUNCH_TWF(LRV, RIGV) hipLaunchKernelGGL((k_band_update_tw_f<4, LRV, RIGV>), dim3(n), dim3(128 * 4), (size_t) 2 * h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, g_dev_err, b->fuse_tag)
-                if (leftright_next) { if (p->use_rigidity) LAUNCH_TWF(true, true); else LAUNCH_TWF(true, false); }
-                else { if (p->use_rigidity) LAUNCH_TWF(false, true); else LAUNCH_TWF(false, false); }
-#undef LAUNCH_TWF
-            }
-            // ... and whatever follows on the batch's stream (the sweep over handed-over rows, the next seam) after both
-            if (two) HIPCK(hipStreamWaitEvent(b->stream, b->ev_work, 0));
-        }
-        if (fused) {
-            // rows the band kernel handed over (flags[FLAG_OVF_ROW] .. h): the keep rule over the full width
-            ProfScope ps("dp_update", b->stream, 0);
-            if ((rc = launch_dp<true>(b, k, wnew, h, leftright_next))) return rc;
-            HIPCK(hipGetLastError());
-            return 0;
-        }
-    }
     {
         // algorithmic bytes of one carve launch: read + write of one 4-byte
         // plane over the half of each row right of the seam = 8 B * w*h/2 per image

@@ -81,6 +81,7 @@ struct _LqrCarver {
 
     /* read-out cache: visible image at (w, level), carver orientation */
     guchar *ro_image;
+    size_t ro_image_len;
     int ro_valid, ro_line;
     guchar *ro_buffer;          /* one line, the pointer scan_line hands out */
     int ro_buffer_len;
@@ -649,8 +650,11 @@ static LqrRetVal group_resize(LqrCarver **rs, int n, int w1, int h1)
     } else {
         if ((ret = group_resize_dir(&g, h1, 1)) == LQR_OK) ret = group_resize_dir(&g, w1, 0);
     }
-    if (ret == LQR_OK) { int k; for (k = 0; k < g.nb && ret == LQR_OK; k++) ret = hip_ret(lqrhip_batch_sync(g.b[k])); }
-    else { int k; for (k = 0; k < g.nb; k++) lqrhip_batch_abort(g.b[k]); }      /* nothing of this resize may surface in the next one */
+    if (ret == LQR_OK) {        /* every sub-batch is synchronised, whatever the others returned */
+        int k;
+        for (k = 0; k < g.nb; k++) { LqrRetVal rk = hip_ret(lqrhip_batch_sync(g.b[k])); if (ret == LQR_OK) ret = rk; }
+    }
+    if (ret != LQR_OK) { int k; for (k = 0; k < g.nb; k++) lqrhip_batch_abort(g.b[k]); }      /* nothing of this resize may surface in the next one */
     FOR_TREE(&g, i, r, { r->ro_valid = 0; r->ro_line = 0; });
     group_close(&g);
     return ret;
@@ -673,9 +677,12 @@ static LqrRetVal fetch_visible(LqrCarver *r)
 {
     size_t n = (size_t) r->w * r->h * r->channels;
     if (r->ro_valid) return LQR_OK;
-    free(r->ro_image);
-    r->ro_image = (guchar *) malloc(n ? n : 1);
-    if (!r->ro_image) return LQR_NOMEM;
+    if (!r->ro_image || r->ro_image_len < n) {       /* kept across read-outs: a fresh block costs a page fault per 4 KiB */
+        free(r->ro_image);
+        r->ro_image = (guchar *) malloc(n ? n : 1);
+        if (!r->ro_image) { r->ro_image_len = 0; return LQR_NOMEM; }
+        r->ro_image_len = n;
+    }
     HIP_CATCH(lqrhip_read_visible(r->dev, r->w0, r->h0, r->w, r->level, r->ro_image));
     if (r->ro_buffer_len < r->w * r->channels) {
         free(r->ro_buffer);
@@ -707,6 +714,10 @@ gboolean lqr_carver_scan_line(LqrCarver *r, gint *n, guchar **rgb)
 LqrRetVal lqrx_carver_read_image(LqrCarver *r, guchar *out)
 {
     int x, y, ch = r->channels;
+    if (!r->transposed && !r->ro_valid) {      /* straight into the caller's buffer: no second host copy */
+        HIP_CATCH(lqrhip_read_visible(r->dev, r->w0, r->h0, r->w, r->level, out));
+        return LQR_OK;
+    }
     LQR_CATCH(fetch_visible(r));
     if (!r->transposed) {
         memcpy(out, r->ro_image, (size_t) r->w * r->h * ch);

@@ -166,12 +166,6 @@ void lqrhip_prof_enable(int on);
  * 2 the per-row-barrier band kernel k_band_update_mw (the default for rows wider than 4200 px), 3 the generic
  * one-wave band kernel k_band_update + k_dp_sweep (what delta_x > 2 runs on) whatever the parameters */
 void lqrhip_set_update_mode(int mode);
-/* Where k_band_update_tw would run: 0 (default) k_carve, k_emap_update, k_band_update_tw as three launches; 1 carve + energy
- * update as one launch that publishes its progress row chunk by row chunk (k_seam_work), then the band update on the same
- * stream; 2 the two on two streams of the batch, the band update starting while rows are still being carved; 3 the energy
- * update first (into per-row patches), then a k_carve that applies them and announces its rows, next to the band update.
- * 1, 2 and 3 are bit-identical and slower; LQRHIP_FUSED in the environment sets the initial value. */
-void lqrhip_set_fused(int mode);
 /* Cap on the workgroups of the persistent tiled DP sweep (k_dp_tile_p), whose tiles spin on their neighbours and
  * must all be resident: -1 = the bound derived from the occupancy query at lqrhip_init, n >= 0 = min(n, that bound).
  * Grids above the cap run as k_dp_tile (one launch per 32 rows).  0 forces that path (tests). */

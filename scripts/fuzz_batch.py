@@ -23,7 +23,7 @@ rng = np.random.default_rng(seed)
 o = L.oracle_api()
 e = L.engine_api()
 lib = e.lib
-for f in ("lqrhip_set_update_mode", "lqrhip_set_sub_batches", "lqrhip_set_fused"):
+for f in ("lqrhip_set_update_mode", "lqrhip_set_sub_batches"):
     getattr(lib, f).argtypes = [ctypes.c_int]
 t_end = time.time() + budget
 n = fails = 0
@@ -49,9 +49,8 @@ while time.time() < t_end and not (max_cases and n >= max_cases):
     masks = rng.random() < 0.2
     mode = int(rng.choice([-1, 0, 1, 2]))
     sub = int(rng.choice([1, 1, 2, 3]))
-    fused = int(rng.choice([0, 0, 1, 2, 3]))
-    what = "%d x %dx%d ch%d -> %dx%d %s%s mode %d sub %d fused %d" % (nimg, w, h, ch, w + dw, h + dh, kw, " +masks" if masks else "", mode, sub, fused)
-    lib.lqrhip_set_update_mode(mode); lib.lqrhip_set_sub_batches(sub); lib.lqrhip_set_fused(fused)
+    what = "%d x %dx%d ch%d -> %dx%d %s%s mode %d sub %d" % (nimg, w, h, ch, w + dw, h + dh, kw, " +masks" if masks else "", mode, sub)
+    lib.lqrhip_set_update_mode(mode); lib.lqrhip_set_sub_batches(sub)
     mk = dict(pres=D.ellipse_mask(w, h), disc=D.band_mask(w, h, w // 5, w // 3)) if masks else {}
     try:
         cs = [H.init_carver(e, im, w + dw, h + dh, **kw, **mk)[0] for im in imgs]
@@ -67,6 +66,6 @@ while time.time() < t_end and not (max_cases and n >= max_cases):
         fails += 1
         print("FAIL case %d" % n, what, str(ex)[:160], flush=True)
     n += 1
-lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_sub_batches(0); lib.lqrhip_set_fused(0)
+lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_sub_batches(0)
 print("batch fuzz: %d cases, %d failures, seed %d" % (n, fails, seed), flush=True)
 sys.exit(1 if fails else 0)
