@@ -9,7 +9,7 @@ eng = L.engine_api()
 lib = eng.lib
 n, W, H = int(sys.argv[1]) if len(sys.argv) > 1 else 64, 3840, 2160
 imgs = [np.random.default_rng(i).integers(0, 256, (H, W, 4), dtype=np.uint8) for i in range(4)]
-for rnd in range(3):
+for rnd in range(6):
     bufs = [L._malloc_copy(imgs[i % 4]) for i in range(n)]
     lib.lqrhip_device_sync()
     t0 = time.perf_counter()
