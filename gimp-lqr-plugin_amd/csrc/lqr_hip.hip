@@ -1780,459 +1780,8 @@ __device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const D
                                              // a second one makes the register allocator spill the staging rows)
         if (!fits) {
             if (just_rebased || (hi - lo + 1 + 2 * R + 8 > WIN && WIN < w)) { ovf = y; break; }
-            int nb = (((lo + hi) >> 1) - WIN / 2) & ~3;        // (placing the changes inside ONE slot instead of on the middle slots' boundary
-                                                               //  measured no gain: 621-630 us against 640, round 4)
-            nb = max(0, min(nb, (w - WIN + 3) & ~3));
-            B = __builtin_amdgcn_readfirstlane(nb);
-            have_window = true;
-            // the first and last slot must stay clean for the next R rows (same test as at the batch
-            // boundaries below); if even the re-centred window cannot promise that, hand over
-            const bool left_ok = (B == 0) || (lo - (R + 2) >= B + SLOT);
-            const bool right_ok = (B + WIN >= w) || (hi + (R + 2) < B + WIN - SLOT);
-            if (!(left_ok && right_ok)) { ovf = y; break; }
-        }
-        const int x0 = B + SLOT * wave + PXL * lane;          // first pixel of this lane
-        const int sx0 = B + SLOT * wave;                      // first pixel of this wave's slot
-        const unsigned lo_off = (unsigned) min(x0, stride - PXL);
-        const bool in_img = x0 < w;
-        // pixels this lane may recompute: inside the image, and not the first / last pixel of a
-        // window that does not end at the image border (their outer neighbour is not in the window;
-        // the window is re-centred long before a change can reach them)
-        uint32_t okmask = 0;
-#pragma unroll
-        for (int k = 0; k < PXL; k++) {
-            const int x = x0 + k;
-            const bool ok = (x < w) && !(B > 0 && x == B) && !(B + WIN < w && x == B + WIN - 1);
-            okmask |= ok ? (1u << k) : 0u;
-        }
-
-        // previous row: rows < y were stored by this workgroup -> make them visible, then load
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        float mp[PXL];
-        int par = 0;
-        {
-            gf32 *mrow = c.m + (size_t) (y - 1) * stride;
-#pragma unroll
-            for (int k = 0; k < PXL; k++)
-                mp[k] = (x0 + k < w) ? __hip_atomic_load(mrow + x0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
-            // after a re-base every slot is recomputed once (cheap, and trivially a superset); bit 2
-            // (really dirty) stays clear so that the window check below sees only real changes
-            if (lane == 0) { s_edge[par][wave + 1].first_val = mp[0]; s_edge[par][wave + 1].flags = 3; }
-            if (lane == 63) s_edge[par][wave + 1].last_val = mp[PXL - 1];
-        }
-        int own_dirty = 1;
-        __syncthreads();
-
-        FV q_mo[2][R], q_e[2][R];
-        LV q_lo[2][R];
-        auto issue = [&](int buf, int ybase) {           // one batch of R rows, unconditional
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const unsigned ro = (unsigned) min(ybase + r, h - 1) * (unsigned) stride + lo_off;
-                q_mo[buf][r] = *(const GFV *) (c.m + ro);
-                q_e[buf][r] = *(const GFV *) (c.en + ro);
-                q_lo[buf][r] = *(const GLV *) (c.least + ro);
-            }
-        };
-        issue(0, y);
-
-        bool rebase = false;
-        while (y < h && !rebase) {
-#pragma unroll
-            for (int buf = 0; buf < 2; buf++) {
-                if (y < h && !rebase) {
-                    // ---- batch boundary: does the window still hold the next R rows?
-                    {
-                        const BandEdge ef = s_edge[par][1], el = s_edge[par][NW];
-                        const int t = s_touch[y];
-                        const int t0 = (t & 0xffff) - (R + 2), t1 = (t >> 16) + (R + 2);
-                        const bool left_ok = (B == 0) || (!(ef.flags & 4) && t0 >= B + SLOT);
-                        const bool right_ok = (B + WIN >= w) || (!(el.flags & 4) && t1 < B + WIN - SLOT);
-                        rebase = !(left_ok && right_ok);
-                    }
-                    if (rebase) {
-                        // dirty slot range of the last finished row, for the re-centring
-                        int lo = -1, hi = -1;
-                        for (int v = 0; v < NW; v++)
-                            if (s_edge[par][v + 1].flags & 4) { if (lo < 0) lo = v; hi = v; }
-                        dirty_lo = __builtin_amdgcn_readfirstlane(lo);
-                        dirty_hi = __builtin_amdgcn_readfirstlane(hi);
-                    } else {
-                        issue(buf ^ 1, y + R);            // next batch in flight while this one is processed
-#pragma unroll
-                        for (int r = 0; r < R; r++) {
-                            if (y < h) {
-                                // what the neighbours published about row y-1
-                                const BandEdge eL = s_edge[par][wave], eR = s_edge[par][wave + 2];
-                                const int t = s_touch[y];
-                                // no short-circuit: all LDS reads of the row are issued together (one round trip)
-                                const int touch = (int) ((t & 0xffff) <= sx0 + SLOT - 1) & (int) ((t >> 16) >= sx0);
-                                const bool active = (own_dirty | (eL.flags & 2) | (eR.flags & 1) | touch) != 0;
-                                float mo[PXL], e[PXL], mc[PXL];
-                                const uint32_t lo4 = (uint32_t) q_lo[buf][r];
-#pragma unroll
-                                for (int k = 0; k < PXL; k++) { mo[k] = q_mo[buf][r][k]; e[k] = q_e[buf][r][k]; }
-#pragma unroll
-                                for (int k = 0; k < PXL; k++) mc[k] = (x0 + k < w) ? mo[k] : INF;
-                                int flags = 0;
-                                if (active) {
-                                    float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(eL.last_val), __float_as_int(mp[PXL - 1]),
-                                                                                        DPP_WAVE_SHR1, 0xf, 0xf, false));
-                                    float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(eR.first_val), __float_as_int(mp[0]),
-                                                                                         DPP_WAVE_SHL1, 0xf, 0xf, false));
-                                    left = (x0 == 0) ? INF : left;
-                                    uint32_t lnew = 0;
-                                    unsigned long long any = 0ull, chg_first = 0ull, chg_last = 0ull;
-#pragma unroll
-                                    for (int k = 0; k < PXL; k++) {
-                                        float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
-                                        const float cc = mp[k];
-                                        float rr = (k == PXL - 1) ? right : mp[k < PXL - 1 ? k + 1 : 0];
-                                        if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
-                                        // ascending scan with strict < (LR=0: the leftmost minimum wins) or <=
-                                        // (LR=1: the rightmost); missing neighbours are +inf.  Written as value
-                                        // selects only (no scalar mask arithmetic on the dependency chain).
-                                        const float best = fminf(fminf(l, cc), rr);
-                                        int bdx;
-                                        if (LR) { bdx = (cc == best) ? 0 : -1; bdx = (rr == best) ? 1 : bdx; }
-                                        else { bdx = (cc == best) ? 0 : 1; bdx = (l == best) ? -1 : bdx; }
-                                        const float nm = __fadd_rn(e[k], best);
-                                        const int lo_k = (int) (int8_t) (lo4 >> (8 * k));
-                                        // keep rule: same parent and (double) fabsf(d) < 1e-5, i.e. fabsf(d) <= 1e-5f
-                                        float d = fabsf(__fsub_rn(mo[k], nm));
-                                        d = (lo_k == bdx) ? d : INF;                 // parent changed: never "stop"
-                                        d = ((okmask >> k) & 1) ? d : 0.0f;          // pixel not ours to recompute: never changes
-                                        const bool ch = d > 1e-5f;
-                                        mc[k] = ch ? nm : mc[k];
-                                        const int outl = ((okmask >> k) & 1) ? bdx : lo_k;
-                                        lnew |= ((uint32_t) outl & 0xffu) << (8 * k);
-                                        const unsigned long long bk = __ballot(ch);
-                                        any |= bk;
-                                        if (k == 0) chg_first = bk;
-                                        if (k == PXL - 1) chg_last = bk;
-                                    }
-                                    flags = (int) (chg_first & 1ull) | ((int) (chg_last >> 63) << 1) | (any ? 4 : 0);
-                                    // lanes outside the image write to a scratch row
-                                    const unsigned so = in_img ? (unsigned) y * (unsigned) stride + (unsigned) x0 : dummy;
-                                    FV tv;
-#pragma unroll
-                                    for (int k = 0; k < PXL; k++) tv[k] = mc[k];
-                                    *(GFV *) (c.m + so) = tv;
-                                    *(GLV *) (c.least + so) = (LV) lnew;
-                                }
-                                own_dirty = flags & 4;
-                                par ^= 1;
-                                if (lane == 0) { s_edge[par][wave + 1].first_val = mc[0]; s_edge[par][wave + 1].flags = flags; }
-                                if (lane == 63) s_edge[par][wave + 1].last_val = mc[PXL - 1];
-#pragma unroll
-                                for (int k = 0; k < PXL; k++) mp[k] = mc[k];
-                                // one barrier per row: LDS only (outstanding global loads/stores keep flying)
-                                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                                y++;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (tid == 0) c.flags[FLAG_OVF_ROW] = ovf;
-}
-
-// ---------------------------------------------------------------------------
-// One DP row for a lane's 4 consecutive pixels (shared by the halo kernels below): E5's
-// recurrence and, with UPDATE, E9's keep-rule.  mp = the row above (this lane's pixels), left /
-// right = its neighbours' adjacent pixels.  Everything on the row's dependency chain is VALU:
-// the back pointer is produced directly as a byte in place ((dx & 0xff) << 8k: two selects of
-// constants), the four are OR-ed, and "same parent as before" is a byte compare of old ^ new.
-// MASK: some of the lane's pixels may lie outside the image (they become +inf).
-// left / right come by DPP wave shifts with bound_ctrl: lane 0's left and lane 63's right neighbour read as 0.  In the
-// halo kernels those two lanes are the outermost halo columns, whose values are allowed to be wrong from the first row
-// of a block on (the error moves inwards one column per row, which is what the halo width pays for), so no register has
-// to be preset with +inf for them; the image's own borders are handled by MASK, not by the shift.
-// ch[k] (UPDATE): the pixel's (m, back pointer) pair changed.
-// ---------------------------------------------------------------------------
-template <bool LR, bool RIG, bool UPDATE, bool MASK>
-__device__ __forceinline__ void dp_row4(const float (&mp)[4], const float left, const float right, const f32x4 e, const f32x4 mo, const uint32_t lo4,
-                                        const bool (&in)[4], const float rig_l, const float rig_r, float (&mc)[4], uint32_t &lnew, bool (&ch)[4])
-{
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const float INF = __int_as_float(0x7f800000);
-    float best[4];
-    uint32_t sel[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
-        const float cc = mp[k];
-        float rr = (k == 3) ? right : mp[k < 3 ? k + 1 : 0];
-        if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
-        // ascending scan with strict < (LR=0: the leftmost minimum wins) or <= (LR=1: the rightmost)
-        best[k] = fminf(fminf(l, cc), rr);
-        const uint32_t minus = 0xffu << (8 * k), plus = 0x01u << (8 * k);
-        if (LR) { sel[k] = (cc == best[k]) ? 0u : minus; sel[k] = (rr == best[k]) ? plus : sel[k]; }
-        else { sel[k] = (cc == best[k]) ? 0u : plus; sel[k] = (l == best[k]) ? minus : sel[k]; }
-    }
-    // the four sums and the four differences as two packed operations each on the pixel pairs (0, 1) and (2, 3): e and mo
-    // sit in aligned register pairs as loaded, so v_pk_add_f32 takes them where they are (left to itself the compiler pairs
-    // pixels 1 and 2 and pays four v_mov per row for it).  Individually rounded IEEE adds, as __fadd_rn / __fsub_rn.
-    const f32x2 nm01 = (f32x2) {e[0], e[1]} + (f32x2) {best[0], best[1]}, nm23 = (f32x2) {e[2], e[3]} + (f32x2) {best[2], best[3]};
-    const float nm[4] = {nm01[0], nm01[1], nm23[0], nm23[1]};
-    lnew = (sel[0] | sel[1]) | (sel[2] | sel[3]);
-    if (UPDATE) {
-        const uint32_t diff = lo4 ^ lnew;
-        const f32x2 d01 = (f32x2) {mo[0], mo[1]} - nm01, d23 = (f32x2) {mo[2], mo[3]} - nm23;
-        const float dd[4] = {d01[0], d01[1], d23[0], d23[1]};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            // keep the stale value iff same parent and (double) fabsf(d) < 1e-5, i.e. fabsf(d) <= 1e-5f
-            float d = fabsf(dd[k]);
-            d = ((diff >> (8 * k)) & 0xffu) ? INF : d;
-            ch[k] = d > 1e-5f;
-            const float v = ch[k] ? nm[k] : mo[k];
-            mc[k] = (!MASK || in[k]) ? v : INF;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) mc[k] = (!MASK || in[k]) ? nm[k] : INF;
-    }
-}
-
-// dp_row4's arithmetic for PX (2 or 4) consecutive pixels per lane; lo / lnew hold PX back-pointer bytes.  With 2 pixels
-// per lane a row is ~33 instructions per wave instead of ~58, and twice as many waves cover the columns.
-template <int PX, bool LR, bool RIG, bool UPDATE, bool MASK>
-__device__ __forceinline__ void dp_row(const float (&mp)[PX], const float left, const float right, const float (&e)[PX], const float (&mo)[PX],
-                                       const uint32_t lo, const bool (&in)[PX], const float rig_l, const float rig_r, float (&mc)[PX],
-                                       uint32_t &lnew, bool (&ch)[PX])
-{
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    static_assert(PX % 2 == 0, "pixel pairs");
-    const float INF = __int_as_float(0x7f800000);
-    float best[PX], nm[PX], dd[PX];
-    uint32_t sel[PX];
-#pragma unroll
-    for (int k = 0; k < PX; k++) {
-        float l = (k == 0) ? left : mp[k > 0 ? k - 1 : 0];
-        const float cc = mp[k];
-        float rr = (k == PX - 1) ? right : mp[k < PX - 1 ? k + 1 : 0];
-        if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
-        best[k] = fminf(fminf(l, cc), rr);
-        const uint32_t minus = 0xffu << (8 * k), plus = 0x01u << (8 * k);
-        if (LR) { sel[k] = (cc == best[k]) ? 0u : minus; sel[k] = (rr == best[k]) ? plus : sel[k]; }
-        else { sel[k] = (cc == best[k]) ? 0u : plus; sel[k] = (l == best[k]) ? minus : sel[k]; }
-    }
-    // sums and differences as packed operations on the pixel pairs (2j, 2j + 1), as dp_row4
-#pragma unroll
-    for (int j = 0; j < PX / 2; j++) {
-        const f32x2 s2 = (f32x2) {e[2 * j], e[2 * j + 1]} + (f32x2) {best[2 * j], best[2 * j + 1]};
-        nm[2 * j] = s2[0]; nm[2 * j + 1] = s2[1];
-        if (UPDATE) {
-            const f32x2 d2 = (f32x2) {mo[2 * j], mo[2 * j + 1]} - s2;
-            dd[2 * j] = d2[0]; dd[2 * j + 1] = d2[1];
-        }
-    }
-    lnew = sel[0];
-#pragma unroll
-    for (int k = 1; k < PX; k++) lnew |= sel[k];
-    const uint32_t diff = lo ^ lnew;
-#pragma unroll
-    for (int k = 0; k < PX; k++) {
-        float v = nm[k];
-        if (UPDATE) {
-            // keep the stale value iff same parent and (double) fabsf(d) < 1e-5, i.e. fabsf(d) <= 1e-5f
-            float d = fabsf(dd[k]);
-            d = ((diff >> (8 * k)) & 0xffu) ? INF : d;
-            ch[k] = d > 1e-5f;
-            v = ch[k] ? v : mo[k];
-        }
-        mc[k] = (!MASK || in[k]) ? v : INF;
-    }
-}
-// The same row for delta_x = DELTA (2 * DELTA + 1 candidate parents) and / or with a rigidity mask (RIGM: the rigidity
-// term of pixel k is rf[k] * rg[dx + DELTA], liblqr's rigidity_mask * rigidity_map).  nl[i] / nr[i]: the row above at the
-// lane's first pixel - 1 - i / last pixel + 1 + i.  The parent is found by liblqr's ascending scan dx = -DELTA .. DELTA
-// with strict < (LR = 0: the leftmost minimum wins) or <= (LR = 1: the rightmost), written as compare-and-select;
-// candidates outside the image are +inf and never win against the pixel straight above.  As in the delta_x = 1 rows the
-// rigidity term of dx = 0 (zero by construction of the table) is not added.
-template <int PX, int DELTA, bool LR, bool RIG, bool RIGM, bool UPDATE, bool MASK>
-__device__ __forceinline__ void dp_row_g(const float (&mp)[PX], const float (&nl)[DELTA], const float (&nr)[DELTA], const float (&e)[PX],
-                                         const float (&mo)[PX], const uint32_t lo, const bool (&in)[PX], const float (&rg)[2 * DELTA + 1],
-                                         const float (&rf)[PX], float (&mc)[PX], uint32_t &lnew, bool (&ch)[PX])
-{
-    static_assert(DELTA <= PX, "the neighbouring lane holds the whole reach");
-    const float INF = __int_as_float(0x7f800000);
-    float nm[PX];
-    lnew = 0;
-#pragma unroll
-    for (int k = 0; k < PX; k++) {
-        float best = 0.0f;
-        int bdx = 0;
-#pragma unroll
-        for (int dx = -DELTA; dx <= DELTA; dx++) {
-            const int j = k + dx;
-            float v = j < 0 ? nl[j < 0 ? -j - 1 : 0] : j >= PX ? nr[j >= PX ? j - PX : 0] : mp[j >= 0 && j < PX ? j : 0];
-            if (RIG && dx != 0) v = __fadd_rn(v, RIGM ? __fmul_rn(rf[k], rg[dx + DELTA]) : rg[dx + DELTA]);
-            if (dx == -DELTA) { best = v; bdx = dx; }
-            else {
-                const bool take = LR ? (v <= best) : (v < best);
-                best = take ? v : best;
-                bdx = take ? dx : bdx;
-            }
-        }
-        nm[k] = __fadd_rn(e[k], best);
-        lnew |= ((uint32_t) bdx & 0xffu) << (8 * k);
-    }
-    const uint32_t diff = lo ^ lnew;
-#pragma unroll
-    for (int k = 0; k < PX; k++) {
-        float v = nm[k];
-        if (UPDATE) {
-            float d = fabsf(__fsub_rn(mo[k], v));
-            d = ((diff >> (8 * k)) & 0xffu) ? INF : d;
-            ch[k] = d > 1e-5f;
-            v = ch[k] ? v : mo[k];
-        }
-        mc[k] = (!MASK || in[k]) ? v : INF;
-    }
-}
-// PX floats / PX back-pointer bytes of one lane, as one load or store
-template <int PX> struct LaneVec;
-template <> struct LaneVec<2> { typedef float F __attribute__((ext_vector_type(2))); typedef uint16_t L; };
-template <> struct LaneVec<4> { typedef f32x4 F; typedef uint32_t L; };
-
-// ---------------------------------------------------------------------------
-// E9 update_mmap, band form, "trapezoid waves" (delta_x == 1, no rigidity mask).
-//
-// k_band_update_mw pays one s_barrier and one LDS exchange per ROW (~0.49 us per row, of which the
-// recompute itself is a third).  Here the waves of a window exchange once per BATCH of 16 rows:
-// a slot is 256 columns (4 px per lane) of which the middle 224 are its own and 16 on each side
-// are halo, recomputed redundantly from the same inputs as the neighbouring slot does -- after r
-// rows the outer r halo columns are wrong, the own columns never are.  At a batch boundary every
-// slot leaves the last row of its own columns in LDS (s_row) and picks up own + halo from there.
-// Each slot is served by two waves that take turns batch by batch (as in k_dp_tile_p): while one
-// computes, the other's 48 loads for the next batch are in flight.
-//
-// In place: a slot's halo columns are its neighbour's own columns, which the neighbour overwrites.
-// A wave therefore waits for its prefetched batch BEFORE the barrier that opens that batch; nobody
-// stores rows of a batch before that barrier.
-//
-// As in k_band_update_mw there is no band bookkeeping (section 4.4: any superset of the pixels with
-// changed inputs gives liblqr's memory): a slot recomputes a batch iff the pixels changed on the
-// row above the batch, or touched by the carve on the batch's rows, are within 16 columns of it.
-// The window (NW slots) is re-centred when those pixels come within 16 columns of its ends; if
-// they do not fit the kernel records the row in flags[FLAG_OVF_ROW] and the full-width sweep
-// finishes from there.
-// ---------------------------------------------------------------------------
-constexpr int TW_R = 16;                     // rows per batch = halo columns
-constexpr int TW_OWN = 256 - 2 * TW_R;       // own columns per slot
-// Within an active slot only the lanes near the changes are staged, stored and handed over: pixels further than R
-// columns from the changed ones cannot change during a batch; lanes that were not staged compute garbage, which moves
-// inwards one column per row, so staging reaches R (kept lanes) + R (rows) + 8 (a kept lane's own four columns, slack).
-// A vector-memory instruction costs the CU's memory path ~12 + 0.7 cycles per ACTIVE lane (scripts/dbg/t_ta.hip),
-// and that path is this kernel's bound.
-constexpr int TW_LANE_MARGIN = 2 * TW_R + 8;
-
-template <int NW, bool LR, bool RIG>
-__device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const DpK &p, int w, int h, int stride, int *dev_err)
-{
-    constexpr int R = TW_R, OWN = TW_OWN, WIN = NW * OWN, NT = 128 * NW;
-    const GCarver c = gview(dc);
-    extern __shared__ int s_tw[];                          // [2h]: per row, per batch-starting-at-row touch ranges
-    int *s_touch = s_tw, *s_touchR = s_tw + h;
-    // m of the last finished row over [B-R, B+WIN+R), double-buffered by batch parity: a slot reads its halo
-    // (the neighbours' own columns) at the start of a batch, and a neighbour that is a whole batch faster
-    // must not have overwritten them yet
-    __shared__ __attribute__((aligned(16))) float s_row[2][WIN + 2 * R];
-    __shared__ int s_rec[2][NW][2];                        // [batch parity][slot] {lo, hi}: px changed on that row (lo > hi: none)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slot = wv % NW, par_w = wv / NW;             // the two waves of a slot sit on the same SIMD
-    const float INF = __int_as_float(0x7f800000);
-    const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
-
-    // pixels of row y whose inputs the carve changed (see k_band_update_mw), then the union over the
-    // 16 rows of a batch starting at y
-    for (int y = tid; y < h; y += NT) {
-        const int v0 = c.seam_x[y], vm = c.seam_x[max(y - 1, 0)], vp = c.seam_x[min(y + 1, h - 1)];
-        const int t0 = max(min(min(v0, vm), vp) - 2, 0), t1 = min(max(max(v0, vm), vp) + 1, w - 1);
-        s_touch[y] = t0 | (t1 << 16);
-    }
-    {   // row 0: m = en on liblqr's interval
-        const int v0 = c.seam_x[0], vp = c.seam_x[min(1, h - 1)];
-        int lo = v0, hi = v0 - 1;
-        if (p.radius) { lo = min(v0, vp) - 1; hi = max(v0, vp); }
-        const int a = max(lo, 0), b = min(hi, w - 1);
-        for (int x = a + tid; x <= b; x += NT) c.m[x] = c.en[x];
-    }
-    __syncthreads();
-    for (int y = tid; y < h; y += NT) {
-        int t0 = 0xffff, t1 = 0;
-        for (int r = 0; r < R; r++) {
-            const int t = s_touch[min(y + r, h - 1)];
-            t0 = min(t0, t & 0xffff); t1 = max(t1, t >> 16);
-        }
-        s_touchR[y] = t0 | (t1 << 16);
-    }
-    __syncthreads();
-    if (h < 2) { if (tid == 0) c.flags[FLAG_OVF_ROW] = h; return; }
-
-    f32x4 q_e[R], q_mo[R];
-    uint32_t q_lo[R];
-    int B = 0;
-    // full = false: the slot cannot become active in that batch (see the prediction at the issue site);
-    // only the row it hands over is needed.  The CU's vector-memory path takes ~16 cycles per 64-lane
-    // 16-byte access, so four slots' 3 loads + 2 stores per row (320 cycles) would be the bound.
-    // Addresses as uniform plane base + 32-bit lane offset (global_load ... v_off, s[base]): per row one scalar
-    // multiply and two VALU adds for the three loads.  With 64-bit per-lane addresses the 48 loads of a batch cost
-    // ~2600 cycles of issue (measured), on the SIMD the partner wave is computing on.
-    auto issue = [&](int ybase, bool full) {        // full: per LANE (see TW_LANE_MARGIN)
-        const int x0 = B + OWN * slot - R + 4 * lane;
-        const unsigned lo_off = (unsigned) min(max(x0, 0), stride - 4);
-        if (full) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const unsigned row = (unsigned) min(ybase + r, h - 1) * (unsigned) stride;
-                const unsigned ro = row + lo_off, ro4 = (row << 2) + (lo_off << 2);
-                q_e[r] = *(const GLOBAL_AS f32x4 *) ((const gu8 *) c.en + ro4);
-                q_mo[r] = *(const GLOBAL_AS f32x4 *) ((const gu8 *) c.m + ro4);
-                q_lo[r] = *(const gu32 *) (c.least + ro);
-            }
-        } else {
-            q_mo[R - 1] = *(const GLOBAL_AS f32x4 *) ((const gu8 *) c.m + ((((unsigned) min(ybase + R - 1, h - 1) * (unsigned) stride) + lo_off) << 2));
-        }
-    };
-    // make the compiler wait for this wave's prefetched batch here
-    auto landed = [&]() {
-#pragma unroll
-        for (int r = 0; r < R; r++) asm volatile("" ::"v"(q_e[r]), "v"(q_mo[r]), "v"(q_lo[r]));
-    };
-
-    int y = 1, ovf = h, kpar = 0;
-    bool loads_full = true;                  // does this wave's staged batch hold all rows (or only the hand-over row)?
-    bool lane_staged = true;                 // ... for this lane (a slot stages only the lanes near the changes)
-    int dlo = 1 << 30, dhi = -1;             // px changed on the last finished row (absolute x)
-    bool have_window = false, force_active = false, just_rebased = false;
-    while (y < h) {
-        // ---- does the window hold the next batch?  (identical decision in every wave)
-        const int t = s_touchR[y];
-        int lo = t & 0xffff, hi = t >> 16;
-        if (dhi >= dlo) { lo = min(lo, dlo - 1); hi = max(hi, dhi + 1); }
-        lo = max(lo, 0); hi = min(hi, w - 1);
-        const bool fits = have_window && (B == 0 || lo - R >= B) && (B + WIN >= w || hi + R <= B + WIN - 1);
-        bool issue_full = true, lane_all = true;     // lane_all: stage every lane (after a re-centring, or nothing known)
-        int plo_l = 0, phi_l = 0;
-        int y_issue = -1;                    // batch this wave prefetches at the end of the iteration (one issue site:
-                                             // a second one makes the register allocator spill the staging rows)
-        if (!fits) {
-            if (just_rebased || (hi - lo + 1 + 2 * R + 8 > WIN && WIN < w)) { ovf = y; break; }
-            // the window is placed so that the changes sit in the middle of ONE slot's own columns (slot 1), not on the boundary
-            // between the two middle slots: a band narrower than a slot then keeps one slot active, not two, and two active
-            // slots share the CU's vector-memory path
-#ifndef TW_CENTRE
-#define TW_CENTRE (OWN + OWN / 2)
-#endif
-            int nb = (((lo + hi) >> 1) - (TW_CENTRE)) & ~3;
+            // (placing the changes inside ONE slot's own columns instead of on the middle slots' boundary measured no gain, round 4)
+            int nb = (((lo + hi) >> 1) - WIN / 2) & ~3;
             nb = max(0, min(nb, (w - WIN + 3) & ~3));
             B = __builtin_amdgcn_readfirstlane(nb);
             have_window = true;
