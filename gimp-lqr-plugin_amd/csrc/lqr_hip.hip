@@ -3454,6 +3454,16 @@ static int dp_persistent_px(const LqrHipBatch *b, int w, bool general = false, i
     return 0;
 }
 static bool dp_persistent_ok(const LqrHipBatch *b, int w) { return dp_persistent_px(b, w) != 0; }
+// How many images of frame width `w` (the direction being carved) one lock-step batch may hold and still run delta_x = 2 /
+// rigidity-mask carvers on the tiled kernels (k_dp_tile_p's general instantiations: one workgroup per 64 columns per image,
+// all co-resident).  Beyond it such a batch would fall to the one-wave-per-image band kernel (~30x slower), so the host
+// carves larger batches of such carvers group after group (host/lqr_carver.c, lqrx_carver_resize_batch).  0: no bound known.
+extern "C" int lqrhip_general_batch_limit(int w)
+{
+    if (lqrhip_init() < 0 || w < 1) return 0;
+    const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_general) : g_dpp_max_wgs_general;
+    return limit / ((w + dpp_own(2) - 1) / dpp_own(2));
+}
 
 // E5 (UPDATE = false) or the full-width form of E9 (UPDATE = true) as one persistent launch
 template <bool UPDATE>

@@ -673,7 +673,24 @@ LqrRetVal lqrx_carver_resize_batch(LqrCarver **carvers, gint n, gint w1, gint h1
     int i, same = 1;
     if (n < 1) return LQR_ERROR;
     for (i = 1; i < n; i++) same &= same_config(carvers[0], carvers[i]);
-    if (same) return group_resize(carvers, n, w1, h1);
+    if (same) {
+        /* delta_x = 2 and rigidity masks (with rigidity) run on the tiled kernels only while the whole group's tiles are
+         * co-resident; a larger group would fall to the one-wave-per-image kernels (~30x slower).  The images are
+         * independent, so such a group is carved in consecutive sub-groups that fit. */
+        const LqrCarver *c = carvers[0];
+        const int general = c->delta_x == 2 || (c->delta_x == 1 && c->has_rigmask && c->rigidity != 0);
+        if (general) {
+            int wmax = c->w_start > c->h_start ? c->w_start : c->h_start, lim;   /* either direction may be carved, shrinking or enlarging */
+            if (w1 > wmax) wmax = w1;
+            if (h1 > wmax) wmax = h1;
+            lim = lqrhip_general_batch_limit(wmax);
+            if (lim >= 1 && n > lim) {
+                for (i = 0; i < n; i += lim) LQR_CATCH(group_resize(carvers + i, n - i < lim ? n - i : lim, w1, h1));
+                return LQR_OK;
+            }
+        }
+        return group_resize(carvers, n, w1, h1);
+    }
     for (i = 0; i < n; i++) LQR_CATCH(lqr_carver_resize(carvers[i], w1, h1));     /* heterogeneous: one by one */
     return LQR_OK;
 }

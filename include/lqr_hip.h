@@ -85,6 +85,9 @@ int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int channels, in
  * >= 8 in the environment before HIP initialises; its default of 4 makes the split 30 % slower than one stream, so it is
  * then not made), else 1.  lqrhip_set_sub_batches(n > 0) pins it. */
 int lqrhip_sub_batches(int n);
+/* Images of carved-frame width w that one lock-step batch may hold and still run delta_x = 2 / rigidity-mask carvers on the
+ * tiled kernels (0: unknown); larger batches of such carvers are carved group after group (lqrx_carver_resize_batch). */
+int lqrhip_general_batch_limit(int w);
 void lqrhip_set_sub_batches(int n);
 LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n);
 /* tell a batch that sibling batches of the same group run concurrently on other streams: kernels whose grid must be
