@@ -941,6 +941,7 @@ __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h
     const GCarver c = gview_phys(cs[blockIdx.y]);
     const int org = c.flags[FLAG_ORG_PREV], side = c.flags[FLAG_SIDE];      // published by k_vpath* for this seam
     const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) c.flags[FLAG_OVF_ROW] = h;       // k_band_tiles lowers it with atomic mins; the other band kernels overwrite it
     for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < h; y += gridDim.x * 4) carve_row(c, org, side, y, w, stride, delta, move_dp, lane);
 }
 
@@ -2077,7 +2078,8 @@ constexpr int DPP_BLK_BITS = 12;                // bits of the block index in a 
 // co-residency bound for the spin waits, set from the occupancy query in lqrhip_init (dpp_resident_workgroups)
 static int g_dpp_max_wgs = 0;
 static int g_dpp_max_wgs_plain = 0, g_dpp_max_wgs_general = 0;      // ... of the plain / the delta_x = 2, rigidity-mask instantiations
-static int g_dpp_max_wgs_px4 = 0;                                   // ... of the plain 4-px instantiations alone (fewer registers than the 2-px ones)
+static int g_dpp_max_wgs_px4 = 0;
+static int g_dpp_max_wgs_tiles = 0;                                 // ... of k_band_tiles                                   // ... of the plain 4-px instantiations alone (fewer registers than the 2-px ones)
 
 
 // DELTA = delta_x (1 or 2: errors move DELTA columns per row, so a block is HALO / DELTA rows); RIGM = a rigidity mask
@@ -2408,6 +2410,331 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
 }
 
 // ---------------------------------------------------------------------------
+// E9 update_mmap for large batches, one image's band spread over SEVERAL CUs ("band tiles", round 4).
+//
+// k_band_update_tw walks an image's band on ONE compute unit, and what bounds it is that unit's vector-memory path (one
+// instruction per ~35-50 cycles) -- 64 of 256 CUs busy, each saturated.  k_dp_tile_p<UPDATE> spreads an
+// image over one CU per 64 columns and runs a row in a third of the time, but out of place and over the FULL width:
+// 14 B/px and 60 tiles per 4K image, too much for a batch.  This kernel is that sweep restricted to T tiles around the
+// seam, IN PLACE, with the band kernel's activity test per tile and 32-row block:
+//   * tile set: T tiles of 64 own columns (+ 32-column halos, 2 px per lane, two turn-taking waves), centred on the middle
+//     of the carve-touched columns of all rows; every tile derives the same placement from seam_x.  The touched columns
+//     must keep 32 columns away from real columns outside the set, otherwise row 0 is handed to the full-width sweep
+//     (flags[FLAG_OVF_ROW], atomic min) and nothing is done here.
+//   * in place: a tile stores block j only after its partner wave has received both neighbours' hand-over for block
+//     j + 1, i.e. after both neighbours have FINISHED block j -- their inputs for block j (which include this tile's own
+//     columns as their halo) were consumed before.  After the last block a "done" hand-over does the same job.  Reading a
+//     pixel a neighbour has already updated would be harmless for the pair (m, back pointer) as a whole (the keep rule is
+//     idempotent) but not for a torn pair; the ordering excludes both.
+//   * activity: a tile is ACTIVE in block j iff a carve-touched pixel of the block's rows lies within 32 columns of its
+//     own columns, or one of its own pixels, or one of the 32 outer own pixels of a neighbour (the hand-over granules carry
+//     a "changed" bit), changed on the last row of block j - 1: a change travels one column per row, a block is 32 rows.
+//     An inactive tile computes and stores nothing; it hands the stored values of its block's last row on.  Inputs are
+//     prefetched two blocks ahead only when the tile may be active then (a wrong guess costs a synchronous load, never
+//     a result).
+//   * edges: lanes beyond the set read the row above a block from memory (nothing changes out there); a change that
+//     reaches the outermost own column of the set stops the image: the block is not stored, its first row goes to
+//     flags[FLAG_OVF_ROW] (atomic min), and ABORT granules tell the neighbours, which pass them on and leave.  Every row
+//     below the recorded one is then redone by k_dp_sweep<UPDATE> from memory that holds, per pixel, either the old or
+//     the final pair -- the same superset argument as for the band kernels' hand-over.
+// Grid (T, images), all co-resident (spin waits, bounded as in k_dp_tile_p); hand-over granules {m, tag} with
+// tag = epoch << 13 | changed << 12 | block.
+// ---------------------------------------------------------------------------
+#define BT_BLK_ABORT 0xfffu
+// [0] images not covered by their tile set, [1] images aborted at an edge (rare events: one atomic each)
+__device__ unsigned long long g_bt_stats[8];
+#define BT_STAT(i) do { if (lane == 0) atomicAdd(&g_bt_stats[i], 1ull); } while (0)
+constexpr int BT_MAX_BLK = 256;           // blocks of 32 rows: images up to 8192 rows
+constexpr int BT_T_MAX = 12;              // tiles per image (768 columns)
+template <bool LR, bool RIG>
+__global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err)
+{
+    constexpr int PX = 2, HALO = 32, OWN = 64, EX_TILE = 2 * 2 * HALO, HL = 16, R = 32, TILE = 128;
+    typedef LaneVec<2>::F FV;
+    typedef LaneVec<2>::L LV;
+    typedef GLOBAL_AS FV GFV;
+    typedef GLOBAL_AS LV GLV;
+    typedef GLOBAL_AS unsigned long long gu64;
+    __shared__ FV s_mp[64];                       // the row above the next block, handed from wave to wave
+    __shared__ int s_fail;                        // leave at the next barrier: a neighbour timed out, or the image was aborted
+    __shared__ volatile int s_polled;             // last block whose hand-over this workgroup has received
+    __shared__ int s_own_chg;                     // an own pixel changed on the last row of the block just finished
+    __shared__ int s_tlo[BT_MAX_BLK], s_thi[BT_MAX_BLK];      // per block: columns the carve touched on its rows
+    __shared__ int s_smin, s_smax;
+    const int T = gridDim.x, tile = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = (h + R - 1) / R;
+    for (int i = tid; i < nblk; i += 128) { s_tlo[i] = 1 << 30; s_thi[i] = -1; }
+    if (tid == 0) { s_fail = 0; s_polled = 0; s_own_chg = 0; s_smin = 1 << 30; s_smax = -1; }
+    __syncthreads();
+    const GCarver c = gview(cs[blockIdx.y]);
+    {
+        int smin = 1 << 30, smax = -1;
+        for (int y = tid; y < h; y += 128) {        // pixels of row y whose inputs the carve changed (as k_band_update_tw)
+            const int v0 = c.seam_x[y], vm = c.seam_x[max(y - 1, 0)], vp = c.seam_x[min(y + 1, h - 1)];
+            const int t0 = max(min(min(v0, vm), vp) - 2, 0), t1 = min(max(max(v0, vm), vp) + 1, w - 1);
+            atomicMin(&s_tlo[y / R], t0); atomicMax(&s_thi[y / R], t1);
+            smin = min(smin, t0); smax = max(smax, t1);
+        }
+        for (int o = 32; o > 0; o >>= 1) { smin = min(smin, __shfl_xor(smin, o)); smax = max(smax, __shfl_xor(smax, o)); }
+        if (lane == 0) { atomicMin(&s_smin, smin); atomicMax(&s_smax, smax); }
+    }
+    __syncthreads();
+    const int smin = s_smin, smax = s_smax;
+    const int ntiles_img = (w + OWN - 1) / OWN;
+    const int tile0 = max(0, min(((smin + smax) >> 1) / OWN - T / 2, ntiles_img - T));
+    const int gt = tile0 + tile;                              // this tile's place in the image
+    if (gt >= ntiles_img) return;                             // the set is wider than the image
+    const bool has_left = tile > 0, has_right = tile + 1 < T && gt + 1 < ntiles_img;
+    const bool out_left = !has_left && gt > 0, out_right = !has_right && gt + 1 < ntiles_img;      // real columns beyond the set
+    {
+        const int set_lo = tile0 * OWN, set_end = min((tile0 + T) * OWN, w);
+        const bool covered = (tile0 == 0 || smin >= set_lo + HALO) && (tile0 + T >= ntiles_img || smax < set_end - HALO);
+        if (!covered) {                                       // uniform over the image's tiles
+            if (tile == 0 && tid == 0) { __hip_atomic_fetch_min(c.flags + FLAG_OVF_ROW, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicAdd(&g_bt_stats[0], 1ull); }
+            return;
+        }
+    }
+    gu64 *ex_img = (gu64 *) exch + (size_t) blockIdx.y * ((size_t) T * EX_TILE + 8);
+    const float INF = __int_as_float(0x7f800000);
+    const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
+    const int x0 = gt * OWN - HALO + PX * lane;               // first pixel of this lane (may be < 0 or >= w)
+    const bool own_lane = lane >= HL && lane < 64 - HL;
+    const bool own = own_lane && x0 < w;
+    const unsigned lo_off = (unsigned) min(max(x0, 0), stride - PX);
+    bool in[PX];
+#pragma unroll
+    for (int k = 0; k < PX; k++) in[k] = x0 + k >= 0 && x0 + k < w;
+    const bool any_in = in[0] || in[1];
+    const bool interior = (x0 - PX * lane >= 0) && (x0 - PX * lane + TILE <= w);
+    const int own_lo = gt * OWN, own_hi = min(own_lo + OWN, w) - 1;
+    const bool watch_l = out_left && lane == HL, watch_r = out_right && lane == 63 - HL;      // the set's outermost own columns
+
+    FV q_e[R], q_mo[R];
+    LV q_lo[R];
+    auto issue_full = [&](int ybase) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const unsigned row = (unsigned) min(ybase + r, h - 1) * (unsigned) stride;
+            const unsigned ro = row + lo_off, ro4 = (row << 2) + (lo_off << 2);
+            q_e[r] = *(const GFV *) ((const gu8 *) c.en + ro4);
+            q_mo[r] = *(const GFV *) ((const gu8 *) c.m + ro4);
+            q_lo[r] = *(const GLV *) (c.least + ro);
+        }
+    };
+    auto issue_last = [&](int ybase) {        // only the row an inactive tile hands on
+        const unsigned row = (unsigned) min(ybase + R - 1, h - 1) * (unsigned) stride;
+        q_mo[R - 1] = *(const GFV *) ((const gu8 *) c.m + (((row + lo_off)) << 2));
+    };
+    float mp[PX] = {INF, INF};
+    bool chl[PX] = {false, false};            // changed on the block's last row
+    bool echg = false;                        // the set's outermost own column changed somewhere in the block
+    auto batch_u = [&](int ybase) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            float mc[PX], e[PX], mo[PX];
+            uint32_t lnew = 0;
+            bool ch[PX];
+#pragma unroll
+            for (int k = 0; k < PX; k++) { e[k] = q_e[r][k]; mo[k] = q_mo[r][k]; }
+            const float left = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1]), DPP_WAVE_SHR1, 0xf, 0xf, true));
+            const float right = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[0]), DPP_WAVE_SHL1, 0xf, 0xf, true));
+            dp_row<PX, LR, RIG, true, false>(mp, left, right, e, mo, (uint32_t) q_lo[r], in, rig_l, rig_r, mc, lnew, ch);
+            if (r == 0 && ybase == 0) {          // row 0: m = en, whatever stood there (update_mmap's first row)
+#pragma unroll
+                for (int k = 0; k < PX; k++) { mc[k] = e[k]; ch[k] = !(e[k] == mo[k]); }
+                lnew = 0;
+            }
+            echg |= (watch_l && ch[0]) || (watch_r && ch[1]);
+            if (r == R - 1) { chl[0] = ch[0]; chl[1] = ch[1]; }
+#pragma unroll
+            for (int k = 0; k < PX; k++) { mp[k] = mc[k]; q_mo[r][k] = mc[k]; }
+            q_lo[r] = (LV) lnew;
+        }
+    };
+    auto store_u = [&](int ybase) {
+        const unsigned inc = own ? (unsigned) stride : 0u, inc4 = inc * 4u;
+        unsigned so = own ? (unsigned) ybase * (unsigned) stride + (unsigned) x0 : (unsigned) h * (unsigned) stride + (unsigned) (PX * lane), so4 = so * 4u;
+        const int nr = min(R, h - ybase);
+#pragma unroll
+        for (int r = 0; r < R; r++, so += inc, so4 += inc4) {
+            if (r < nr) {
+                *(GFV *) ((gu8 *) c.m + so4) = q_mo[r];
+                *(GLV *) (c.least + so) = q_lo[r];
+            }
+        }
+    };
+    // the hand-over for block j (published by the neighbours after their block j - 1; j == nblk: "done"): the halo lanes
+    // take the row above the block from it.  Returns: bit 0 a neighbour's outer pixels changed, bit 1 abort seen, bit 2 time-out
+    auto receive = [&](int j, bool take) -> int {
+        const bool halo_lane = !own_lane && any_in;
+        const bool side_l = lane < 32;
+        const bool from_nbr = halo_lane && (side_l ? has_left : has_right);
+        const bool from_mem = halo_lane && (side_l ? out_left : out_right);
+        const int nb = side_l ? tile - 1 : tile + 1;
+        const int col = !from_nbr ? 0 : side_l ? PX * lane : PX * (lane - 64 + HL);
+        gu64 *src = ex_img + (size_t) (from_nbr ? nb : tile) * EX_TILE + (size_t) (((j - 1) & 1) * 2 + (side_l ? 1 : 0)) * HALO + col;
+        const unsigned want = ((unsigned) epoch << 13) | (unsigned) j, abort_tag = ((unsigned) epoch << 13) | BT_BLK_ABORT;
+        unsigned long long g[PX];
+        int spins = 0, res = 0;
+        FV mem = {INF, INF};
+        if (take && from_mem) mem = *(const GFV *) ((const gu8 *) c.m + ((((unsigned) (j * R - 1) * (unsigned) stride) + lo_off) << 2));
+        {
+            // light poll first: ONE lane per side watches one granule, backing off -- most tiles of a set are inactive and spend
+            // their time here; 32 lanes x 2 agent-scope loads per turn from each of them would sit in front of the active
+            // tiles' loads in L2
+            const bool scout = from_nbr && (lane == 0 || lane == 63);
+            int sp = 0;
+            while (true) {
+                const unsigned t = scout ? (unsigned) (__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) : want;
+                if (__all(!scout || (t & ~0x1000u) == want || t == abort_tag)) break;
+                if (sp < 8) __builtin_amdgcn_s_sleep(2); else if (sp < 64) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
+                ++sp;
+                if ((sp & 255) == 0 && dev_failed(dev_err)) break;
+                if (sp > (1 << 18)) break;                   // the full poll below reports the time-out
+            }
+        }
+        while (true) {
+#pragma unroll
+            for (int k = 0; k < PX; k++) g[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = true, ab = false;
+#pragma unroll
+            for (int k = 0; k < PX; k++) {
+                const unsigned t = (unsigned) (g[k] >> 32);
+                ab |= (t == abort_tag);
+                ok &= ((t & ~0x1000u) == want) || (t == abort_tag);
+            }
+            if (__any(from_nbr && ab)) { res |= 2; break; }
+            if (__all(ok || !from_nbr)) break;
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+            if ((spins & 1023) == 0 && dev_failed(dev_err)) { res |= 4; break; }
+            if (spins > (1 << 22)) { if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); res |= 4; break; }
+        }
+        if (!(res & 6)) {
+            bool chg = false;
+#pragma unroll
+            for (int k = 0; k < PX; k++) chg |= ((unsigned) (g[k] >> 32) & 0x1000u) != 0;
+            if (__any(from_nbr && chg)) res |= 1;
+            if (take && halo_lane) {
+#pragma unroll
+                for (int k = 0; k < PX; k++) mp[k] = !in[k] ? INF : from_nbr ? __uint_as_float((unsigned) g[k]) : from_mem ? mem[k] : INF;
+            }
+        }
+        return res;
+    };
+    auto publish = [&](int j_next, bool abort) {       // the block's last row (in mp) to both neighbours
+        if (own_lane) {
+            const int side = lane < 32 ? 0 : 1;
+            gu64 *dst = ex_img + (size_t) tile * EX_TILE + (size_t) (((j_next - 1) & 1) * 2 + side) * HALO + PX * (lane - (side ? 32 : HL));
+#pragma unroll
+            for (int k = 0; k < PX; k++) {
+                const unsigned tag = ((unsigned) epoch << 13) | (abort ? BT_BLK_ABORT : ((chl[k] ? 0x1000u : 0u) | (unsigned) j_next));
+                __hip_atomic_store(dst + k, ((unsigned long long) tag << 32) | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    // may the tile be active in block j?  (touched pixels of blocks ja..j within `reach` columns)
+    auto touched_near = [&](int ja, int j, int reach) -> bool {
+        bool t = false;
+        for (int b = max(ja, 0); b <= min(j, nblk - 1); b++) t |= (s_tlo[b] <= own_hi + reach && s_thi[b] >= own_lo - reach);
+        return t;
+    };
+
+    bool staged = touched_near(q, q, HALO + 2);               // this wave's first block
+    if (q < nblk) { if (staged) issue_full(q * R); else issue_last(q * R); }
+    for (int j = 0; j < nblk; j++) {
+        const int y0 = j * R;
+        const bool mine = (j & 1) == q;
+        bool act = false, abort = false;
+        if (mine) {
+            if (j > 0) {
+                const FV v = s_mp[lane];
+                mp[0] = v[0]; mp[1] = v[1];
+            }
+            int rcv = 0;
+            if (j > 0) {
+                rcv = receive(j, true);
+                if (rcv & 4) s_fail = 1;
+                if (lane == 0) s_polled = j;
+            }
+            abort = (rcv & 2) != 0;
+            act = !abort && !(rcv & 4) && (touched_near(j, j, HALO + 2) || (j > 0 && (s_own_chg != 0 || (rcv & 1))));
+            chl[0] = chl[1] = false;
+            echg = false;
+            if (act) {
+                if (!staged) issue_full(y0);
+                if (!interior) {
+                    // outside the image the energy AND the old value become +inf (see k_dp_tile_p)
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+#pragma unroll
+                        for (int k = 0; k < PX; k++) { q_e[r][k] = in[k] ? q_e[r][k] : INF; q_mo[r][k] = in[k] ? q_mo[r][k] : INF; }
+                }
+                batch_u(y0);
+                if (__any(echg)) {
+                    // the change front has reached the edge of the set: this block stays unstored, rows from y0 on are the
+                    // full-width sweep's
+                    if (lane == 0) __hip_atomic_fetch_min(c.flags + FLAG_OVF_ROW, y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    BT_STAT(1);
+                    abort = true;
+                }
+            } else if (!abort) {
+                // nothing can change in this block: hand the stored last row on
+                const FV v = q_mo[R - 1];
+                mp[0] = in[0] ? v[0] : INF; mp[1] = in[1] ? v[1] : INF;
+            }
+            {
+                FV v;
+                v[0] = mp[0]; v[1] = mp[1];
+                s_mp[lane] = v;
+            }
+            if (lane == 0) s_own_chg = 0;
+            if (__any(own_lane && (chl[0] || chl[1])) && lane == 0) s_own_chg = 1;
+            if (abort) s_fail = 1;
+            publish(j + 1, abort);               // j + 1 == nblk: "done" (the neighbours wait for it before their last store)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s_fail) return;                      // uniform: written before the barrier
+        if (mine) {
+            if (j + 1 < nblk) {
+                int spins = 0;
+                while (s_polled < j + 1 && !*(volatile int *) &s_fail && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
+                if (*(volatile int *) &s_fail) continue;          // the partner saw an abort or a time-out: it is at the barrier
+            } else if (act) {
+                if (receive(nblk, false) & 6) continue;            // (aborted neighbours: their rows are the sweep's anyway)
+            }
+            if (act) store_u(y0);
+            const int j2 = j + 2;
+            if (j2 < nblk) {
+                staged = act || touched_near(j + 1, j2, 3 * HALO + 2);
+                if (staged) issue_full(j2 * R); else issue_last(j2 * R);
+            }
+        }
+    }
+}
+
+extern "C" int lqrhip_band_tiles_stats(unsigned long long *out, int reset)
+{
+    (void) hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bt_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_bt_stats), z, sizeof z); }
+    return 0;
+}
+static int band_tiles_resident(int n_cu)
+{
+    int per_cu = 1 << 20;
+    auto q = [&](auto kern) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 128, 0) != hipSuccess) { (void) hipGetLastError(); n = 0; }
+        per_cu = std::min(per_cu, n);
+    };
+    q(k_band_tiles<false, false>); q(k_band_tiles<false, true>); q(k_band_tiles<true, false>); q(k_band_tiles<true, true>);
+    return std::max(0, per_cu - 1) * n_cu;
+}
+
+// ---------------------------------------------------------------------------
 // visibility map: seam log -> levels in the base layout (E8 update_vsmap for a
 // whole session), inflate (E14), flatten / read-out compaction (E11, E12),
 // transpose (E11)
@@ -2664,6 +2991,7 @@ struct LqrHipBatch {
     int exch_ntiles = 0, exch_n = 0, exch_px = 0;      // geometry the exchange area was last laid out for
     int tile_epoch = 0;                     // launches of k_dp_tile_p on this batch (part of the granule tags)
     bool dirty = true;
+    int shared_n = 1;                       // ... how many batches of the group there are (lqrhip_batch_set_shared)
     bool shared = false;                    // other batches of the same group run concurrently on their own streams:
                                             // no persistent (spin-waiting, co-residency-dependent) kernels
 };
@@ -2707,6 +3035,7 @@ static int dpp_resident_workgroups(int dev)
     QG(false, false); QG(false, true); QG(true, false); QG(true, true);
 #undef QG
     g_dpp_max_wgs_general = std::max(0, per_cu - 1) * prop.multiProcessorCount;
+    g_dpp_max_wgs_tiles = band_tiles_resident(prop.multiProcessorCount);
     return g_dpp_max_wgs_plain;
 }
 
@@ -3208,7 +3537,7 @@ extern "C" int lqrhip_sub_batches(int n)
     return n >= 2 * nb ? nb : 1;
 }
 
-extern "C" void lqrhip_batch_set_shared(LqrHipBatch *b, int shared) { b->shared = shared != 0; }
+extern "C" void lqrhip_batch_set_shared(LqrHipBatch *b, int shared) { b->shared = shared != 0; b->shared_n = shared > 1 ? shared : 1; }
 
 extern "C" LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n)
 {
@@ -3604,6 +3933,47 @@ static int frozen_catchup(LqrHipBatch *b, int to, int w_at_to, int h)
 
 // batches up to this many pixels use the tiled full-width update (measured break-even with the band kernel at 4K, Mseams*px/s
 // tiled / band: 7 images 118 k / 97 k, 8: 130 / 109, 9: 119 / 121, 12: 130 / 139+, 16: 158 / 175+)
+// Tiles per image for k_band_tiles (0: not usable here).  All of a group's sub-batches run side by side, each with a
+// persistent grid of its own: together they must fit the residency bound of the 2-px tiled instantiations (same register
+// budget: the occupancy query below covers k_band_tiles).
+static int g_band_tiles = -1;            // -1: automatic; 0: never; n: force n tiles per image (tests)
+extern "C" void lqrhip_set_band_tiles(int t) { g_band_tiles = t; }
+static int band_tiles_T(const LqrHipBatch *b, int h)
+{
+    if (g_band_tiles == 0 || (h + 31) / 32 > BT_MAX_BLK) return 0;
+    const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_tiles) : g_dpp_max_wgs_tiles;
+    const int per_batch = limit / std::max(b->shared_n, 1);
+    int T = std::min(BT_T_MAX, per_batch / (int) std::max<size_t>(b->cs.size(), 1));
+    if (g_band_tiles > 0) T = std::min(T, g_band_tiles);
+    return T >= (g_band_tiles > 0 ? 1 : 8) ? T : 0;
+}
+static int launch_band_tiles(LqrHipBatch *b, const DpK &k, int w, int h, int lr, int T)
+{
+    LqrHipCarver *c0 = b->cs[0];
+    const size_t n = b->cs.size();
+    int rc;
+    const size_t need_elems = ((size_t) T * dpp_ex_tile(2) + 8) * n;
+    if (b->exch_elems < need_elems) {
+        HIPCK(hipStreamSynchronize(b->stream));
+        dfree(b->exch);
+        b->exch_elems = 0;
+        if ((rc = dmalloc(&b->exch, need_elems))) return rc;
+        b->exch_elems = need_elems;
+        b->exch_ntiles = 0;
+    }
+    if (b->exch_ntiles != T || b->exch_n != (int) n || b->exch_px != 102) {       // 102: this kernel's tag layout
+        HIPCK(hipMemsetAsync(b->exch, 0, need_elems * sizeof(unsigned long long), b->stream));
+        b->exch_ntiles = T; b->exch_n = (int) n; b->exch_px = 102;
+    }
+    const int epoch = 1 + ((b->tile_epoch++) % ((1 << 19) - 2));           // never 0; 19 bits above changed-bit and block index
+    const dim3 grid(T, (unsigned) n);
+#define LAUNCH_BT(LRV, RIGV) hipLaunchKernelGGL((k_band_tiles<LRV, RIGV>), grid, dim3(128), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
+    if (lr) { if (k.use_rig) LAUNCH_BT(true, true); else LAUNCH_BT(true, false); }
+    else { if (k.use_rig) LAUNCH_BT(false, true); else LAUNCH_BT(false, false); }
+#undef LAUNCH_BT
+    HIPCK(hipGetLastError());
+    return 0;
+}
 static const long long g_tiled_update_px = 8LL * 3840 * 2160;
 
 // One seam of a lock-step batch: k_vpath* (pick + backtrack, publishes the side to move) -> k_carve ->
@@ -3704,6 +4074,25 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     const bool tiled_update = fast_ok ? ((g_update_mode < 0 ? (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px : g_update_mode == 1) &&
                                          dp_persistent_ok(b, w))
                                       : (p->delta_x >= 1 && p->delta_x <= 2 && g_update_mode != 0 && g_update_mode != 2 && g_update_mode != 3 && dp_persistent_px(b, w, true, p->delta_x) != 0);
+    // Batches of 8 to ~48 images: the band spread over several CUs per image (k_band_tiles).  Measured (Mseams*px/s, 4K, tiles /
+    // before): 4 images 80 k / 93 k (the full-width tiled update stays), 8: 144 / 127, 12: 195 / 152, 16: 239 / 193, 24: 294 /
+    // 260, 32: 375 / 341, 40: 423 / 398, 48: 456 / 448, 56: 486 / 485, 64: 486 / 543 -- beyond ~600 resident tile workgroups
+    // the carves of the sibling streams are starved of registers and an aborted image per launch becomes the rule
+    // (DESIGN.md 4.15), so large groups keep k_band_update_tw.
+    {
+        const int T = (fast_ok && (g_update_mode < 0 || g_update_mode == 4)) ? band_tiles_T(b, h) : 0;
+        const size_t group_images = (size_t) n * (size_t) std::max(b->shared_n, 1);
+        if (T > 0 && (g_update_mode == 4 || (group_images >= 8 && group_images * (size_t) T <= 576))) {
+            {
+                ProfScope ps("band_update", b->stream, 0);
+                if ((rc = launch_band_tiles(b, k, wnew, h, leftright_next, T))) return rc;
+            }
+            ProfScope ps("dp_update", b->stream, 0);
+            if ((rc = launch_dp<true>(b, k, wnew, h, leftright_next))) return rc;
+            HIPCK(hipGetLastError());
+            return 0;
+        }
+    }
     if (tiled_update) {
         ProfScope ps("dp_update_tiled", b->stream, 0);
         if ((rc = launch_dp_persistent<true>(b, k, wnew, h, leftright_next))) return rc;

@@ -88,6 +88,8 @@ int lqrhip_sub_batches(int n);
 /* Images of carved-frame width w that one lock-step batch may hold and still run delta_x = 2 / rigidity-mask carvers on the
  * tiled kernels (0: unknown); larger batches of such carvers are carved group after group (lqrx_carver_resize_batch). */
 int lqrhip_general_batch_limit(int w);
+/* Test hook: tiles per image of the multi-CU band update k_band_tiles (-1 automatic, 0 never, n at most n). */
+void lqrhip_set_band_tiles(int tiles);
 void lqrhip_set_sub_batches(int n);
 LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n);
 /* tell a batch that sibling batches of the same group run concurrently on other streams: kernels whose grid must be

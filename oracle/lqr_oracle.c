@@ -162,9 +162,11 @@ static int g_debug_snapshot = 0;
 void lqrx_set_debug(gint on) { g_debug_snapshot = on; }
 
 /* ---- instrumentation (oracle only; used to size the engine's band kernel) -- */
+static long long g_ext_hist[64];   /* per update_mmap call: extent of the union of the rows' bands, in 64-column bins */
+void olqr_oracle_get_extent_hist(long long *out) { memcpy(out, g_ext_hist, sizeof g_ext_hist); }
 static long long g_stats[8];    /* 0:update rows 1:band px 2:max band 3:rows band>62 4:full builds 5:updates 6:rows band>254 */
 void olqr_oracle_get_stats(long long *out) { memcpy(out, g_stats, sizeof g_stats); }
-void olqr_oracle_reset_stats(void) { memset(g_stats, 0, sizeof g_stats); }
+void olqr_oracle_reset_stats(void) { memset(g_stats, 0, sizeof g_stats); memset(g_ext_hist, 0, sizeof g_ext_hist); }
 
 /* ======================= progress ======================================== */
 LqrProgress *lqr_progress_new(void)
@@ -764,6 +766,7 @@ static LqrRetVal build_mmap(LqrCarver *r)
 static LqrRetVal update_mmap(LqrCarver *r)
 {
     int x, y, x_min, x_max, data, least, stop, x_stop;
+    int ext_lo = 1 << 30, ext_hi = -1;
     g_stats[5]++;
     x_min = MAXI(r->nrg_xmin[0], 0);
     x_max = MINI(r->nrg_xmax[0], r->w - 1);
@@ -792,6 +795,7 @@ static LqrRetVal update_mmap(LqrCarver *r)
         {
             long long bw = (long long) x_max - x_min + 1;
             if (bw < 0) bw = 0;
+            if (bw > 0) { if (x_min < ext_lo) ext_lo = x_min; if (x_max > ext_hi) ext_hi = x_max; }
             g_stats[0]++; g_stats[1] += bw;
             if (bw > g_stats[2]) g_stats[2] = bw;
             if (bw > 62) g_stats[3]++;
@@ -823,6 +827,7 @@ static LqrRetVal update_mmap(LqrCarver *r)
             if (x == x_max && stop) x_max = x_stop;
         }
     }
+    { int e = ext_hi >= ext_lo ? (ext_hi - ext_lo + 1) / 64 : 0; g_ext_hist[e > 63 ? 63 : e]++; }
     if (g_debug_snapshot) {
         /* consistency probe (debug only): every back-pointer must name a pixel that is still
          * within delta_x of its child in the carved frame; g_stats[7] counts violations */

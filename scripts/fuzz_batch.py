@@ -47,7 +47,7 @@ while time.time() < t_end and not (max_cases and n >= max_cases):
     if rng.random() < 0.2:
         kw.update(delta_x=int(rng.choice([2, 3])))
     masks = rng.random() < 0.2
-    mode = int(rng.choice([-1, 0, 1, 2]))
+    mode = int(rng.choice([-1, 0, 1, 2, 4, 4]))
     sub = int(rng.choice([1, 1, 2, 3]))
     what = "%d x %dx%d ch%d -> %dx%d %s%s mode %d sub %d" % (nimg, w, h, ch, w + dw, h + dh, kw, " +masks" if masks else "", mode, sub)
     lib.lqrhip_set_update_mode(mode); lib.lqrhip_set_sub_batches(sub)

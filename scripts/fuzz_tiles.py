@@ -1,0 +1,51 @@
+"""Randomised parity run for the multi-CU band update (k_band_tiles, update mode 4): engine vs oracle through the C ABI with
+the tile count forced to 1..12 per image -- small counts put the edges of the tile set next to the seam (coverage test,
+abort and hand-over to the full-width sweep), large ones cover small images entirely.  Also compares the DP planes after the
+last incremental update bit for bit.
+    python scripts/fuzz_tiles.py [seconds] [seed]"""
+import ctypes, os, sys, time
+sys.path.insert(0, "tests")
+import numpy as np
+import datasets as D, fuzz_cases as F, harness as H, lqr_ctypes as L
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+max_cases = int(os.environ.get("FUZZ_COUNT", "0"))
+rng = np.random.default_rng(seed)
+o, e = L.oracle_api(), L.engine_api()
+lib = e.lib
+lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]; lib.lqrhip_set_band_tiles.argtypes = [ctypes.c_int]
+t_end = time.time() + budget
+n = fails = 0
+try:
+    while time.time() < t_end and not (max_cases and n >= max_cases):
+        img, nw, nh, kw, what = F.draw_case(rng)
+        kw.pop("delta_x", None); kw.pop("rigmask", None)          # the plain kernels' domain
+        if rng.random() < 0.5:
+            kw["switch_freq"] = 0
+        T = int(rng.choice([1, 2, 3, 4, 6, 8, 12]))
+        lib.lqrhip_set_update_mode(4); lib.lqrhip_set_band_tiles(T)
+        planes = kw.get("switch_freq") == 0 and nh == img.shape[0] and nw < img.shape[1]
+        try:
+            if planes:
+                o.lqrx_set_debug(1); e.lqrx_set_debug(1)
+            ca, _ = H.init_carver(o, img, nw, nh, **kw); cb, _ = H.init_carver(e, img, nw, nh, **kw)
+            ra, rb = ca.resize(nw, nh), cb.resize(nw, nh)
+            assert ra == rb == 1, (ra, rb)
+            va, vb = ca.vmap_dump(), cb.vmap_dump()
+            assert np.array_equal(va["data"], vb["data"]), "seam maps"
+            assert np.array_equal(ca.read_image(), cb.read_image()), "pixels"
+            if planes:
+                (ea, ma, da), (eb, mb, db) = ca.debug_snapshot(), cb.debug_snapshot()
+                assert np.array_equal(ea, eb) and np.array_equal(ma, mb) and np.array_equal(da[1:], db[1:]), "DP planes"
+            ca.destroy(); cb.destroy()
+        except AssertionError as ex:
+            fails += 1
+            print("FAIL case %d T=%d %s: %s" % (n, T, what, str(ex)[:120]), flush=True)
+        finally:
+            o.lqrx_set_debug(0); e.lqrx_set_debug(0)
+        n += 1
+finally:
+    lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_tiles(-1)
+print("tiles fuzz: %d cases, %d failures, seed %d" % (n, fails, seed), flush=True)
+sys.exit(1 if fails else 0)

@@ -23,7 +23,7 @@ def test_fuzz_seed(oracle, engine, seed):
         for n in range(CASES_PER_SEED):
             # every third case large (band window < image); the others small, so the whole file stays ~2 min
             img, nw, nh, kw, what = F.draw_case(rng, small=(n % 3 != 0))
-            name, mode = list(F.MODES.items())[(n + n // 3) % 3]      # large cases (n % 3 == 0) visit all three modes
+            name, mode = list(F.MODES.items())[(n + n // 3) % len(F.MODES)]      # the cases visit all the update modes
             engine.lib.lqrhip_set_update_mode(mode)
             a = H.run_case(oracle, img, nw, nh, **kw)
             b = H.run_case(engine, img, nw, nh, **kw)

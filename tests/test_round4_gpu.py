@@ -66,3 +66,33 @@ def test_host_transfers_odd_sizes(engine, w, h, ch):
         assert n == h and np.array_equal(lines, img)
         assert np.array_equal(c.read_image(), img)
         c.destroy()
+
+
+def test_band_tiles_seeded_cases_with_forced_tile_counts():
+    """scripts/fuzz_tiles.py: the multi-CU band update with 1..12 tiles per image -- sets narrower than the band (coverage
+    test, abort at the edge of the set and hand-over to the full-width sweep), sets wider than the image, both tie rules,
+    rigidity; seam maps, pixels and the DP planes after the last incremental update against the oracle"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_tiles.py"), "300", "4400"], cwd=root,
+                       env=dict(os.environ, FUZZ_COUNT="400"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " 0 failures" in r.stdout, (r.stdout[-3000:], r.stderr[-1000:])
+
+
+def test_band_tiles_batch_of_12_images(oracle, engine):
+    """a lock-step batch of the size the engine itself sends to k_band_tiles (8 to ~48 images): every image against the oracle"""
+    import ctypes
+    lib = engine.lib
+    n, w, h = 12, 1200, 330
+    imgs = [D.photo_like(w, h, 1200 + i) if i % 2 else D.noise(w, h, 1200 + i) for i in range(n)]
+    cs = [L.Carver(engine, im).configure() for im in imgs]
+    lib.lqrhip_prof_reset(); lib.lqrhip_prof_enable(1)
+    assert L.resize_batch(engine, cs, w - 60, h) == L.LQR_OK
+    lib.lqrhip_prof_enable(0)
+    st = (ctypes.c_ulonglong * 8)()
+    for c, im in zip(cs, imgs):
+        ref = H.run_case(oracle, im, w - 60, h)
+        assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"])
+        assert np.array_equal(c.read_image(), ref["image"])
+    for c in cs:
+        c.destroy()
