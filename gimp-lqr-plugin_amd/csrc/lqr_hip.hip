@@ -2440,11 +2440,11 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
 // Grid (T, images), all co-resident (spin waits, bounded as in k_dp_tile_p); hand-over granules {m, tag} with
 // tag = epoch << 13 | changed << 12 | block.
 // ---------------------------------------------------------------------------
-#define BT_BLK_ABORT 0xfffu
+#define BT_BLK_ABORT 0x7ffu
 // [0] images not covered by their tile set, [1] images aborted at an edge (rare events: one atomic each)
 __device__ unsigned long long g_bt_stats[8];
 #define BT_STAT(i) do { if (lane == 0) atomicAdd(&g_bt_stats[i], 1ull); } while (0)
-constexpr int BT_MAX_BLK = 256;           // blocks of 32 rows: images up to 8192 rows
+constexpr int BT_MAX_BLK = 256;           // blocks of 32 rows: images up to 8192 rows (the tag has 11 bits for the block)
 constexpr int BT_T_MAX = 12;              // tiles per image (768 columns)
 template <bool LR, bool RIG>
 __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err)
@@ -2566,7 +2566,8 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
         }
     };
     // the hand-over for block j (published by the neighbours after their block j - 1; j == nblk: "done"): the halo lanes
-    // take the row above the block from it.  Returns: bit 0 a neighbour's outer pixels changed, bit 1 abort seen, bit 2 time-out
+    // take the row above the block from it.  Returns: bit 0 a neighbour's outer pixels changed, bit 1 abort seen, bit 2 time-out,
+    // bit 3 a neighbour was active
     auto receive = [&](int j, bool take) -> int {
         const bool halo_lane = !own_lane && any_in;
         const bool side_l = lane < 32;
@@ -2580,21 +2581,6 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
         int spins = 0, res = 0;
         FV mem = {INF, INF};
         if (take && from_mem) mem = *(const GFV *) ((const gu8 *) c.m + ((((unsigned) (j * R - 1) * (unsigned) stride) + lo_off) << 2));
-        {
-            // light poll first: ONE lane per side watches one granule, backing off -- most tiles of a set are inactive and spend
-            // their time here; 32 lanes x 2 agent-scope loads per turn from each of them would sit in front of the active
-            // tiles' loads in L2
-            const bool scout = from_nbr && (lane == 0 || lane == 63);
-            int sp = 0;
-            while (true) {
-                const unsigned t = scout ? (unsigned) (__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) : want;
-                if (__all(!scout || (t & ~0x1000u) == want || t == abort_tag)) break;
-                if (sp < 8) __builtin_amdgcn_s_sleep(2); else if (sp < 64) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
-                ++sp;
-                if ((sp & 255) == 0 && dev_failed(dev_err)) break;
-                if (sp > (1 << 18)) break;                   // the full poll below reports the time-out
-            }
-        }
         while (true) {
 #pragma unroll
             for (int k = 0; k < PX; k++) g[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2603,20 +2589,35 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
             for (int k = 0; k < PX; k++) {
                 const unsigned t = (unsigned) (g[k] >> 32);
                 ab |= (t == abort_tag);
-                ok &= ((t & ~0x1000u) == want) || (t == abort_tag);
+                ok &= ((t & ~0x1800u) == want) || (t == abort_tag);
             }
             if (__any(from_nbr && ab)) { res |= 2; break; }
             if (__all(ok || !from_nbr)) break;
-            __builtin_amdgcn_s_sleep(1);
+            {
+                // not there yet: ONE lane per side watches one granule, backing off, before the full read is tried again --
+                // most tiles of a set are inactive and spend their time here; 32 lanes x 2 agent-scope loads per turn from
+                // each of them would sit in front of the active tiles' loads
+                const bool scout = from_nbr && (lane == 0 || lane == 63);
+                int sp = 0;
+                while (true) {
+                    if (sp < 4) __builtin_amdgcn_s_sleep(1); else if (sp < 32) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(48);
+                    const unsigned t = scout ? (unsigned) (__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) : want;
+                    if (__all(!scout || (t & ~0x1800u) == want || t == abort_tag)) break;
+                    ++sp;
+                    if ((sp & 255) == 0 && dev_failed(dev_err)) break;
+                    if (sp > (1 << 16)) break;
+                }
+            }
             ++spins;
-            if ((spins & 1023) == 0 && dev_failed(dev_err)) { res |= 4; break; }
-            if (spins > (1 << 22)) { if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); res |= 4; break; }
+            if ((spins & 63) == 0 && dev_failed(dev_err)) { res |= 4; break; }
+            if (spins > (1 << 12)) { if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); res |= 4; break; }
         }
         if (!(res & 6)) {
             bool chg = false;
 #pragma unroll
             for (int k = 0; k < PX; k++) chg |= ((unsigned) (g[k] >> 32) & 0x1000u) != 0;
             if (__any(from_nbr && chg)) res |= 1;
+            if (__any(from_nbr && (((unsigned) (g[0] >> 32) & 0x800u) != 0))) res |= 8;          // a neighbour was active in its last block
             if (take && halo_lane) {
 #pragma unroll
                 for (int k = 0; k < PX; k++) mp[k] = !in[k] ? INF : from_nbr ? __uint_as_float((unsigned) g[k]) : from_mem ? mem[k] : INF;
@@ -2624,13 +2625,13 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
         }
         return res;
     };
-    auto publish = [&](int j_next, bool abort) {       // the block's last row (in mp) to both neighbours
+    auto publish = [&](int j_next, bool abort, bool was_active) {       // the block's last row (in mp) to both neighbours
         if (own_lane) {
             const int side = lane < 32 ? 0 : 1;
             gu64 *dst = ex_img + (size_t) tile * EX_TILE + (size_t) (((j_next - 1) & 1) * 2 + side) * HALO + PX * (lane - (side ? 32 : HL));
 #pragma unroll
             for (int k = 0; k < PX; k++) {
-                const unsigned tag = ((unsigned) epoch << 13) | (abort ? BT_BLK_ABORT : ((chl[k] ? 0x1000u : 0u) | (unsigned) j_next));
+                const unsigned tag = ((unsigned) epoch << 13) | (abort ? BT_BLK_ABORT : ((chl[k] ? 0x1000u : 0u) | (was_active ? 0x800u : 0u) | (unsigned) j_next));
                 __hip_atomic_store(dst + k, ((unsigned long long) tag << 32) | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -2647,7 +2648,7 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
     for (int j = 0; j < nblk; j++) {
         const int y0 = j * R;
         const bool mine = (j & 1) == q;
-        bool act = false, abort = false;
+        bool act = false, abort = false, nbr_act = false;
         if (mine) {
             if (j > 0) {
                 const FV v = s_mp[lane];
@@ -2693,7 +2694,8 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
             if (lane == 0) s_own_chg = 0;
             if (__any(own_lane && (chl[0] || chl[1])) && lane == 0) s_own_chg = 1;
             if (abort) s_fail = 1;
-            publish(j + 1, abort);               // j + 1 == nblk: "done" (the neighbours wait for it before their last store)
+            publish(j + 1, abort, act);
+            nbr_act = (rcv & 8) != 0;               // j + 1 == nblk: "done" (the neighbours wait for it before their last store)
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (s_fail) return;                      // uniform: written before the barrier
@@ -2708,7 +2710,7 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
             if (act) store_u(y0);
             const int j2 = j + 2;
             if (j2 < nblk) {
-                staged = act || touched_near(j + 1, j2, 3 * HALO + 2);
+                staged = act || nbr_act || touched_near(j + 1, j2, 3 * HALO + 2);      // an active neighbour's band may arrive within two blocks
                 if (staged) issue_full(j2 * R); else issue_last(j2 * R);
             }
         }
