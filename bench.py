@@ -186,7 +186,7 @@ def config5_masks(w, h, rigmask):
 KERNEL_NAMES = {
     "carve": (["k_carve"], ["k_carve"]),
     "vpath": (["k_vpath1", "k_vpath"], ["k_vpath1", "k_vpath"]),
-    "band_update": (["k_band_update_tw", "k_band_update_mw", "k_band_update"], ["k_band_update_tw", "k_band_update"]),
+    "band_update": (["k_band_update_tw", "k_band_tiles", "k_band_update_mw", "k_band_update"], ["k_band_tiles", "k_band_update_tw", "k_band_update"]),
     "dp_update": (["k_dp_sweep"], ["k_dp_sweep"]),
     "dp_update_tiled": (["k_dp_tile_p"], ["k_dp_tile_p"]),
     "dp_sweep": (["k_dp_tile", "k_dp_sweep"], ["k_dp_tile_p", "k_dp_tile", "k_dp_sweep"]),

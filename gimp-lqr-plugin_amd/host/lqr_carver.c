@@ -326,7 +326,7 @@ static LqrRetVal group_open(Group *g, LqrCarver **rs, int n)
                 free(ds);
                 return LQR_NOMEM;
             }
-            lqrhip_batch_set_shared(g->b[k], nb > 1);
+            lqrhip_batch_set_shared(g->b[k], nb > 1 ? nb : 0);       /* how many sub-batches run side by side */
             g->nb = k + 1;
         }
         free(ds);

@@ -92,8 +92,9 @@ int lqrhip_general_batch_limit(int w);
 void lqrhip_set_band_tiles(int tiles);
 void lqrhip_set_sub_batches(int n);
 LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n);
-/* tell a batch that sibling batches of the same group run concurrently on other streams: kernels whose grid must be
- * co-resident (k_dp_tile_p spins on neighbour tiles) are then never chosen */
+/* tell a batch how many batches of its group run concurrently on their own streams (0 or 1: alone): kernels whose grid
+ * must be co-resident are then never chosen (k_dp_tile_p spins on neighbour tiles) or sized so that ALL the siblings' grids
+ * fit together (k_band_tiles) */
 void lqrhip_batch_set_shared(LqrHipBatch *b, int shared);
 void lqrhip_batch_destroy(LqrHipBatch *b);
 int lqrhip_batch_sync(LqrHipBatch *b);
