@@ -39,18 +39,19 @@ Run with --gpus N > 1 and no RANK in the environment, the script re-executes
 itself under torch.distributed.run with N ranks (one per GPU, RCCL).
 
 Also on the JSON line:
-  roofline      the dominant HBM kernel (k_carve), HIP-event timed per launch on its
-                own stream(s) inside the timed region.  achieved = algorithmic bytes
-                (8 B x W*H/2 per image per launch) / the time during which
-                a carve was running (launches of sub-batch streams overlap: the union of
-                their intervals, not the sum); avg_launch_us is the plain mean per launch
-                (what rocprofv3 --kernel-trace reports).  peak 8 TB/s nominal,
-                measured_copy_peak = this device's own 16-B streaming-copy rate.
-                end_to_end = the whole step against the roof: value x (4 B carve + 9 B x
-                full DPs per phase / seams per phase) / 8 TB/s.
-  cpu_baseline  the CPU oracle (oracle/, a port -- real liblqr is not available
-                here) timed on this host: one image on one core, and one image
-                per core on all cores for the batch workload (nproc stated).
+  roofline      the dominant HBM kernel (k_carve), HIP-event timed per launch on its own stream(s) inside the timed
+                region.  achieved = algorithmic bytes per launch (8 B x W*H/2 per image) / the average
+                launch duration; frac = achieved / 8 TB/s.  (frac_while_active divides by the union of the overlapping
+                launches' intervals instead.)  traffic = HBM bytes per launch from the committed PMC passes of this
+                command (profiles/pmc_kernels.json, scripts/profile_r04.sh).  kernels = EVERY kernel of the step from one
+                extra untimed step with all of them timed: launches, average duration, share of the kernel time,
+                algorithmic and PMC bytes, fraction of the roof.  end_to_end = the whole step against the roof:
+                value x (4 B carve + 9 B x full DPs per phase / seams per phase) / 8 TB/s.
+  configs       after the headline, BASELINE configs 2, 3 and 5 (fhd, single4k, config5: one carver, the plug-in's own
+                call shape), 3 steps each, with their own roofline.kernels, phases and cpu_baseline (--no-configs skips).
+  cpu_baseline  the CPU oracle (oracle/, a port of liblqr pinned against the genuine liblqr 0.4.1, oracle/REF_CHECK.md)
+                timed on this host: one image on one core, and one image per core on all cores for the batch workload
+                (nproc stated).
 """
 import argparse
 import ctypes as C
