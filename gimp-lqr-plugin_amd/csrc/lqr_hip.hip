@@ -1615,7 +1615,7 @@ __device__ __forceinline__ void dp_row_g(const float (&mp)[PX], const float (&nl
                                          const float (&mo)[PX], const uint32_t lo, const bool (&in)[PX], const float (&rg)[2 * DELTA + 1],
                                          const float (&rf)[PX], float (&mc)[PX], uint32_t &lnew, bool (&ch)[PX])
 {
-    static_assert(DELTA <= PX, "the neighbouring lane holds the whole reach");
+    static_assert(DELTA <= 2 * PX, "the two neighbouring lanes hold the whole reach");
     const float INF = __int_as_float(0x7f800000);
     float nm[PX];
     lnew = 0;
@@ -2071,6 +2071,7 @@ __global__ __launch_bounds__(64) void k_dp_tile(const DevCarver *cs, DpK p, int 
 constexpr int dpp_halo(int px) { return 16 * px; }              // halo columns on each side = rows per block
 constexpr int dpp_own(int px) { return 64 * px - 2 * dpp_halo(px); }     // columns a tile owns
 constexpr int dpp_ex_tile(int px) { return 2 * 2 * dpp_halo(px); }       // granules a tile publishes: [block parity][side: 0 to the left, 1 to the right][column]
+constexpr int dpp_rb(int px, int delta) { return delta >= 3 ? 8 : dpp_halo(px) / delta; }      // rows per block
 constexpr int DPP_R = 16;                       // rows per batch
 constexpr int DPP_W = 2;                        // waves taking turns
 static_assert(dpp_halo(2) % (2 * DPP_R) == 0 && dpp_halo(4) % (2 * DPP_R) == 0, "a block (halo / delta_x rows, delta_x <= 2) is a whole number of batches");
@@ -2094,7 +2095,7 @@ __device__ unsigned long long g_tile_dbg[2 * 16];
 template <int PX, bool LR, bool RIG, bool UPDATE, int DELTA = 1, bool RIGM = false>
 __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err)
 {
-    static_assert(DELTA >= 1 && DELTA <= 2 && (RIG || !RIGM), "delta_x 1 or 2; a rigidity mask only matters with rigidity");
+    static_assert(DELTA >= 1 && DELTA <= 4 && DELTA <= 2 * PX && (RIG || !RIGM), "delta_x 1 .. 4; a rigidity mask only matters with rigidity");
     typedef typename LaneVec<PX>::F FV;
     typedef typename LaneVec<PX>::L LV;
     typedef GLOBAL_AS FV GFV;
@@ -2137,10 +2138,11 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
     // block, as the delta_x = 2 instantiations do with their 16-row blocks): half the hand-overs, barriers and loop
     // iterations of 16-row batches for 80 more staging registers (193 VGPRs, no spill; the residency bound is queried per
     // instantiation).  Measured on one box: 4K 20.0 -> 21.85 k, FHD 12.3 -> 13.1 k, config 5 50.9 -> 55.9 k.
-    constexpr int R = (PX == 2 && DELTA == 1 && (!RIGM || DPP_RIGM32)) ? DPP_R2 : DPP_R;
+    constexpr int R = (PX == 2 && DELTA == 1 && (!RIGM || DPP_RIGM32)) ? DPP_R2 : DELTA >= 3 ? 8 : DPP_R;      // delta_x 3, 4: 8-row blocks (errors move up to 4 columns per row)
     FV q_e[R], q_mo[R], q_rf[RIGM ? R : 1];
     LV q_lo[R];
-    constexpr int RB = HALO / DELTA, NBB = RB / R;          // rows, batches per block
+    constexpr int RB = dpp_rb(PX, DELTA), NBB = RB / R;          // rows, batches per block
+    static_assert(RB * DELTA <= HALO && RB % R == 0, "a block's errors stay inside the halo");
     float rg[2 * DELTA + 1];
 #pragma unroll
     for (int i = 0; i < 2 * DELTA + 1; i++) rg[i] = p.rigmap[i];
@@ -2193,9 +2195,12 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                         // the neighbouring lanes' pixels next to this lane's: DELTA on each side (DELTA <= PX)
                         float nl[DELTA], nr[DELTA], rf[PX];
 #pragma unroll
-                        for (int i = 0; i < DELTA; i++) {
-                            nl[i] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1 - i]), DPP_WAVE_SHR1, 0xf, 0xf, true));
-                            nr[i] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[i]), DPP_WAVE_SHL1, 0xf, 0xf, true));
+                        for (int i = 0; i < DELTA; i++) {       // pixel i % PX of the lane i / PX + 1 away: one wave shift per lane
+                            int a = __builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1 - i % PX]), DPP_WAVE_SHR1, 0xf, 0xf, true);
+                            int b2 = __builtin_amdgcn_mov_dpp(__float_as_int(mp[i % PX]), DPP_WAVE_SHL1, 0xf, 0xf, true);
+                            if (i >= PX) { a = __builtin_amdgcn_mov_dpp(a, DPP_WAVE_SHR1, 0xf, 0xf, true); b2 = __builtin_amdgcn_mov_dpp(b2, DPP_WAVE_SHL1, 0xf, 0xf, true); }
+                            nl[i] = __int_as_float(a);
+                            nr[i] = __int_as_float(b2);
                         }
 #pragma unroll
                         for (int k = 0; k < PX; k++) rf[k] = RIGM ? q_rf[RIGM ? r : 0][k] : 1.0f;
@@ -2236,9 +2241,12 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
             } else {
                 float nl[DELTA], nr[DELTA], rf[PX];
 #pragma unroll
-                for (int i = 0; i < DELTA; i++) {
-                    nl[i] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1 - i]), DPP_WAVE_SHR1, 0xf, 0xf, true));
-                    nr[i] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[i]), DPP_WAVE_SHL1, 0xf, 0xf, true));
+                for (int i = 0; i < DELTA; i++) {       // pixel i % PX of the lane i / PX + 1 away: one wave shift per lane
+                    int a = __builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1 - i % PX]), DPP_WAVE_SHR1, 0xf, 0xf, true);
+                    int b2 = __builtin_amdgcn_mov_dpp(__float_as_int(mp[i % PX]), DPP_WAVE_SHL1, 0xf, 0xf, true);
+                    if (i >= PX) { a = __builtin_amdgcn_mov_dpp(a, DPP_WAVE_SHR1, 0xf, 0xf, true); b2 = __builtin_amdgcn_mov_dpp(b2, DPP_WAVE_SHL1, 0xf, 0xf, true); }
+                    nl[i] = __int_as_float(a);
+                    nr[i] = __int_as_float(b2);
                 }
 #pragma unroll
                 for (int k = 0; k < PX; k++) rf[k] = RIGM ? q_rf[RIGM ? r : 0][k] : 1.0f;
@@ -3033,7 +3041,9 @@ static int dpp_resident_workgroups(int dev)
     g_dpp_max_wgs_plain = std::max(0, per_cu - 1) * prop.multiProcessorCount;
     // the delta_x = 2 / rigidity-mask instantiations (2 px per lane only) hold more registers
     per_cu = 1 << 20;
-#define QG(LRV, UPD) q(k_dp_tile_p<2, LRV, true, UPD, 1, true>); q(k_dp_tile_p<2, LRV, false, UPD, 2, false>); q(k_dp_tile_p<2, LRV, true, UPD, 2, false>); q(k_dp_tile_p<2, LRV, true, UPD, 2, true>)
+#define QG(LRV, UPD) q(k_dp_tile_p<2, LRV, true, UPD, 1, true>); q(k_dp_tile_p<2, LRV, false, UPD, 2, false>); q(k_dp_tile_p<2, LRV, true, UPD, 2, false>); q(k_dp_tile_p<2, LRV, true, UPD, 2, true>); \
+    q(k_dp_tile_p<2, LRV, false, UPD, 3, false>); q(k_dp_tile_p<2, LRV, true, UPD, 3, false>); q(k_dp_tile_p<2, LRV, true, UPD, 3, true>); \
+    q(k_dp_tile_p<2, LRV, false, UPD, 4, false>); q(k_dp_tile_p<2, LRV, true, UPD, 4, false>); q(k_dp_tile_p<2, LRV, true, UPD, 4, true>)
     QG(false, false); QG(false, true); QG(true, false); QG(true, true);
 #undef QG
     g_dpp_max_wgs_general = std::max(0, per_cu - 1) * prop.multiProcessorCount;
@@ -3779,7 +3789,7 @@ static int dp_persistent_px(const LqrHipBatch *b, int w, bool general = false, i
     const size_t n = b->cs.size();
     const int hh = b->cs[0]->wk_h;                            // the block index is DPP_BLK_BITS bits of the granule tag
     const int maxblk = (1 << DPP_BLK_BITS) - 1;
-    if ((general || g_dpp_px_override != 4) && hh <= maxblk * (dpp_halo(2) / delta) && (size_t) ((w + dpp_own(2) - 1) / dpp_own(2)) * n <= (size_t) limit) return 2;
+    if ((general || g_dpp_px_override != 4) && hh <= maxblk * dpp_rb(2, delta) && (size_t) ((w + dpp_own(2) - 1) / dpp_own(2)) * n <= (size_t) limit) return 2;
     const int limit4 = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_px4) : g_dpp_max_wgs_px4;
     if (!general && g_dpp_px_override != 2 && hh <= maxblk * dpp_halo(4) && (size_t) ((w + dpp_own(4) - 1) / dpp_own(4)) * n <= (size_t) limit4) return 4;
     return 0;
@@ -3806,7 +3816,7 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
     for (auto *c : b->cs) rigm |= (c->rig != nullptr);
     rigm = rigm && k.use_rig;                                  // without rigidity the mask multiplies nothing
     const bool general = k.delta != 1 || rigm;
-    if (k.delta < 1 || k.delta > 2) return LQRHIP_EARG;
+    if (k.delta < 1 || k.delta > 4) return LQRHIP_EARG;
     const int px = dp_persistent_px(b, w, general, k.delta);
     if (!px) return LQRHIP_EARG;
     const int ntiles = (w + dpp_own(px) - 1) / dpp_own(px);
@@ -3857,10 +3867,12 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
 #define LAUNCH_TILE_G(LRV, RIGV, DV, RMV) hipLaunchKernelGGL((k_dp_tile_p<2, LRV, RIGV, UPDATE, DV, RMV>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
 #define LAUNCH_TILE_G_LR(RIGV, DV, RMV) do { if (lr) LAUNCH_TILE_G(true, RIGV, DV, RMV); else LAUNCH_TILE_G(false, RIGV, DV, RMV); } while (0)
     if (general) {
+#define LAUNCH_TILE_G_D(DV) do { if (!k.use_rig) LAUNCH_TILE_G_LR(false, DV, false); else if (!rigm) LAUNCH_TILE_G_LR(true, DV, false); else LAUNCH_TILE_G_LR(true, DV, true); } while (0)
         if (k.delta == 1) LAUNCH_TILE_G_LR(true, 1, true);
-        else if (!k.use_rig) LAUNCH_TILE_G_LR(false, 2, false);
-        else if (!rigm) LAUNCH_TILE_G_LR(true, 2, false);
-        else LAUNCH_TILE_G_LR(true, 2, true);
+        else if (k.delta == 2) LAUNCH_TILE_G_D(2);
+        else if (k.delta == 3) LAUNCH_TILE_G_D(3);
+        else LAUNCH_TILE_G_D(4);
+#undef LAUNCH_TILE_G_D
     }
     else if (px == 2) LAUNCH_TILE_PX(2); else LAUNCH_TILE_PX(4);
 #undef LAUNCH_TILE_G_LR
@@ -3882,7 +3894,7 @@ static int launch_dp(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
         for (auto *c : b->cs) rigm |= (c->rig != nullptr);
         rigm = rigm && k.use_rig;
         if (k.delta == 1 && !rigm) return dp_persistent_ok(b, w) ? launch_dp_persistent<false>(b, k, w, h, lr) : launch_dp_tiled(b, k, w, h, lr);
-        if (k.delta >= 1 && k.delta <= 2 && dp_persistent_px(b, w, true, k.delta)) return launch_dp_persistent<false>(b, k, w, h, lr);
+        if (k.delta >= 1 && k.delta <= 4 && dp_persistent_px(b, w, true, k.delta)) return launch_dp_persistent<false>(b, k, w, h, lr);
     }
     int pxt = (w + DP_THREADS - 1) / DP_THREADS;
     size_t lds = (size_t) 2 * ((w + 3) & ~3) * sizeof(float);
@@ -4075,7 +4087,7 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     const bool fast_ok = p->delta_x == 1 && !rigm && g_update_mode != 3;
     const bool tiled_update = fast_ok ? ((g_update_mode < 0 ? (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px : g_update_mode == 1) &&
                                          dp_persistent_ok(b, w))
-                                      : (p->delta_x >= 1 && p->delta_x <= 2 && g_update_mode != 0 && g_update_mode != 2 && g_update_mode != 3 && dp_persistent_px(b, w, true, p->delta_x) != 0);
+                                      : (p->delta_x >= 1 && p->delta_x <= 4 && g_update_mode != 0 && g_update_mode != 2 && g_update_mode != 3 && dp_persistent_px(b, w, true, p->delta_x) != 0);
     // Batches of 8 to ~48 images: the band spread over several CUs per image (k_band_tiles).  Measured (Mseams*px/s, 4K, tiles /
     // before): 4 images 80 k / 93 k (the full-width tiled update stays), 8: 144 / 127, 12: 195 / 152, 16: 239 / 193, 24: 294 /
     // 260, 32: 375 / 341, 40: 423 / 398, 48: 456 / 448, 56: 486 / 485, 64: 486 / 543 -- beyond ~600 resident tile workgroups

@@ -674,11 +674,11 @@ LqrRetVal lqrx_carver_resize_batch(LqrCarver **carvers, gint n, gint w1, gint h1
     if (n < 1) return LQR_ERROR;
     for (i = 1; i < n; i++) same &= same_config(carvers[0], carvers[i]);
     if (same) {
-        /* delta_x = 2 and rigidity masks (with rigidity) run on the tiled kernels only while the whole group's tiles are
+        /* delta_x = 2 .. 4 and rigidity masks (with rigidity) run on the tiled kernels only while the whole group's tiles are
          * co-resident; a larger group would fall to the one-wave-per-image kernels (~30x slower).  The images are
          * independent, so such a group is carved in consecutive sub-groups that fit. */
         const LqrCarver *c = carvers[0];
-        const int general = c->delta_x == 2 || (c->delta_x == 1 && c->has_rigmask && c->rigidity != 0);
+        const int general = (c->delta_x >= 2 && c->delta_x <= 4) || (c->delta_x == 1 && c->has_rigmask && c->rigidity != 0);
         if (general) {
             int wmax = c->w_start > c->h_start ? c->w_start : c->h_start, lim;   /* either direction may be carved, shrinking or enlarging */
             if (w1 > wmax) wmax = w1;

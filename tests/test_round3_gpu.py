@@ -18,6 +18,11 @@ VARIANTS = {
     "delta2": dict(delta_x=2, rigidity=0.0, rigmask=False),
     "delta2-rigidity": dict(delta_x=2, rigidity=5.0, rigmask=False),
     "delta2-rigmask": dict(delta_x=2, rigidity=9.0, rigmask=True),
+    # round 4: delta_x 3 and 4 on the same kernels (8-row blocks, the parents reach two lanes out)
+    "delta3": dict(delta_x=3, rigidity=0.0, rigmask=False),
+    "delta4-rigidity": dict(delta_x=4, rigidity=5.0, rigmask=False),
+    "delta3-rigmask": dict(delta_x=3, rigidity=9.0, rigmask=True),
+    "delta4": dict(delta_x=4, rigidity=0.0, rigmask=False),
 }
 
 

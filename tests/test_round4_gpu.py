@@ -19,13 +19,13 @@ def prof_launches(lib, name):
     return n.value
 
 
-@pytest.mark.parametrize("variant", ["delta2", "rigmask", "delta2-rigidity"])
+@pytest.mark.parametrize("variant", ["delta2", "rigmask", "delta2-rigidity", "delta4"])
 def test_large_general_batches_run_group_after_group_on_the_tiled_kernels(oracle, engine, variant):
     lib = engine.lib
     lib.lqrhip_set_dp_persistent_limit.argtypes = [ctypes.c_int]
     lib.lqrhip_general_batch_limit.argtypes = [ctypes.c_int]
     w, h, n = 520, 140, 7
-    kw = dict(delta2=dict(delta_x=2), rigmask=dict(rigidity=6.0), **{"delta2-rigidity": dict(delta_x=2, rigidity=4.0)})[variant]
+    kw = dict(delta2=dict(delta_x=2), rigmask=dict(rigidity=6.0), delta4=dict(delta_x=4), **{"delta2-rigidity": dict(delta_x=2, rigidity=4.0)})[variant]
     rigm = D.top_half_mask(w, h) if variant == "rigmask" else None
     imgs = [D.photo_like(w, h, 900 + i) for i in range(n)]
     tiles = (w + 63) // 64
