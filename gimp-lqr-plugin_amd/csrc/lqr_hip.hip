@@ -555,7 +555,7 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
 }
 
 // ---------------------------------------------------------------------------
-// k_vpath1<DELTA>: k_vpath for delta_x == 1 (described below) and, with 12-row chunks, delta_x == 2.  The chase is a
+// k_vpath1<DELTA>: k_vpath for delta_x == 1 (described below) and, with 12- / 8- / 4-row chunks, delta_x == 2 / 3 / 4.  The chase is a
 // chain of H dependent steps on one wave, so what counts
 // is the length of one step and that the back pointers are there when the chase reaches them.  In k_vpath a step
 // is v_readlane + 7 scalar instructions (find the lane, pull the dword, extract and sign-extend the byte), ~55 ns.
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
 // ---------------------------------------------------------------------------
 // rows per chunk by delta_x: the path drifts up to ROWS * delta_x columns inside a chunk and must stay within lanes 4 .. 60 of the 64
 // spread around its start (<= 28), and the window loaded VP1_AHEAD chunks ahead must still hold those 64 columns
-constexpr int vp1_rows(int delta) { return delta == 1 ? 28 : 12; }
+constexpr int vp1_rows(int delta) { return delta == 1 ? 28 : delta == 2 ? 12 : delta == 3 ? 8 : 4; }
 #define VP1_AHEAD 3
 template <int r>
 __device__ __forceinline__ void vp1_step(const int e, int &o, int &path)
@@ -4041,6 +4041,10 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
             hipLaunchKernelGGL(k_vpath1<1>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index);
         else if (p->delta_x == 2)
             hipLaunchKernelGGL(k_vpath1<2>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index);
+        else if (p->delta_x == 3)
+            hipLaunchKernelGGL(k_vpath1<3>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index);
+        else if (p->delta_x == 4)
+            hipLaunchKernelGGL(k_vpath1<4>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index);
         else
             hipLaunchKernelGGL(k_vpath, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, p->delta_x,
                                log_index);
