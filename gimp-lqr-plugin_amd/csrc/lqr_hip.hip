@@ -2618,7 +2618,7 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
             }
             ++spins;
             if ((spins & 63) == 0 && dev_failed(dev_err)) { res |= 4; break; }
-            if (spins > (1 << 12)) { if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); res |= 4; break; }
+            if (spins > (1 << 6)) { if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); res |= 4; break; }      // 64 x ~0.1 s of backed-off polling
         }
         if (!(res & 6)) {
             bool chg = false;
