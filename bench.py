@@ -93,6 +93,7 @@ def parse():
                     help="update_mmap kernel: -1 the engine's choice, 0 band, 1 tiled full width, 2 band-mw")
     ap.add_argument("--band-tiles", type=int, default=-1,
                     help="tiles per image of the multi-CU band update k_band_tiles: -1 the engine's choice, 0 never (k_band_update_tw), n at most n")
+    ap.add_argument("--band-tiles-reserve", type=int, default=-1, help="how many of those are reserve tiles (-1: a third)")
     ap.add_argument("--dp-px", type=int, default=0, help="pin the persistent tiled sweep's pixels per lane (2 or 4; 0: by batch size)")
     ap.add_argument("--band-kernel", type=int, default=None,
                     help="A/B hook (experiments build): 0 k_band_update_tw, 1 k_band_update_td<4 px>, 2 k_band_update_td<2 px>, 3 k_band_update_ls")
@@ -275,6 +276,8 @@ def main():
     lib.lqrhip_set_update_mode(args.update_mode)
     lib.lqrhip_set_band_tiles.argtypes = [C.c_int]
     lib.lqrhip_set_band_tiles(args.band_tiles)
+    lib.lqrhip_set_band_tiles_reserve.argtypes = [C.c_int]
+    lib.lqrhip_set_band_tiles_reserve(args.band_tiles_reserve)
     if args.dp_px:
         lib.lqrhip_set_dp_persistent_px.argtypes = [C.c_int]
         lib.lqrhip_set_dp_persistent_px(args.dp_px)
@@ -603,8 +606,8 @@ def main():
     result = measure(args.workload, args.steps, args.warmup, True)
     if hasattr(lib, "lqrhip_band_tiles_stats"):
         st = (C.c_ulonglong * 8)()
-        if lib.lqrhip_band_tiles_stats(st, 1) == 0 and st[3]:
-            result["band_tiles_stats"] = {"uncovered_images": st[0], "aborted_images": st[1], "active_tile_blocks": st[2], "tile_blocks": st[3], "synchronous_loads": st[4]}
+        if lib.lqrhip_band_tiles_stats(st, 1) == 0 and any(st[i] for i in range(4)):
+            result["band_tiles_stats"] = {"uncovered_images": st[0], "aborted_images": st[1], "reserve_tiles_woken": st[2], "requests_without_reserve": st[3]}
     # ---- BASELINE configs 2, 3 and 5 -- the plug-in's own call shape, one carver (render.c:318) -- on the same line
     if args.workload == "batch4k" and world == 1 and not args.no_configs and args.seams is None:
         result["configs"] = {}

@@ -2440,22 +2440,41 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
 //     An inactive tile computes and stores nothing; it hands the stored values of its block's last row on.  Inputs are
 //     prefetched two blocks ahead only when the tile may be active then (a wrong guess costs a synchronous load, never
 //     a result).
-//   * edges: lanes beyond the set read the row above a block from memory (nothing changes out there); a change that
-//     reaches the outermost own column of the set stops the image: the block is not stored, its first row goes to
-//     flags[FLAG_OVF_ROW] (atomic min), and ABORT granules tell the neighbours, which pass them on and leave.  Every row
-//     below the recorded one is then redone by k_dp_sweep<UPDATE> from memory that holds, per pixel, either the old or
-//     the final pair -- the same superset argument as for the band kernels' hand-over.
-// Grid (T, images), all co-resident (spin waits, bounded as in k_dp_tile_p); hand-over granules {m, tag} with
+//   * edges: lanes beyond the set read the row above a block from memory (nothing changes out there).  The set GROWS on
+//     demand: a third of an image's workgroups are RESERVE tiles that wait on a request word; an edge tile asks for one
+//     (atomic ticket + request {epoch, side, first block, tile}) as soon as a change enters its outer 32 columns -- from
+//     there it cannot pass the outermost column before the block's last row, so a tile that starts with the NEXT block is
+//     in time -- or when the seam comes within 64 columns of the edge in the next two blocks.  The woken tile takes the
+//     row above its first block from memory (nothing has changed there yet), hands it to the tile that asked, and joins
+//     the protocol; it may ask for the next one.  Reserve tiles nobody asked for leave when all base tiles are done
+//     (every request precedes the last base tile's end; the asker drains the request store before it publishes anything
+//     later).  Only if no reserve is left and a change reaches the outermost own column before a block's last row does the
+//     image stop: the block is not stored, its first row goes to flags[FLAG_OVF_ROW] (atomic min), and ABORT granules tell
+//     the neighbours, which pass them on and leave.  Every row below the recorded one is then redone by k_dp_sweep<UPDATE>
+//     from memory that holds, per pixel, either the old or the final pair -- the same superset argument as for the band
+//     kernels' hand-over.  (Rows past the image in its last, partial block are computed from copies and never counted as
+//     changes: they were 90 % of the "aborts" of the first version.)
+// Grid (base + reserve tiles, images), all co-resident (spin waits, bounded as in k_dp_tile_p); hand-over granules {m, tag} with
 // tag = epoch << 13 | changed << 12 | block.
 // ---------------------------------------------------------------------------
 #define BT_BLK_ABORT 0x7ffu
-// [0] images not covered by their tile set, [1] images aborted at an edge (rare events: one atomic each)
+// [0] images not covered by their tile set, [1] images aborted at an edge, [2] reserve tiles woken, [3] requests that found
+// no reserve left (rare events: one atomic each)
 __device__ unsigned long long g_bt_stats[8];
 #define BT_STAT(i) do { if (lane == 0) atomicAdd(&g_bt_stats[i], 1ull); } while (0)
 constexpr int BT_MAX_BLK = 256;           // blocks of 32 rows: images up to 8192 rows (the tag has 11 bits for the block)
-constexpr int BT_T_MAX = 12;              // tiles per image (768 columns)
+constexpr int BT_T_MAX = 12;              // workgroups per image: base tiles + reserve tiles
+constexpr int BT_HDR = 16;                // 8-byte words of an image's header in the exchange area: [0] base tiles finished,
+                                          // [1] requests made, [2 ..] the requests {epoch << 32 | side << 31 | start block << 16 | tile}
+constexpr int BT_NEVER = 1 << 30;
+
+// One tile of one image from block j0 on.  gt: the tile's place in the image (columns [64 gt, 64 gt + 64)); left_from /
+// right_from: first block from which a neighbour tile exists on that side (BT_NEVER: none -- the columns out there are
+// read from memory, and watched).
 template <bool LR, bool RIG>
-__global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err)
+__device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, int w, int h, int stride, GLOBAL_AS unsigned long long *hdr,
+                                              GLOBAL_AS unsigned long long *ex_img, int epoch, int *dev_err, int n_rsv,
+                                              int gt, int j0, int left_from0, int right_from0, const int *s_tlo, const int *s_thi)
 {
     constexpr int PX = 2, HALO = 32, OWN = 64, EX_TILE = 2 * 2 * HALO, HL = 16, R = 32, TILE = 128;
     typedef LaneVec<2>::F FV;
@@ -2467,44 +2486,32 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
     __shared__ int s_fail;                        // leave at the next barrier: a neighbour timed out, or the image was aborted
     __shared__ volatile int s_polled;             // last block whose hand-over this workgroup has received
     __shared__ int s_own_chg;                     // an own pixel changed on the last row of the block just finished
-    __shared__ int s_tlo[BT_MAX_BLK], s_thi[BT_MAX_BLK];      // per block: columns the carve touched on its rows
-    __shared__ int s_smin, s_smax;
-    const int T = gridDim.x, tile = blockIdx.x;
+    __shared__ int s_from[2];                     // first block with a left / right neighbour
+    __shared__ int s_asked[2];                    // a reserve tile was asked for on that side (or there is none left)
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nblk = (h + R - 1) / R;
-    for (int i = tid; i < nblk; i += 128) { s_tlo[i] = 1 << 30; s_thi[i] = -1; }
-    if (tid == 0) { s_fail = 0; s_polled = 0; s_own_chg = 0; s_smin = 1 << 30; s_smax = -1; }
-    __syncthreads();
-    const GCarver c = gview(cs[blockIdx.y]);
-    {
-        int smin = 1 << 30, smax = -1;
-        for (int y = tid; y < h; y += 128) {        // pixels of row y whose inputs the carve changed (as k_band_update_tw)
-            const int v0 = c.seam_x[y], vm = c.seam_x[max(y - 1, 0)], vp = c.seam_x[min(y + 1, h - 1)];
-            const int t0 = max(min(min(v0, vm), vp) - 2, 0), t1 = min(max(max(v0, vm), vp) + 1, w - 1);
-            atomicMin(&s_tlo[y / R], t0); atomicMax(&s_thi[y / R], t1);
-            smin = min(smin, t0); smax = max(smax, t1);
-        }
-        for (int o = 32; o > 0; o >>= 1) { smin = min(smin, __shfl_xor(smin, o)); smax = max(smax, __shfl_xor(smax, o)); }
-        if (lane == 0) { atomicMin(&s_smin, smin); atomicMax(&s_smax, smax); }
-    }
-    __syncthreads();
-    const int smin = s_smin, smax = s_smax;
     const int ntiles_img = (w + OWN - 1) / OWN;
-    const int tile0 = max(0, min(((smin + smax) >> 1) / OWN - T / 2, ntiles_img - T));
-    const int gt = tile0 + tile;                              // this tile's place in the image
-    if (gt >= ntiles_img) return;                             // the set is wider than the image
-    const bool has_left = tile > 0, has_right = tile + 1 < T && gt + 1 < ntiles_img;
-    const bool out_left = !has_left && gt > 0, out_right = !has_right && gt + 1 < ntiles_img;      // real columns beyond the set
+    // what the carve-touched columns of each block mean for THIS tile, worked out once: bit 0 within reach of its own columns
+    // during the block (the tile is active), bit 1 / 2 within 64 columns of its outermost left / right column (a reserve tile
+    // may be needed there), bit 3 within three halos (prefetch)
+    __shared__ unsigned char s_flag[BT_MAX_BLK + 4];
     {
-        const int set_lo = tile0 * OWN, set_end = min((tile0 + T) * OWN, w);
-        const bool covered = (tile0 == 0 || smin >= set_lo + HALO) && (tile0 + T >= ntiles_img || smax < set_end - HALO);
-        if (!covered) {                                       // uniform over the image's tiles
-            if (tile == 0 && tid == 0) { __hip_atomic_fetch_min(c.flags + FLAG_OVF_ROW, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicAdd(&g_bt_stats[0], 1ull); }
-            return;
+        const int own_lo_ = gt * OWN, own_hi_ = min(own_lo_ + OWN, w) - 1;
+        for (int b = tid; b < nblk + 4; b += 128) {
+            unsigned f = 0;
+            if (b < nblk) {
+                const int lo = s_tlo[b], hi = s_thi[b];
+                f |= (lo <= own_hi_ + HALO + 2 && hi >= own_lo_ - HALO - 2) ? 1u : 0u;
+                f |= (lo <= own_lo_ + 2 * HALO && hi >= own_lo_ - 2 * HALO) ? 2u : 0u;
+                f |= (lo <= own_hi_ + 2 * HALO && hi >= own_hi_ - 2 * HALO) ? 4u : 0u;
+                f |= (lo <= own_hi_ + 3 * HALO + 2 && hi >= own_lo_ - 3 * HALO - 2) ? 8u : 0u;
+            }
+            s_flag[b] = (unsigned char) f;
         }
     }
-    gu64 *ex_img = (gu64 *) exch + (size_t) blockIdx.y * ((size_t) T * EX_TILE + 8);
+    if (tid == 0) { s_fail = 0; s_polled = j0; s_own_chg = 0; s_from[0] = left_from0; s_from[1] = right_from0; s_asked[0] = s_asked[1] = 0; }
+    __syncthreads();
     const float INF = __int_as_float(0x7f800000);
     const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
     const int x0 = gt * OWN - HALO + PX * lane;               // first pixel of this lane (may be < 0 or >= w)
@@ -2516,8 +2523,7 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
     for (int k = 0; k < PX; k++) in[k] = x0 + k >= 0 && x0 + k < w;
     const bool any_in = in[0] || in[1];
     const bool interior = (x0 - PX * lane >= 0) && (x0 - PX * lane + TILE <= w);
-    const int own_lo = gt * OWN, own_hi = min(own_lo + OWN, w) - 1;
-    const bool watch_l = out_left && lane == HL, watch_r = out_right && lane == 63 - HL;      // the set's outermost own columns
+    const bool real_l = gt > 0, real_r = gt + 1 < ntiles_img;          // real columns beyond this tile on that side
 
     FV q_e[R], q_mo[R];
     LV q_lo[R];
@@ -2536,9 +2542,13 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
         q_mo[R - 1] = *(const GFV *) ((const gu8 *) c.m + (((row + lo_off)) << 2));
     };
     float mp[PX] = {INF, INF};
-    bool chl[PX] = {false, false};            // changed on the block's last row
-    bool echg = false;                        // the set's outermost own column changed somewhere in the block
+    // what changed in the block, per lane, as bits in VGPRs (bit k: pixel k) -- as lane masks in SGPR pairs the four
+    // accumulators made the register allocator spill 400 SGPRs into the row loop
+    int acc_all = 0;                          // ... on any row of the block
+    int acc_early = 0;                        // ... before the block's last row (a change ON the last row reaches the columns beyond in the next block)
+    int acc_last = 0;                         // ... on the block's last row
     auto batch_u = [&](int ybase) {
+        const int nr = min(R, h - ybase);     // (the image's last block computes surplus rows from copies of its last row)
 #pragma unroll
         for (int r = 0; r < R; r++) {
             float mc[PX], e[PX], mo[PX];
@@ -2554,8 +2564,9 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
                 for (int k = 0; k < PX; k++) { mc[k] = e[k]; ch[k] = !(e[k] == mo[k]); }
                 lnew = 0;
             }
-            echg |= (watch_l && ch[0]) || (watch_r && ch[1]);
-            if (r == R - 1) { chl[0] = ch[0]; chl[1] = ch[1]; }
+            const int v = ((ch[0] ? 1 : 0) | (ch[1] ? 2 : 0)) & ((r < nr) ? -1 : 0);
+            acc_all |= v;
+            if (r < R - 1) acc_early |= v; else acc_last = v;
 #pragma unroll
             for (int k = 0; k < PX; k++) { mp[k] = mc[k]; q_mo[r][k] = mc[k]; }
             q_lo[r] = (LV) lnew;
@@ -2579,11 +2590,14 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
     auto receive = [&](int j, bool take) -> int {
         const bool halo_lane = !own_lane && any_in;
         const bool side_l = lane < 32;
-        const bool from_nbr = halo_lane && (side_l ? has_left : has_right);
-        const bool from_mem = halo_lane && (side_l ? out_left : out_right);
-        const int nb = side_l ? tile - 1 : tile + 1;
+        // a neighbour that exists from block f on publishes the hand-over for every block >= f (a reserve tile's first act is
+        // the hand-over for its first block; base tiles start at block 0, which has none)
+        const bool has_nbr = j >= (side_l ? s_from[0] : s_from[1]);
+        const bool from_nbr = halo_lane && has_nbr;
+        const bool from_mem = halo_lane && !has_nbr && (side_l ? real_l : real_r);
+        const int nb = side_l ? gt - 1 : gt + 1;
         const int col = !from_nbr ? 0 : side_l ? PX * lane : PX * (lane - 64 + HL);
-        gu64 *src = ex_img + (size_t) (from_nbr ? nb : tile) * EX_TILE + (size_t) (((j - 1) & 1) * 2 + (side_l ? 1 : 0)) * HALO + col;
+        gu64 *src = ex_img + (size_t) (from_nbr ? nb : gt) * EX_TILE + (size_t) (((j - 1) & 1) * 2 + (side_l ? 1 : 0)) * HALO + col;
         const unsigned want = ((unsigned) epoch << 13) | (unsigned) j, abort_tag = ((unsigned) epoch << 13) | BT_BLK_ABORT;
         unsigned long long g[PX];
         int spins = 0, res = 0;
@@ -2605,7 +2619,9 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
                 // not there yet: ONE lane per side watches one granule, backing off, before the full read is tried again --
                 // most tiles of a set are inactive and spend their time here; 32 lanes x 2 agent-scope loads per turn from
                 // each of them would sit in front of the active tiles' loads
-                const bool scout = from_nbr && (lane == 0 || lane == 63);
+                // (the innermost halo lane of each side: its columns are inside the image whenever the neighbour exists; the
+                // outermost ones may lie beyond the image's last column)
+                const bool scout = from_nbr && (lane == HL - 1 || lane == 64 - HL);
                 int sp = 0;
                 while (true) {
                     if (sp < 4) __builtin_amdgcn_s_sleep(1); else if (sp < 32) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(48);
@@ -2636,31 +2652,59 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
     auto publish = [&](int j_next, bool abort, bool was_active) {       // the block's last row (in mp) to both neighbours
         if (own_lane) {
             const int side = lane < 32 ? 0 : 1;
-            gu64 *dst = ex_img + (size_t) tile * EX_TILE + (size_t) (((j_next - 1) & 1) * 2 + side) * HALO + PX * (lane - (side ? 32 : HL));
+            gu64 *dst = ex_img + (size_t) gt * EX_TILE + (size_t) (((j_next - 1) & 1) * 2 + side) * HALO + PX * (lane - (side ? 32 : HL));
 #pragma unroll
             for (int k = 0; k < PX; k++) {
-                const unsigned tag = ((unsigned) epoch << 13) | (abort ? BT_BLK_ABORT : ((chl[k] ? 0x1000u : 0u) | (was_active ? 0x800u : 0u) | (unsigned) j_next));
+                const unsigned tag = ((unsigned) epoch << 13) | (abort ? BT_BLK_ABORT : ((((acc_last >> k) & 1) ? 0x1000u : 0u) | (was_active ? 0x800u : 0u) | (unsigned) j_next));
                 __hip_atomic_store(dst + k, ((unsigned long long) tag << 32) | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
-    // may the tile be active in block j?  (touched pixels of blocks ja..j within `reach` columns)
-    auto touched_near = [&](int ja, int j, int reach) -> bool {
-        bool t = false;
-        for (int b = max(ja, 0); b <= min(j, nblk - 1); b++) t |= (s_tlo[b] <= own_hi + reach && s_thi[b] >= own_lo - reach);
-        return t;
+    auto flag = [&](int b) -> unsigned { return s_flag[max(b, 0)]; };          // (blocks past the image: 0)
+    // Ask for a reserve tile beyond this one on side s (0 left, 1 right), to start with block jstart.  One wave, uniform.
+    auto ask = [&](int s, int jstart) {
+        int okv = 0;
+        if (lane == 0) {
+            const unsigned long long k = __hip_atomic_fetch_add(hdr + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k < (unsigned long long) n_rsv) {
+                const unsigned long long word = ((unsigned long long) (unsigned) epoch << 32) | ((unsigned long long) s << 31) | ((unsigned long long) jstart << 16) |
+                                                (unsigned long long) (s == 0 ? gt - 1 : gt + 1);
+                __hip_atomic_store(hdr + 2 + k, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the request is in memory before anything this tile publishes later
+                okv = 1;
+                atomicAdd(&g_bt_stats[2], 1ull);
+            } else atomicAdd(&g_bt_stats[3], 1ull);
+            s_asked[s] = 1;
+            if (okv) s_from[s] = jstart;
+        }
     };
 
-    bool staged = touched_near(q, q, HALO + 2);               // this wave's first block
-    if (q < nblk) { if (staged) issue_full(q * R); else issue_last(q * R); }
-    for (int j = 0; j < nblk; j++) {
+    // this wave's first block: the first one >= j0 of its parity
+    const int jq = j0 + (((j0 & 1) != q) ? 1 : 0);
+    bool staged = jq < nblk && (flag(jq) & 1u);
+    if (jq < nblk) { if (staged) issue_full(jq * R); else issue_last(jq * R); }
+    if (j0 == 0 && q == 0) {
+        // the seam may start within reach of an edge of the set: a reserve tile from the first block on
+        if (s_from[0] == BT_NEVER && real_l && ((flag(0) | flag(1)) & 2u)) ask(0, 0);
+        if (s_from[1] == BT_NEVER && real_r && ((flag(0) | flag(1)) & 4u)) ask(1, 0);
+    }
+    __syncthreads();
+    for (int j = j0; j < nblk; j++) {
         const int y0 = j * R;
         const bool mine = (j & 1) == q;
         bool act = false, abort = false, nbr_act = false;
+        unsigned fnext = 0;
         if (mine) {
-            if (j > 0) {
+            if (j > j0) {
                 const FV v = s_mp[lane];
                 mp[0] = v[0]; mp[1] = v[1];
+            } else if (j > 0) {
+                // a reserve tile's first block: nothing has changed in its columns so far, the row above is in memory; its
+                // first act is the hand-over of that row to the neighbour that woke it
+                const FV v = *(const GFV *) ((const gu8 *) c.m + ((((unsigned) (y0 - 1) * (unsigned) stride) + lo_off) << 2));
+                mp[0] = in[0] ? v[0] : INF; mp[1] = in[1] ? v[1] : INF;
+                acc_last = 0;
+                publish(j, false, false);
             }
             int rcv = 0;
             if (j > 0) {
@@ -2669,9 +2713,10 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
                 if (lane == 0) s_polled = j;
             }
             abort = (rcv & 2) != 0;
-            act = !abort && !(rcv & 4) && (touched_near(j, j, HALO + 2) || (j > 0 && (s_own_chg != 0 || (rcv & 1))));
-            chl[0] = chl[1] = false;
-            echg = false;
+            act = !abort && !(rcv & 4) && ((flag(j) & 1u) || (j > j0 && s_own_chg != 0) || (rcv & 1));
+            acc_all = acc_early = acc_last = 0;
+            fnext = flag(j + 1) | flag(j + 2);
+            const bool alone_l = real_l && s_from[0] > j, alone_r = real_r && s_from[1] > j;      // nobody beyond this tile during block j
             if (act) {
                 if (!staged) issue_full(y0);
                 if (!interior) {
@@ -2682,9 +2727,21 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
                         for (int k = 0; k < PX; k++) { q_e[r][k] = in[k] ? q_e[r][k] : INF; q_mo[r][k] = in[k] ? q_mo[r][k] : INF; }
                 }
                 batch_u(y0);
-                if (__any(echg)) {
-                    // the change front has reached the edge of the set: this block stays unstored, rows from y0 on are the
-                    // full-width sweep's
+                // grow the set: a change has entered this edge tile's outer 32 columns (it cannot pass the outermost one before
+                // the block's last row), or the seam comes within 64 columns of the edge in the next two blocks
+                if (j + 1 < nblk) {
+                    const bool zl = __any(acc_all != 0 && own_lane && lane < 32), zr = __any(acc_all != 0 && own_lane && lane >= 32);
+                    if (real_l && s_from[0] == BT_NEVER && !s_asked[0] && (zl || (fnext & 2u))) ask(0, j + 1);
+                    if (real_r && s_from[1] == BT_NEVER && !s_asked[1] && (zr || (fnext & 4u))) ask(1, j + 1);
+                }
+                __builtin_amdgcn_wave_barrier();
+                // nobody beyond the outermost own column during this block: it must not have changed before the block's last
+                // row, and if it changed ON the last row somebody must be there from the next block on
+                const bool last_l = __any((acc_last & 1) && lane == HL), last_r = __any((acc_last & 2) && lane == 63 - HL);
+                const int fl = *(volatile int *) &s_from[0], fr = *(volatile int *) &s_from[1];
+                if ((alone_l && (__any((acc_early & 1) && lane == HL) || (last_l && j + 1 < nblk && fl > j + 1))) ||
+                    (alone_r && (__any((acc_early & 2) && lane == 63 - HL) || (last_r && j + 1 < nblk && fr > j + 1)))) {
+                    // this block stays unstored, rows from y0 on are the full-width sweep's
                     if (lane == 0) __hip_atomic_fetch_min(c.flags + FLAG_OVF_ROW, y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     BT_STAT(1);
                     abort = true;
@@ -2693,6 +2750,10 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
                 // nothing can change in this block: hand the stored last row on
                 const FV v = q_mo[R - 1];
                 mp[0] = in[0] ? v[0] : INF; mp[1] = in[1] ? v[1] : INF;
+                if (j + 1 < nblk) {      // the seam may still be heading for this edge
+                    if (real_l && s_from[0] == BT_NEVER && !s_asked[0] && (fnext & 2u)) ask(0, j + 1);
+                    if (real_r && s_from[1] == BT_NEVER && !s_asked[1] && (fnext & 4u)) ask(1, j + 1);
+                }
             }
             {
                 FV v;
@@ -2700,10 +2761,10 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
                 s_mp[lane] = v;
             }
             if (lane == 0) s_own_chg = 0;
-            if (__any(own_lane && (chl[0] || chl[1])) && lane == 0) s_own_chg = 1;
+            if (__any(own_lane && acc_last != 0) && lane == 0) s_own_chg = 1;
             if (abort) s_fail = 1;
-            publish(j + 1, abort, act);
-            nbr_act = (rcv & 8) != 0;               // j + 1 == nblk: "done" (the neighbours wait for it before their last store)
+            publish(j + 1, abort, act);               // j + 1 == nblk: "done" (the neighbours wait for it before their last store)
+            nbr_act = (rcv & 8) != 0;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (s_fail) return;                      // uniform: written before the barrier
@@ -2718,13 +2779,96 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
             if (act) store_u(y0);
             const int j2 = j + 2;
             if (j2 < nblk) {
-                staged = act || nbr_act || touched_near(j + 1, j2, 3 * HALO + 2);      // an active neighbour's band may arrive within two blocks
+                staged = act || nbr_act || (fnext & 8u);      // an active neighbour's band may arrive within two blocks
                 if (staged) issue_full(j2 * R); else issue_last(j2 * R);
             }
         }
     }
 }
 
+template <bool LR, bool RIG>
+__global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err, int t_base)
+{
+    constexpr int OWN = 64, HALO = 32, EX_TILE = 2 * 2 * HALO, R = 32;
+    typedef GLOBAL_AS unsigned long long gu64;
+    __shared__ int s_tlo[BT_MAX_BLK], s_thi[BT_MAX_BLK];      // per block: columns the carve touched on its rows
+    __shared__ int s_smin, s_smax;
+    __shared__ unsigned long long s_req;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n_rsv = (int) gridDim.x - t_base, slot = (int) blockIdx.x;
+    const int nblk = (h + R - 1) / R;
+    const int ntiles_img = (w + OWN - 1) / OWN;
+    const GCarver c = gview(cs[blockIdx.y]);
+    gu64 *hdr = (gu64 *) exch + (size_t) blockIdx.y * BT_HDR;
+    gu64 *ex_img = (gu64 *) exch + (size_t) gridDim.y * BT_HDR + (size_t) blockIdx.y * ((size_t) ntiles_img * EX_TILE);
+    int gt, j0 = 0, lf = BT_NEVER, rf = BT_NEVER;
+    if (slot >= t_base) {
+        // a reserve tile: wait until an edge tile of this image asks for it, or until all base tiles are done
+        const int r = slot - t_base;
+        if (tid == 0) {
+            unsigned long long word = 0;
+            int sp = 0;
+            while (true) {
+                word = __hip_atomic_load(hdr + 2 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned) (word >> 32) == (unsigned) epoch) break;
+                if (__hip_atomic_load(hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long) t_base) {
+                    // every request precedes the last base tile's end: one more look
+                    word = __hip_atomic_load(hdr + 2 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned) (word >> 32) != (unsigned) epoch) word = 0;
+                    break;
+                }
+                if (sp < 16) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
+                if ((++sp & 255) == 0 && dev_failed(dev_err)) { word = 0; break; }
+                if (sp > (1 << 22)) { word = 0; break; }
+            }
+            s_req = word;
+        }
+        __syncthreads();
+        const unsigned long long word = s_req;
+        if ((unsigned) (word >> 32) != (unsigned) epoch) return;
+        gt = (int) (word & 0xffffu); j0 = (int) ((word >> 16) & 0x7fffu);
+        if ((word >> 31) & 1) lf = j0; else rf = j0;          // asked for on the right of a tile: that tile is its left neighbour
+    }
+    // carve-touched columns per block, and over the whole image (base tiles derive the set's placement from them)
+    for (int i = tid; i < nblk; i += 128) { s_tlo[i] = 1 << 30; s_thi[i] = -1; }
+    if (tid == 0) { s_smin = 1 << 30; s_smax = -1; }
+    __syncthreads();
+    {
+        int smin = 1 << 30, smax = -1;
+        for (int y = tid; y < h; y += 128) {        // pixels of row y whose inputs the carve changed (as k_band_update_tw)
+            const int v0 = c.seam_x[y], vm = c.seam_x[max(y - 1, 0)], vp = c.seam_x[min(y + 1, h - 1)];
+            const int t0 = max(min(min(v0, vm), vp) - 2, 0), t1 = min(max(max(v0, vm), vp) + 1, w - 1);
+            atomicMin(&s_tlo[y / R], t0); atomicMax(&s_thi[y / R], t1);
+            smin = min(smin, t0); smax = max(smax, t1);
+        }
+        for (int o = 32; o > 0; o >>= 1) { smin = min(smin, __shfl_xor(smin, o)); smax = max(smax, __shfl_xor(smax, o)); }
+        if (lane == 0) { atomicMin(&s_smin, smin); atomicMax(&s_smax, smax); }
+    }
+    __syncthreads();
+    if (slot < t_base) {
+        const int smin = s_smin, smax = s_smax;
+        const int tile0 = max(0, min(((smin + smax) >> 1) / OWN - t_base / 2, ntiles_img - t_base));
+        gt = tile0 + slot;
+        bool run = gt < ntiles_img;                           // (the set may be wider than the image)
+        if (run) {
+            const int set_lo = tile0 * OWN, set_end = min((tile0 + t_base) * OWN, w);
+            const bool covered = (tile0 == 0 || smin >= set_lo + HALO) && (tile0 + t_base >= ntiles_img || smax < set_end - HALO);
+            if (!covered) {                                   // uniform over the image's base tiles
+                if (slot == 0 && tid == 0) { __hip_atomic_fetch_min(c.flags + FLAG_OVF_ROW, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicAdd(&g_bt_stats[0], 1ull); }
+                run = false;
+            }
+        }
+        if (run) {
+            if (slot > 0) lf = 0;
+            if (slot + 1 < t_base && gt + 1 < ntiles_img) rf = 0;
+            band_tile_run<LR, RIG>(c, p, w, h, stride, hdr, ex_img, epoch, dev_err, n_rsv, gt, 0, lf, rf, s_tlo, s_thi);
+        }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(hdr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // this base tile is done
+    } else {
+        band_tile_run<LR, RIG>(c, p, w, h, stride, hdr, ex_img, epoch, dev_err, n_rsv, gt, j0, lf, rf, s_tlo, s_thi);
+    }
+}
 extern "C" int lqrhip_band_tiles_stats(unsigned long long *out, int reset)
 {
     (void) hipDeviceSynchronize();
@@ -3961,12 +4105,20 @@ static int band_tiles_T(const LqrHipBatch *b, int h)
     if (g_band_tiles > 0) T = std::min(T, g_band_tiles);
     return T >= (g_band_tiles > 0 ? 1 : 8) ? T : 0;
 }
+// T workgroups per image: two thirds of them base tiles around the seam, the rest reserve tiles that an edge tile wakes
+// when the band comes near the edge of the set (lqrhip_set_band_tiles_reserve pins the number of reserves for tests)
+static int g_band_tiles_rsv = -1;
+extern "C" void lqrhip_set_band_tiles_reserve(int n) { g_band_tiles_rsv = n; }
 static int launch_band_tiles(LqrHipBatch *b, const DpK &k, int w, int h, int lr, int T)
 {
     LqrHipCarver *c0 = b->cs[0];
     const size_t n = b->cs.size();
     int rc;
-    const size_t need_elems = ((size_t) T * dpp_ex_tile(2) + 8) * n;
+    int n_rsv = g_band_tiles_rsv >= 0 ? std::min(g_band_tiles_rsv, T - 1) : T / 3;
+    n_rsv = std::max(0, std::min(n_rsv, BT_HDR - 2));
+    const int t_base = T - n_rsv;
+    const int ntiles_img = (w + 63) / 64;
+    const size_t need_elems = ((size_t) ntiles_img * dpp_ex_tile(2) + BT_HDR) * n;
     if (b->exch_elems < need_elems) {
         HIPCK(hipStreamSynchronize(b->stream));
         dfree(b->exch);
@@ -3975,13 +4127,17 @@ static int launch_band_tiles(LqrHipBatch *b, const DpK &k, int w, int h, int lr,
         b->exch_elems = need_elems;
         b->exch_ntiles = 0;
     }
-    if (b->exch_ntiles != T || b->exch_n != (int) n || b->exch_px != 102) {       // 102: this kernel's tag layout
+    if (b->exch_ntiles != ntiles_img || b->exch_n != (int) n || b->exch_px != 102) {       // 102: this kernel's layout and tags
         HIPCK(hipMemsetAsync(b->exch, 0, need_elems * sizeof(unsigned long long), b->stream));
-        b->exch_ntiles = T; b->exch_n = (int) n; b->exch_px = 102;
+        b->exch_ntiles = ntiles_img; b->exch_n = (int) n; b->exch_px = 102;
+    } else {
+        // the images' headers (base tiles finished, requests made) start every launch at zero; granules and request words
+        // carry the launch epoch
+        HIPCK(hipMemsetAsync(b->exch, 0, n * BT_HDR * sizeof(unsigned long long), b->stream));
     }
-    const int epoch = 1 + ((b->tile_epoch++) % ((1 << 19) - 2));           // never 0; 19 bits above changed-bit and block index
+    const int epoch = 1 + ((b->tile_epoch++) % ((1 << 19) - 2));           // never 0; 19 bits above changed / active bits and block index
     const dim3 grid(T, (unsigned) n);
-#define LAUNCH_BT(LRV, RIGV) hipLaunchKernelGGL((k_band_tiles<LRV, RIGV>), grid, dim3(128), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
+#define LAUNCH_BT(LRV, RIGV) hipLaunchKernelGGL((k_band_tiles<LRV, RIGV>), grid, dim3(128), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err, t_base)
     if (lr) { if (k.use_rig) LAUNCH_BT(true, true); else LAUNCH_BT(true, false); }
     else { if (k.use_rig) LAUNCH_BT(false, true); else LAUNCH_BT(false, false); }
 #undef LAUNCH_BT
@@ -4092,15 +4248,15 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     const bool tiled_update = fast_ok ? ((g_update_mode < 0 ? (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px : g_update_mode == 1) &&
                                          dp_persistent_ok(b, w))
                                       : (p->delta_x >= 1 && p->delta_x <= 4 && g_update_mode != 0 && g_update_mode != 2 && g_update_mode != 3 && dp_persistent_px(b, w, true, p->delta_x) != 0);
-    // Batches of 8 to ~48 images: the band spread over several CUs per image (k_band_tiles).  Measured (Mseams*px/s, 4K, tiles /
-    // before): 4 images 80 k / 93 k (the full-width tiled update stays), 8: 144 / 127, 12: 195 / 152, 16: 239 / 193, 24: 294 /
-    // 260, 32: 375 / 341, 40: 423 / 398, 48: 456 / 448, 56: 486 / 485, 64: 486 / 543 -- beyond ~600 resident tile workgroups
-    // the carves of the sibling streams are starved of registers and an aborted image per launch becomes the rule
-    // (DESIGN.md 4.15), so large groups keep k_band_update_tw.
+    // Batches of 8 to ~40 images: the band spread over several CUs per image (k_band_tiles).  Measured (Mseams*px/s, 4K, tiles /
+    // k_band_update_tw or the full-width tiled update): 4 images 80 k / 93 k (the full-width tiled update stays), 8: 145 / 127,
+    // 12: 195 / 152, 16: 246 / 193, 24: 294 / 260, 32: 382 / 341, 40: 423 / 398, 48: 434 / 448, 64: 488 / 510-540 -- beyond ~500
+    // resident tile workgroups the carves of the sibling streams are starved of registers, so large groups
+    // keep k_band_update_tw.
     {
         const int T = (fast_ok && (g_update_mode < 0 || g_update_mode == 4)) ? band_tiles_T(b, h) : 0;
         const size_t group_images = (size_t) n * (size_t) std::max(b->shared_n, 1);
-        if (T > 0 && (g_update_mode == 4 || (group_images >= 8 && group_images * (size_t) T <= 576))) {
+        if (T > 0 && (g_update_mode == 4 || (group_images >= 8 && group_images * (size_t) T <= 480))) {
             {
                 ProfScope ps("band_update", b->stream, 0);
                 if ((rc = launch_band_tiles(b, k, wnew, h, leftright_next, T))) return rc;

@@ -90,6 +90,8 @@ int lqrhip_sub_batches(int n);
 int lqrhip_general_batch_limit(int w);
 /* Test hook: tiles per image of the multi-CU band update k_band_tiles (-1 automatic, 0 never, n at most n). */
 void lqrhip_set_band_tiles(int tiles);
+/* Test hook: how many of those are reserve tiles, woken when the band nears the edge of the set (-1: a third of them). */
+void lqrhip_set_band_tiles_reserve(int n);
 void lqrhip_set_sub_batches(int n);
 LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n);
 /* tell a batch how many batches of its group run concurrently on their own streams (0 or 1: alone): kernels whose grid

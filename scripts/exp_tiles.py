@@ -9,10 +9,11 @@ import lqr_ctypes as L
 n, W, px = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 bt = int(sys.argv[5]) if len(sys.argv) > 5 else -1
+rsv = int(sys.argv[6]) if len(sys.argv) > 6 else -1
 H, seams = 2160, 24
 eng = L.engine_api(); lib = eng.lib
-for f in ("lqrhip_set_update_mode", "lqrhip_set_sub_batches", "lqrhip_set_dp_persistent_px", "lqrhip_set_band_tiles"): getattr(lib, f).argtypes = [C.c_int]
-lib.lqrhip_set_band_tiles(bt)
+for f in ("lqrhip_set_update_mode", "lqrhip_set_sub_batches", "lqrhip_set_dp_persistent_px", "lqrhip_set_band_tiles", "lqrhip_set_band_tiles_reserve"): getattr(lib, f).argtypes = [C.c_int]
+lib.lqrhip_set_band_tiles(bt); lib.lqrhip_set_band_tiles_reserve(rsv)
 lib.lqrhip_set_update_mode(mode); lib.lqrhip_set_sub_batches(1); lib.lqrhip_set_dp_persistent_px(px)
 rng = np.random.default_rng(1)
 cs = [L.Carver(eng, rng.integers(0, 256, (H, W, 4), dtype=np.uint8)).configure(switch_freq=0) for _ in range(n)]
@@ -26,6 +27,6 @@ for k in ("vpath", "carve", "emap_update", "band_update", "dp_update_tiled", "dp
     lib.lqrhip_prof_get(k.encode(), C.byref(ms), C.byref(cnt), C.byref(by))
     if cnt.value: out.append("%s %.1f us x %d" % (k, ms.value * 1e3 / cnt.value, cnt.value))
 st = (C.c_ulonglong * 8)(); lib.lqrhip_band_tiles_stats(st, 1)
-print("mode %d bt %d stats %s:" % (mode, bt, list(st)[:5]), end=" ")
+print("mode %d bt %d rsv %d stats [uncov, abort, woken, norsv] %s:" % (mode, bt, rsv, list(st)[:8]), end=" ")
 print("%d images of %dx%d, %d px per lane (%d tiles): %s" % (n, W, H, px, n * ((W + (64 * px - 32 * px) - 1) // (64 * px - 32 * px)), "; ".join(out)), flush=True)
 for c in cs: c.destroy()

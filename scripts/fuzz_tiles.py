@@ -14,7 +14,7 @@ max_cases = int(os.environ.get("FUZZ_COUNT", "0"))
 rng = np.random.default_rng(seed)
 o, e = L.oracle_api(), L.engine_api()
 lib = e.lib
-lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]; lib.lqrhip_set_band_tiles.argtypes = [ctypes.c_int]
+lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]; lib.lqrhip_set_band_tiles.argtypes = [ctypes.c_int]; lib.lqrhip_set_band_tiles_reserve.argtypes = [ctypes.c_int]
 t_end = time.time() + budget
 n = fails = 0
 try:
@@ -24,7 +24,8 @@ try:
         if rng.random() < 0.5:
             kw["switch_freq"] = 0
         T = int(rng.choice([1, 2, 3, 4, 6, 8, 12]))
-        lib.lqrhip_set_update_mode(4); lib.lqrhip_set_band_tiles(T)
+        rsv = int(rng.integers(-1, T))             # reserve tiles among them (-1: the engine's third)
+        lib.lqrhip_set_update_mode(4); lib.lqrhip_set_band_tiles(T); lib.lqrhip_set_band_tiles_reserve(rsv)
         planes = kw.get("switch_freq") == 0 and nh == img.shape[0] and nw < img.shape[1]
         try:
             if planes:
@@ -41,11 +42,11 @@ try:
             ca.destroy(); cb.destroy()
         except AssertionError as ex:
             fails += 1
-            print("FAIL case %d T=%d %s: %s" % (n, T, what, str(ex)[:120]), flush=True)
+            print("FAIL case %d T=%d rsv=%d %s: %s" % (n, T, rsv, what, str(ex)[:120]), flush=True)
         finally:
             o.lqrx_set_debug(0); e.lqrx_set_debug(0)
         n += 1
 finally:
-    lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_tiles(-1)
+    lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_tiles(-1); lib.lqrhip_set_band_tiles_reserve(-1)
 print("tiles fuzz: %d cases, %d failures, seed %d" % (n, fails, seed), flush=True)
 sys.exit(1 if fails else 0)
