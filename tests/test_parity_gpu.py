@@ -21,7 +21,7 @@ def update_mode(request, engine):
     """Every test runs four times: with the engine's default choice of update_mmap kernel (the tiled
     full-width sweep at these sizes), with the band kernel the large batches use, with the
     per-row-barrier band kernel k_band_update_mw (the default for rows wider than 4200 px), and with the
-    multi-CU band update k_band_tiles (round 4: batches of 8 to ~48 images)."""
+    multi-CU band update k_band_tiles (round 4: batches of 8 to ~40 images)."""
     import ctypes
     lib = engine.lib
     lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]

@@ -80,7 +80,7 @@ def test_band_tiles_seeded_cases_with_forced_tile_counts():
 
 
 def test_band_tiles_batch_of_12_images(oracle, engine):
-    """a lock-step batch of the size the engine itself sends to k_band_tiles (8 to ~48 images): every image against the oracle"""
+    """a lock-step batch of the size the engine itself sends to k_band_tiles (8 to ~40 images): every image against the oracle"""
     import ctypes
     lib = engine.lib
     n, w, h = 12, 1200, 330
