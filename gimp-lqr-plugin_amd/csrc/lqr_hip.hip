@@ -2461,6 +2461,14 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
 // [0] images not covered by their tile set, [1] images aborted at an edge, [2] reserve tiles woken, [3] requests that found
 // no reserve left (rare events: one atomic each)
 __device__ unsigned long long g_bt_stats[8];
+#ifdef LQR_BT_TIMING
+// per tile slot of image 0 and wave: cycles in [0] receive, [1] compute, [2] rest before the barrier, [3] barrier, [4] wait for the partner's poll,
+// [5] stores, [6] prefetch issue, [7] active blocks, [8] whole kernel
+__device__ unsigned long long g_bt_time[16][2][10];
+#define BTT(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); btt[i] += t__ - btprev; btprev = t__; } while (0)
+#else
+#define BTT(i) do { } while (0)
+#endif
 #define BT_STAT(i) do { if (lane == 0) atomicAdd(&g_bt_stats[i], 1ull); } while (0)
 constexpr int BT_MAX_BLK = 256;           // blocks of 32 rows: images up to 8192 rows (the tag has 11 bits for the block)
 constexpr int BT_T_MAX = 12;              // workgroups per image: base tiles + reserve tiles
@@ -2486,6 +2494,7 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
     __shared__ int s_fail;                        // leave at the next barrier: a neighbour timed out, or the image was aborted
     __shared__ volatile int s_polled;             // last block whose hand-over this workgroup has received
     __shared__ int s_own_chg;                     // an own pixel changed on the last row of the block just finished
+    __shared__ volatile int s_nbr_live;           // the hand-over last received says a neighbour was active or changed at its edge
     __shared__ int s_from[2];                     // first block with a left / right neighbour
     __shared__ int s_asked[2];                    // a reserve tile was asked for on that side (or there is none left)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2510,7 +2519,7 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
             s_flag[b] = (unsigned char) f;
         }
     }
-    if (tid == 0) { s_fail = 0; s_polled = j0; s_own_chg = 0; s_from[0] = left_from0; s_from[1] = right_from0; s_asked[0] = s_asked[1] = 0; }
+    if (tid == 0) { s_fail = 0; s_polled = j0; s_own_chg = 0; s_nbr_live = 0; s_from[0] = left_from0; s_from[1] = right_from0; s_asked[0] = s_asked[1] = 0; }
     __syncthreads();
     const float INF = __int_as_float(0x7f800000);
     const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
@@ -2542,11 +2551,13 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
         q_mo[R - 1] = *(const GFV *) ((const gu8 *) c.m + (((row + lo_off)) << 2));
     };
     float mp[PX] = {INF, INF};
-    // what changed in the block, per lane, as bits in VGPRs (bit k: pixel k) -- as lane masks in SGPR pairs the four
-    // accumulators made the register allocator spill 400 SGPRs into the row loop
-    int acc_all = 0;                          // ... on any row of the block
-    int acc_early = 0;                        // ... before the block's last row (a change ON the last row reaches the columns beyond in the next block)
-    int acc_last = 0;                         // ... on the block's last row
+    // What changed in the block, per lane.  "Changed" = the stored m of the pixel has other bits than before: that is all a
+    // child row can see of its parents (the keep rule of a child looks at its OWN old pair and its parents' m), so it is exactly
+    // what has to travel on.  Accumulated as XORs in VGPRs: two v_xor + two v_or per row -- as lane masks in SGPR pairs (`bool`s
+    // of the `changed` flags) four accumulators made the register allocator spill 400 SGPRs into the row loop.
+    int acc_e0 = 0, acc_e1 = 0;               // pixel 0 / 1 of the lane, rows before the block's last one (a change ON the last
+                                              // row reaches the columns beyond in the next block)
+    int acc_l0 = 0, acc_l1 = 0;               // ... on the block's last row
     auto batch_u = [&](int ybase) {
         const int nr = min(R, h - ybase);     // (the image's last block computes surplus rows from copies of its last row)
 #pragma unroll
@@ -2561,12 +2572,12 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
             dp_row<PX, LR, RIG, true, false>(mp, left, right, e, mo, (uint32_t) q_lo[r], in, rig_l, rig_r, mc, lnew, ch);
             if (r == 0 && ybase == 0) {          // row 0: m = en, whatever stood there (update_mmap's first row)
 #pragma unroll
-                for (int k = 0; k < PX; k++) { mc[k] = e[k]; ch[k] = !(e[k] == mo[k]); }
+                for (int k = 0; k < PX; k++) mc[k] = e[k];
                 lnew = 0;
             }
-            const int v = ((ch[0] ? 1 : 0) | (ch[1] ? 2 : 0)) & ((r < nr) ? -1 : 0);
-            acc_all |= v;
-            if (r < R - 1) acc_early |= v; else acc_last = v;
+            const int msk = (r < nr) ? -1 : 0;
+            const int x0b = (__float_as_int(mc[0]) ^ __float_as_int(mo[0])) & msk, x1b = (__float_as_int(mc[1]) ^ __float_as_int(mo[1])) & msk;
+            if (r < R - 1) { acc_e0 |= x0b; acc_e1 |= x1b; } else { acc_l0 = x0b; acc_l1 = x1b; }
 #pragma unroll
             for (int k = 0; k < PX; k++) { mp[k] = mc[k]; q_mo[r][k] = mc[k]; }
             q_lo[r] = (LV) lnew;
@@ -2655,7 +2666,7 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
             gu64 *dst = ex_img + (size_t) gt * EX_TILE + (size_t) (((j_next - 1) & 1) * 2 + side) * HALO + PX * (lane - (side ? 32 : HL));
 #pragma unroll
             for (int k = 0; k < PX; k++) {
-                const unsigned tag = ((unsigned) epoch << 13) | (abort ? BT_BLK_ABORT : ((((acc_last >> k) & 1) ? 0x1000u : 0u) | (was_active ? 0x800u : 0u) | (unsigned) j_next));
+                const unsigned tag = ((unsigned) epoch << 13) | (abort ? BT_BLK_ABORT : (((k == 0 ? acc_l0 : acc_l1) != 0 ? 0x1000u : 0u) | (was_active ? 0x800u : 0u) | (unsigned) j_next));
                 __hip_atomic_store(dst + k, ((unsigned long long) tag << 32) | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -2679,6 +2690,11 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
         }
     };
 
+#ifdef LQR_BT_TIMING
+    unsigned long long btt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long btprev = __builtin_readcyclecounter();
+    const unsigned long long btstart = btprev;
+#endif
     // this wave's first block: the first one >= j0 of its parity
     const int jq = j0 + (((j0 & 1) != q) ? 1 : 0);
     bool staged = jq < nblk && (flag(jq) & 1u);
@@ -2703,18 +2719,20 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
                 // first act is the hand-over of that row to the neighbour that woke it
                 const FV v = *(const GFV *) ((const gu8 *) c.m + ((((unsigned) (y0 - 1) * (unsigned) stride) + lo_off) << 2));
                 mp[0] = in[0] ? v[0] : INF; mp[1] = in[1] ? v[1] : INF;
-                acc_last = 0;
+                acc_l0 = acc_l1 = 0;
                 publish(j, false, false);
             }
+            BTT(2);
             int rcv = 0;
             if (j > 0) {
                 rcv = receive(j, true);
                 if (rcv & 4) s_fail = 1;
-                if (lane == 0) s_polled = j;
+                if (lane == 0) { s_nbr_live = (rcv & 9) != 0; s_polled = j; }
             }
+            BTT(0);
             abort = (rcv & 2) != 0;
             act = !abort && !(rcv & 4) && ((flag(j) & 1u) || (j > j0 && s_own_chg != 0) || (rcv & 1));
-            acc_all = acc_early = acc_last = 0;
+            acc_e0 = acc_e1 = acc_l0 = acc_l1 = 0;
             fnext = flag(j + 1) | flag(j + 2);
             const bool alone_l = real_l && s_from[0] > j, alone_r = real_r && s_from[1] > j;      // nobody beyond this tile during block j
             if (act) {
@@ -2726,21 +2744,27 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
 #pragma unroll
                         for (int k = 0; k < PX; k++) { q_e[r][k] = in[k] ? q_e[r][k] : INF; q_mo[r][k] = in[k] ? q_mo[r][k] : INF; }
                 }
+                BTT(2);
                 batch_u(y0);
+                BTT(1);
+#ifdef LQR_BT_TIMING
+                btt[7]++;
+#endif
                 // grow the set: a change has entered this edge tile's outer 32 columns (it cannot pass the outermost one before
                 // the block's last row), or the seam comes within 64 columns of the edge in the next two blocks
                 if (j + 1 < nblk) {
-                    const bool zl = __any(acc_all != 0 && own_lane && lane < 32), zr = __any(acc_all != 0 && own_lane && lane >= 32);
+                    const bool any_chg = (acc_e0 | acc_e1 | acc_l0 | acc_l1) != 0;
+                    const bool zl = __any(any_chg && own_lane && lane < 32), zr = __any(any_chg && own_lane && lane >= 32);
                     if (real_l && s_from[0] == BT_NEVER && !s_asked[0] && (zl || (fnext & 2u))) ask(0, j + 1);
                     if (real_r && s_from[1] == BT_NEVER && !s_asked[1] && (zr || (fnext & 4u))) ask(1, j + 1);
                 }
                 __builtin_amdgcn_wave_barrier();
                 // nobody beyond the outermost own column during this block: it must not have changed before the block's last
                 // row, and if it changed ON the last row somebody must be there from the next block on
-                const bool last_l = __any((acc_last & 1) && lane == HL), last_r = __any((acc_last & 2) && lane == 63 - HL);
+                const bool last_l = __any(acc_l0 != 0 && lane == HL), last_r = __any(acc_l1 != 0 && lane == 63 - HL);
                 const int fl = *(volatile int *) &s_from[0], fr = *(volatile int *) &s_from[1];
-                if ((alone_l && (__any((acc_early & 1) && lane == HL) || (last_l && j + 1 < nblk && fl > j + 1))) ||
-                    (alone_r && (__any((acc_early & 2) && lane == 63 - HL) || (last_r && j + 1 < nblk && fr > j + 1)))) {
+                if ((alone_l && (__any(acc_e0 != 0 && lane == HL) || (last_l && j + 1 < nblk && fl > j + 1))) ||
+                    (alone_r && (__any(acc_e1 != 0 && lane == 63 - HL) || (last_r && j + 1 < nblk && fr > j + 1)))) {
                     // this block stays unstored, rows from y0 on are the full-width sweep's
                     if (lane == 0) __hip_atomic_fetch_min(c.flags + FLAG_OVF_ROW, y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     BT_STAT(1);
@@ -2761,12 +2785,14 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
                 s_mp[lane] = v;
             }
             if (lane == 0) s_own_chg = 0;
-            if (__any(own_lane && acc_last != 0) && lane == 0) s_own_chg = 1;
+            if (__any(own_lane && (acc_l0 | acc_l1) != 0) && lane == 0) s_own_chg = 1;
             if (abort) s_fail = 1;
             publish(j + 1, abort, act);               // j + 1 == nblk: "done" (the neighbours wait for it before their last store)
             nbr_act = (rcv & 8) != 0;
         }
+        BTT(2);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        BTT(3);
         if (s_fail) return;                      // uniform: written before the barrier
         if (mine) {
             if (j + 1 < nblk) {
@@ -2776,14 +2802,22 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
             } else if (act) {
                 if (receive(nblk, false) & 6) continue;            // (aborted neighbours: their rows are the sweep's anyway)
             }
+            BTT(4);
             if (act) store_u(y0);
+            BTT(5);
             const int j2 = j + 2;
             if (j2 < nblk) {
-                staged = act || nbr_act || (fnext & 8u);      // an active neighbour's band may arrive within two blocks
+                // (the partner has just received the hand-over for block j + 1: what it says about the neighbours' block j is one
+                // block fresher than this wave's own knowledge)
+                staged = act || nbr_act || s_nbr_live != 0 || (fnext & 8u);      // an active neighbour's band may arrive within two blocks
                 if (staged) issue_full(j2 * R); else issue_last(j2 * R);
             }
+            BTT(6);
         }
     }
+#ifdef LQR_BT_TIMING
+    if (blockIdx.y == 0 && lane == 0 && blockIdx.x < 16) { btt[8] = __builtin_readcyclecounter() - btstart; for (int i = 0; i < 10; i++) g_bt_time[blockIdx.x][q][i] = btt[i]; }
+#endif
 }
 
 template <bool LR, bool RIG>
@@ -2869,6 +2903,9 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
         band_tile_run<LR, RIG>(c, p, w, h, stride, hdr, ex_img, epoch, dev_err, n_rsv, gt, j0, lf, rf, s_tlo, s_thi);
     }
 }
+#ifdef LQR_BT_TIMING
+extern "C" int lqrhip_band_tiles_timing(unsigned long long *out) { (void) hipDeviceSynchronize(); return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bt_time), sizeof(unsigned long long) * 320) == hipSuccess ? 0 : -1; }
+#endif
 extern "C" int lqrhip_band_tiles_stats(unsigned long long *out, int reset)
 {
     (void) hipDeviceSynchronize();
