@@ -2446,8 +2446,10 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
 //     there it cannot pass the outermost column before the block's last row, so a tile that starts with the NEXT block is
 //     in time -- or when the seam comes within 64 columns of the edge in the next two blocks.  The woken tile takes the
 //     row above its first block from memory (nothing has changed there yet), hands it to the tile that asked, and joins
-//     the protocol; it may ask for the next one.  Reserve tiles nobody asked for leave when all base tiles are done
-//     (every request precedes the last base tile's end; the asker drains the request store before it publishes anything
+//     the protocol; it may ask for the next one.  Every tile that ran counts itself in the image's header when it is done;
+//     a reserve tile nobody asked for leaves when as many are done as were ever started (base tiles + tickets drawn, the
+//     ticket count unchanged around the read: nobody is left who could ask; the asker drains the request store before it
+//     publishes anything
 //     later).  Only if no reserve is left and a change reaches the outermost own column before a block's last row does the
 //     image stop: the block is not stored, its first row goes to flags[FLAG_OVF_ROW] (atomic min), and ABORT granules tell
 //     the neighbours, which pass them on and leave.  Every row below the recorded one is then redone by k_dp_sweep<UPDATE>
@@ -2821,7 +2823,8 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
 }
 
 template <bool LR, bool RIG>
-__global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err, int t_base)
+// (two waves per SIMD, as the residency bound assumes: left alone the max-ilp scheduler spreads the 32-row loop over 262 registers)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_band_tiles(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err, int t_base)
 {
     constexpr int OWN = 64, HALO = 32, EX_TILE = 2 * 2 * HALO, R = 32;
     typedef GLOBAL_AS unsigned long long gu64;
@@ -2837,7 +2840,13 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
     gu64 *ex_img = (gu64 *) exch + (size_t) gridDim.y * BT_HDR + (size_t) blockIdx.y * ((size_t) ntiles_img * EX_TILE);
     int gt, j0 = 0, lf = BT_NEVER, rf = BT_NEVER;
     if (slot >= t_base) {
-        // a reserve tile: wait until an edge tile of this image asks for it, or until all base tiles are done
+        // a reserve tile: wait until an edge tile of this image asks for it, or until nobody is left who could.  Tiles that
+        // run are the base tiles and the reserves whose ticket has been drawn; each counts itself in hdr[0] when it is done.
+        // With K tickets drawn (hdr[1], monotone) and K unchanged around a read of hdr[0] that says t_base + K tiles are
+        // done, every tile that was ever started has ended: no request can follow.  (The first version left when the BASE
+        // tiles were done: a request of reserve tile A precedes the hand-over that lets its neighbour go on, but with a
+        // second reserve B beyond A the base tiles can be a block ahead of B's last request -- one time-out in 7 000 fuzz
+        // cases, on images of few blocks.)
         const int r = slot - t_base;
         if (tid == 0) {
             unsigned long long word = 0;
@@ -2845,11 +2854,13 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
             while (true) {
                 word = __hip_atomic_load(hdr + 2 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned) (word >> 32) == (unsigned) epoch) break;
-                if (__hip_atomic_load(hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long) t_base) {
-                    // every request precedes the last base tile's end: one more look
-                    word = __hip_atomic_load(hdr + 2 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned) (word >> 32) != (unsigned) epoch) word = 0;
-                    break;
+                const unsigned long long k0 = __hip_atomic_load(hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (k0 <= (unsigned long long) r) {         // (else: this tile's ticket is drawn, the word is on its way)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned long long fin = __hip_atomic_load(hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned long long k1 = __hip_atomic_load(hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (k1 == k0 && fin >= (unsigned long long) t_base + k0) { word = 0; break; }
                 }
                 if (sp < 16) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
                 if ((++sp & 255) == 0 && dev_failed(dev_err)) { word = 0; break; }
@@ -2898,9 +2909,11 @@ __global__ __launch_bounds__(128) void k_band_tiles(DevCarver *cs, DpK p, int w,
             band_tile_run<LR, RIG>(c, p, w, h, stride, hdr, ex_img, epoch, dev_err, n_rsv, gt, 0, lf, rf, s_tlo, s_thi);
         }
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(hdr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // this base tile is done
+        if (tid == 0) __hip_atomic_fetch_add(hdr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // this base tile is done (or never ran)
     } else {
         band_tile_run<LR, RIG>(c, p, w, h, stride, hdr, ex_img, epoch, dev_err, n_rsv, gt, j0, lf, rf, s_tlo, s_thi);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(hdr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // this reserve tile is done
     }
 }
 #ifdef LQR_BT_TIMING

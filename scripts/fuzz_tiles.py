@@ -11,6 +11,8 @@ import datasets as D, fuzz_cases as F, harness as H, lqr_ctypes as L
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 max_cases = int(os.environ.get("FUZZ_COUNT", "0"))
+only = int(os.environ.get("FUZZ_ONLY", "-1"))            # replay: draw every case, run only this one (FUZZ_REPEAT times)
+repeat = int(os.environ.get("FUZZ_REPEAT", "1"))
 rng = np.random.default_rng(seed)
 o, e = L.oracle_api(), L.engine_api()
 lib = e.lib
@@ -25,26 +27,32 @@ try:
             kw["switch_freq"] = 0
         T = int(rng.choice([1, 2, 3, 4, 6, 8, 12]))
         rsv = int(rng.integers(-1, T))             # reserve tiles among them (-1: the engine's third)
+        if only >= 0 and n != only:
+            n += 1
+            if n > only:
+                break
+            continue
         lib.lqrhip_set_update_mode(4); lib.lqrhip_set_band_tiles(T); lib.lqrhip_set_band_tiles_reserve(rsv)
         planes = kw.get("switch_freq") == 0 and nh == img.shape[0] and nw < img.shape[1]
-        try:
-            if planes:
-                o.lqrx_set_debug(1); e.lqrx_set_debug(1)
-            ca, _ = H.init_carver(o, img, nw, nh, **kw); cb, _ = H.init_carver(e, img, nw, nh, **kw)
-            ra, rb = ca.resize(nw, nh), cb.resize(nw, nh)
-            assert ra == rb == 1, (ra, rb)
-            va, vb = ca.vmap_dump(), cb.vmap_dump()
-            assert np.array_equal(va["data"], vb["data"]), "seam maps"
-            assert np.array_equal(ca.read_image(), cb.read_image()), "pixels"
-            if planes:
-                (ea, ma, da), (eb, mb, db) = ca.debug_snapshot(), cb.debug_snapshot()
-                assert np.array_equal(ea, eb) and np.array_equal(ma, mb) and np.array_equal(da[1:], db[1:]), "DP planes"
-            ca.destroy(); cb.destroy()
-        except AssertionError as ex:
-            fails += 1
-            print("FAIL case %d T=%d rsv=%d %s: %s" % (n, T, rsv, what, str(ex)[:120]), flush=True)
-        finally:
-            o.lqrx_set_debug(0); e.lqrx_set_debug(0)
+        for rep in range(repeat if only >= 0 else 1):
+            try:
+                if planes:
+                    o.lqrx_set_debug(1); e.lqrx_set_debug(1)
+                ca, _ = H.init_carver(o, img, nw, nh, **kw); cb, _ = H.init_carver(e, img, nw, nh, **kw)
+                ra, rb = ca.resize(nw, nh), cb.resize(nw, nh)
+                assert ra == rb == 1, (ra, rb)
+                va, vb = ca.vmap_dump(), cb.vmap_dump()
+                assert np.array_equal(va["data"], vb["data"]), "seam maps"
+                assert np.array_equal(ca.read_image(), cb.read_image()), "pixels"
+                if planes:
+                    (ea, ma, da), (eb, mb, db) = ca.debug_snapshot(), cb.debug_snapshot()
+                    assert np.array_equal(ea, eb) and np.array_equal(ma, mb) and np.array_equal(da[1:], db[1:]), "DP planes"
+                ca.destroy(); cb.destroy()
+            except AssertionError as ex:
+                fails += 1
+                print("FAIL case %d T=%d rsv=%d %s: %s" % (n, T, rsv, what, str(ex)[:120]), flush=True)
+            finally:
+                o.lqrx_set_debug(0); e.lqrx_set_debug(0)
         n += 1
 finally:
     lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_tiles(-1); lib.lqrhip_set_band_tiles_reserve(-1)

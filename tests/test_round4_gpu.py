@@ -96,3 +96,25 @@ def test_band_tiles_batch_of_12_images(oracle, engine):
         assert np.array_equal(c.read_image(), ref["image"])
     for c in cs:
         c.destroy()
+
+
+@pytest.mark.parametrize("seed", [607398534, 7001])        # the first one is the image of the fuzz case below
+def test_band_tiles_chains_of_reserve_tiles(oracle, engine, seed):
+    """3 base tiles and 9 reserves on a tall noise image with a discard band: the band of changes walks outward through
+    several reserve tiles, one waking the next.  A reserve tile may only give up waiting when every tile that ever started
+    has ended (k_band_tiles's header count): the first version left when the BASE tiles were done, and a request made two
+    hops out in the second-to-last block then waited for a tile that had gone (fuzz seed 30311 case 1308: time-out)."""
+    lib = engine.lib
+    lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]; lib.lqrhip_set_band_tiles.argtypes = [ctypes.c_int]; lib.lqrhip_set_band_tiles_reserve.argtypes = [ctypes.c_int]
+    w, h = 1125, 834
+    img = D.noise(w, h, seed, channels=2)
+    kw = dict(nrg_func=3, switch_freq=9, res_order=1, pres=D.ellipse_mask(w, h), disc=D.band_mask(w, h, w // 5, w // 3))
+    lib.lqrhip_set_update_mode(4); lib.lqrhip_set_band_tiles(12); lib.lqrhip_set_band_tiles_reserve(9)
+    try:
+        ca, _ = H.init_carver(oracle, img, w - 46, h, **kw); cb, _ = H.init_carver(engine, img, w - 46, h, **kw)
+        assert ca.resize(w - 46, h) == cb.resize(w - 46, h) == L.LQR_OK
+        assert np.array_equal(ca.vmap_dump()["data"], cb.vmap_dump()["data"])
+        assert np.array_equal(ca.read_image(), cb.read_image())
+        ca.destroy(); cb.destroy()
+    finally:
+        lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_tiles(-1); lib.lqrhip_set_band_tiles_reserve(-1)
