@@ -111,10 +111,16 @@ def test_band_tiles_chains_of_reserve_tiles(oracle, engine, seed):
     kw = dict(nrg_func=3, switch_freq=9, res_order=1, pres=D.ellipse_mask(w, h), disc=D.band_mask(w, h, w // 5, w // 3))
     lib.lqrhip_set_update_mode(4); lib.lqrhip_set_band_tiles(12); lib.lqrhip_set_band_tiles_reserve(9)
     try:
-        ca, _ = H.init_carver(oracle, img, w - 46, h, **kw); cb, _ = H.init_carver(engine, img, w - 46, h, **kw)
-        assert ca.resize(w - 46, h) == cb.resize(w - 46, h) == L.LQR_OK
-        assert np.array_equal(ca.vmap_dump()["data"], cb.vmap_dump()["data"])
-        assert np.array_equal(ca.read_image(), cb.read_image())
+        ca, _ = H.init_carver(oracle, img, w - 46, h, **kw)
+        assert ca.resize(w - 46, h) == L.LQR_OK
+        vref, iref = ca.vmap_dump()["data"], ca.read_image()
+        for rep in range(10):            # (who leaves first is a matter of timing: the old exit failed one run in a few)
+            cb, _ = H.init_carver(engine, img, w - 46, h, **kw)
+            assert cb.resize(w - 46, h) == L.LQR_OK, rep
+            assert np.array_equal(vref, cb.vmap_dump()["data"])
+            assert np.array_equal(iref, cb.read_image())
+            if rep < 9:
+                cb.destroy()
         ca.destroy(); cb.destroy()
     finally:
         lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_tiles(-1); lib.lqrhip_set_band_tiles_reserve(-1)
