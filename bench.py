@@ -68,7 +68,10 @@ sys.path.insert(0, ROOT)
 # shared with torch's streams; with fewer queues than streams the split is slower than one stream, so the engine only
 # makes it when this variable says there are 8 or more.  It must be in the environment before the first HIP call of the
 # process, i.e. before torch is imported.  INTEGRATION.md says the same to a host application.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (The engine library sets it itself when it is loaded before the runtime is up -- `lqrhip_on_load` -- which is the case here too;
+# LQR_BENCH_NO_QUEUE_ENV=1 leaves it to the library, to show that.)
+if not os.environ.get("LQR_BENCH_NO_QUEUE_ENV"):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def parse():

@@ -43,6 +43,8 @@
 #include <thread>
 #include <mutex>
 #include <condition_variable>
+#include <dirent.h>
+#include <unistd.h>
 
 #include "../../include/lqr_hip.h"
 
@@ -3248,6 +3250,35 @@ static int dpp_resident_workgroups(int dev)
 #ifdef LQR_TILE_TIMING
 extern "C" int lqrhip_tile_timing(unsigned long long *out) { (void) hipDeviceSynchronize(); return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_dbg), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }
 #endif
+// Large lock-step groups are carved on 4 streams, and those need hardware queues of their own: the HIP runtime's
+// GPU_MAX_HW_QUEUES, default 4 per process, read ONCE when the runtime initialises (lqrhip_sub_batches below).  A host
+// that has never heard of the variable (the plug-in) would silently get one stream and 10 % less.  So when this library
+// is loaded into a process that has not brought the GPU runtime up yet -- no descriptor of /dev/kfd is open -- and the
+// variable is not set, it is set to 8 here, before the library's own first HIP call initialises the runtime.  A host that
+// set it (to anything) keeps its value; a host whose runtime is already up keeps one stream.
+static bool kfd_is_open(void)
+{
+    DIR *d = opendir("/proc/self/fd");
+    if (!d) return true;                      // cannot tell: leave the environment alone
+    bool open_ = false;
+    while (struct dirent *e = readdir(d)) {
+        if (e->d_name[0] == '.') continue;
+        char path[64], link[64];
+        snprintf(path, sizeof path, "/proc/self/fd/%s", e->d_name);
+        const ssize_t n = readlink(path, link, sizeof link - 1);
+        if (n <= 0) continue;
+        link[n] = 0;
+        if (strcmp(link, "/dev/kfd") == 0) { open_ = true; break; }
+    }
+    closedir(d);
+    return open_;
+}
+__attribute__((constructor)) static void lqrhip_on_load(void)
+{
+    if (getenv("GPU_MAX_HW_QUEUES") || kfd_is_open()) return;
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
 extern "C" int lqrhip_init(void)
 {
     if (g_device >= 0) return g_device;

@@ -83,7 +83,8 @@ int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int channels, in
 /* into how many device batches (HIP streams) the host splits a lock-step group of n carvers.  Automatic (set 0): 4 for
  * groups of 32 carvers and more when the process has the hardware queues for them (the HIP runtime's GPU_MAX_HW_QUEUES
  * >= 8 in the environment before HIP initialises; its default of 4 makes the split 30 % slower than one stream, so it is
- * then not made), else 1.  lqrhip_set_sub_batches(n > 0) pins it. */
+ * then not made), else 1.  The library sets the variable to 8 itself when it is loaded with the variable unset into a
+ * process whose GPU runtime is not up yet.  lqrhip_set_sub_batches(n > 0) pins the number of streams. */
 int lqrhip_sub_batches(int n);
 /* Images of carved-frame width w that one lock-step batch may hold and still run delta_x = 2 / rigidity-mask carvers on the
  * tiled kernels (0: unknown); larger batches of such carvers are carved group after group (lqrx_carver_resize_batch). */
