@@ -2826,7 +2826,7 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
 
 template <bool LR, bool RIG>
 // (two waves per SIMD, as the residency bound assumes: left alone the max-ilp scheduler spreads the 32-row loop over 262 registers)
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_band_tiles(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err, int t_base)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_band_tiles(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err, int t_base, int hset)
 {
     constexpr int OWN = 64, HALO = 32, EX_TILE = 2 * 2 * HALO, R = 32;
     typedef GLOBAL_AS unsigned long long gu64;
@@ -2838,8 +2838,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int nblk = (h + R - 1) / R;
     const int ntiles_img = (w + OWN - 1) / OWN;
     const GCarver c = gview(cs[blockIdx.y]);
-    gu64 *hdr = (gu64 *) exch + (size_t) blockIdx.y * BT_HDR;
-    gu64 *ex_img = (gu64 *) exch + (size_t) gridDim.y * BT_HDR + (size_t) blockIdx.y * ((size_t) ntiles_img * EX_TILE);
+    // two sets of image headers, used by alternate launches (hset): this launch clears the other set for the next one
+    // (a memset node per seam round cost 6 us + a dependency gap on the stream)
+    gu64 *hdr = (gu64 *) exch + ((size_t) hset * gridDim.y + blockIdx.y) * BT_HDR;
+    gu64 *ex_img = (gu64 *) exch + (size_t) 2 * gridDim.y * BT_HDR + (size_t) blockIdx.y * ((size_t) ntiles_img * EX_TILE);
+    if (slot == 0 && tid < BT_HDR) ((gu64 *) exch + ((size_t) (hset ^ 1) * gridDim.y + blockIdx.y) * BT_HDR)[tid] = 0ull;
     int gt, j0 = 0, lf = BT_NEVER, rf = BT_NEVER;
     if (slot >= t_base) {
         // a reserve tile: wait until an edge tile of this image asks for it, or until nobody is left who could.  Tiles that
@@ -3196,6 +3199,7 @@ struct LqrHipBatch {
     size_t exch_elems = 0;
     int exch_ntiles = 0, exch_n = 0, exch_px = 0;      // geometry the exchange area was last laid out for
     int tile_epoch = 0;                     // launches of k_dp_tile_p on this batch (part of the granule tags)
+    int bt_launches = 0;                    // launches of k_band_tiles on this batch (which of the two header sets)
     bool dirty = true;
     int shared_n = 1;                       // ... how many batches of the group there are (lqrhip_batch_set_shared)
     bool shared = false;                    // other batches of the same group run concurrently on their own streams:
@@ -4199,7 +4203,7 @@ static int launch_band_tiles(LqrHipBatch *b, const DpK &k, int w, int h, int lr,
     n_rsv = std::max(0, std::min(n_rsv, BT_HDR - 2));
     const int t_base = T - n_rsv;
     const int ntiles_img = (w + 63) / 64;
-    const size_t need_elems = ((size_t) ntiles_img * dpp_ex_tile(2) + BT_HDR) * n;
+    const size_t need_elems = ((size_t) ntiles_img * dpp_ex_tile(2) + 2 * BT_HDR) * n;
     if (b->exch_elems < need_elems) {
         HIPCK(hipStreamSynchronize(b->stream));
         dfree(b->exch);
@@ -4211,14 +4215,13 @@ static int launch_band_tiles(LqrHipBatch *b, const DpK &k, int w, int h, int lr,
     if (b->exch_ntiles != ntiles_img || b->exch_n != (int) n || b->exch_px != 102) {       // 102: this kernel's layout and tags
         HIPCK(hipMemsetAsync(b->exch, 0, need_elems * sizeof(unsigned long long), b->stream));
         b->exch_ntiles = ntiles_img; b->exch_n = (int) n; b->exch_px = 102;
-    } else {
-        // the images' headers (base tiles finished, requests made) start every launch at zero; granules and request words
-        // carry the launch epoch
-        HIPCK(hipMemsetAsync(b->exch, 0, n * BT_HDR * sizeof(unsigned long long), b->stream));
     }
+    // (the images' headers -- tiles finished, tickets drawn, requests -- start every launch at zero: there are two sets, a launch
+    // uses one and clears the other for the next launch; granules and request words carry the epoch)
+    const int hset = (b->bt_launches++) & 1;
     const int epoch = 1 + ((b->tile_epoch++) % ((1 << 19) - 2));           // never 0; 19 bits above changed / active bits and block index
     const dim3 grid(T, (unsigned) n);
-#define LAUNCH_BT(LRV, RIGV) hipLaunchKernelGGL((k_band_tiles<LRV, RIGV>), grid, dim3(128), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err, t_base)
+#define LAUNCH_BT(LRV, RIGV) hipLaunchKernelGGL((k_band_tiles<LRV, RIGV>), grid, dim3(128), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err, t_base, hset)
     if (lr) { if (k.use_rig) LAUNCH_BT(true, true); else LAUNCH_BT(true, false); }
     else { if (k.use_rig) LAUNCH_BT(false, true); else LAUNCH_BT(false, false); }
 #undef LAUNCH_BT
