@@ -98,33 +98,45 @@ def test_general_tiled_batch(oracle, engine):
         c.destroy()
 
 
-def test_sub_batch_streams_are_the_default_for_large_groups(oracle, engine, monkeypatch):
+def test_sub_batch_streams_are_the_default_for_large_groups(oracle, engine):
     """lqrhip_sub_batches: 4 streams for 32 carvers and more when the process says it has the hardware queues
     (GPU_MAX_HW_QUEUES >= 8), else one; then a 34-image group through that default path, image by image
-    against the oracle.  (The variable only steers the engine's choice here: HIP read it, or its absence, long ago.)"""
+    against the oracle.  (The variable only steers the engine's choice here: HIP read it, or its absence, long ago.  It is
+    changed in the C environment -- where the library set it when it was loaded, tests/test_queue_env.py -- not in
+    os.environ, which does not see what C code sets.)"""
     lib = engine.lib
     lib.lqrhip_set_sub_batches.argtypes = [ctypes.c_int]
     lib.lqrhip_sub_batches.argtypes = [ctypes.c_int]
+    libc = ctypes.CDLL(None)
+    libc.getenv.restype = ctypes.c_char_p
+    before = libc.getenv(b"GPU_MAX_HW_QUEUES")
     lib.lqrhip_set_sub_batches(0)
-    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
-    assert [lib.lqrhip_sub_batches(n) for n in (1, 31, 32, 64)] == [1, 1, 1, 1]
-    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
-    assert lib.lqrhip_sub_batches(64) == 1
-    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
-    assert [lib.lqrhip_sub_batches(n) for n in (1, 31, 32, 64)] == [1, 1, 4, 4]
-    lib.lqrhip_set_sub_batches(2)
-    assert [lib.lqrhip_sub_batches(n) for n in (3, 4, 64)] == [1, 2, 2]
-    lib.lqrhip_set_sub_batches(0)
-    w, h = 260, 90
-    imgs = [D.noise(w, h, 400 + i) if i % 3 else D.photo_like(w, h, 400 + i) for i in range(34)]
-    cs = [L.Carver(engine, im).configure() for im in imgs]
-    assert L.resize_batch(engine, cs, w - 25, h - 10) == L.LQR_OK
-    for i, (im, c) in enumerate(zip(imgs, cs)):
-        if i % 4 == 0 or i == 33:
-            ref = H.run_case(oracle, im, w - 25, h - 10)
-            assert np.array_equal(c.read_image(), ref["image"]), i
-            assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"]), i
-        c.destroy()
+    try:
+        libc.unsetenv(b"GPU_MAX_HW_QUEUES")
+        assert [lib.lqrhip_sub_batches(n) for n in (1, 31, 32, 64)] == [1, 1, 1, 1]
+        libc.setenv(b"GPU_MAX_HW_QUEUES", b"4", 1)
+        assert lib.lqrhip_sub_batches(64) == 1
+        libc.setenv(b"GPU_MAX_HW_QUEUES", b"8", 1)
+        assert [lib.lqrhip_sub_batches(n) for n in (1, 31, 32, 64)] == [1, 1, 4, 4]
+        # the 34-image group on 4 streams, as the bench runs it
+        lib.lqrhip_set_sub_batches(2)
+        assert [lib.lqrhip_sub_batches(n) for n in (3, 4, 64)] == [1, 2, 2]
+        lib.lqrhip_set_sub_batches(0)
+        w, h = 260, 90
+        imgs = [D.noise(w, h, 400 + i) if i % 3 else D.photo_like(w, h, 400 + i) for i in range(34)]
+        cs = [L.Carver(engine, im).configure() for im in imgs]
+        assert L.resize_batch(engine, cs, w - 25, h - 10) == L.LQR_OK
+        for i, (im, c) in enumerate(zip(imgs, cs)):
+            if i % 4 == 0 or i == 33:
+                ref = H.run_case(oracle, im, w - 25, h - 10)
+                assert np.array_equal(c.read_image(), ref["image"]), i
+                assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"]), i
+            c.destroy()
+    finally:
+        if before is None:
+            libc.unsetenv(b"GPU_MAX_HW_QUEUES")
+        else:
+            libc.setenv(b"GPU_MAX_HW_QUEUES", before, 1)
 
 
 # ---- BASELINE.json's large configs against the oracle at FULL size (round 2 checked them through properties only) ----
