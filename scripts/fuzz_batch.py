@@ -2,7 +2,7 @@
 contents and common parameters, engine as one batch vs oracle image by image; sub-batch streams, update modes and the
 opt-in seam-round forms vary with the case.
 
-    python scripts/fuzz_batch.py [seconds] [seed]
+    python scripts/fuzz_batch.py [seconds] [seed]          (FUZZ_COUNT=n: exactly n cases instead of the wall-clock budget)
 """
 import ctypes
 import os
@@ -13,21 +13,21 @@ sys.path.insert(0, "tests")
 import numpy as np
 
 import datasets as D
+import fuzz_common as FC
 import harness as H
 import lqr_ctypes as L
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+budget = FC.Budget(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0)      # FUZZ_COUNT=n: exactly n cases, no wall-clock exit
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-max_cases = int(os.environ.get("FUZZ_COUNT", "0"))
 rng = np.random.default_rng(seed)
 o = L.oracle_api()
 e = L.engine_api()
 lib = e.lib
 for f in ("lqrhip_set_update_mode", "lqrhip_set_sub_batches"):
     getattr(lib, f).argtypes = [ctypes.c_int]
-t_end = time.time() + budget
-n = fails = 0
-while time.time() < t_end and not (max_cases and n >= max_cases):
+fails = FC.Failures(lib)
+n = 0
+while budget.more(n):
     kind = int(rng.integers(0, 3))
     if kind == 0:
         w, h = int(rng.integers(900, 2400)), int(rng.integers(40, 160))
@@ -62,10 +62,9 @@ while time.time() < t_end and not (max_cases and n >= max_cases):
             assert np.array_equal(got_img, ref["image"]), "image %d: pixels differ" % i
         for c in cs:
             c.destroy()
-    except AssertionError as ex:
-        fails += 1
-        print("FAIL case %d" % n, what, str(ex)[:160], flush=True)
+    except Exception as ex:
+        fails.record(n, what, ex)
     n += 1
 lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_sub_batches(0)
-print("batch fuzz: %d cases, %d failures, seed %d" % (n, fails, seed), flush=True)
-sys.exit(1 if fails else 0)
+FC.summary("batch fuzz", n, budget, fails, seed)
+sys.exit(1 if fails.total else 0)

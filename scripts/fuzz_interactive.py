@@ -13,19 +13,19 @@ sys.path.insert(0, "tests")
 import numpy as np
 
 import datasets as D
+import fuzz_common as FC
 import harness as H
 import lqr_ctypes as L
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+budget = FC.Budget(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0)      # FUZZ_COUNT=n: exactly n cases, no wall-clock exit
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-max_cases = int(os.environ.get("FUZZ_COUNT", "0"))
 rng = np.random.default_rng(seed)
 o = L.oracle_api()
 e = L.engine_api()
 e.lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]
-t_end = time.time() + budget
-n = fails = ok_steps = err_breaks = 0
-while time.time() < t_end and not (max_cases and n >= max_cases):
+fails = FC.Failures(e.lib)
+n = ok_steps = err_breaks = 0
+while budget.more(n):
     big = rng.random() < 0.3
     w, h = (int(rng.integers(900, 1500)), int(rng.integers(60, 160))) if big else (int(rng.integers(24, 260)), int(rng.integers(16, 160)))
     ch = int(rng.integers(1, 5))
@@ -65,10 +65,9 @@ while time.time() < t_end and not (max_cases and n >= max_cases):
             assert va["depth"] == vb["depth"] and np.array_equal(va["data"], vb["data"]), "map at %s" % (st,)
         for c in cs:
             c.destroy()
-    except AssertionError as ex:
-        fails += 1
-        print("FAIL case %d" % n, what, str(ex)[:160], flush=True)
+    except Exception as ex:
+        fails.record(n, what, ex)
     n += 1
 e.lib.lqrhip_set_update_mode(-1)
-print("interactive fuzz: %d cases (%d calls compared, %d sequences ended by an error both libraries returned), %d failures, seed %d" % (n, ok_steps, err_breaks, fails, seed), flush=True)
-sys.exit(1 if fails else 0)
+FC.summary("interactive fuzz", n, budget, fails, seed, " (%d calls compared, %d sequences ended by an error both libraries returned)" % (ok_steps, err_breaks))
+sys.exit(1 if fails.total else 0)

@@ -14,10 +14,11 @@ sys.path.insert(0, "tests")
 import numpy as np
 
 import fuzz_cases as F
+import fuzz_common as FC
 import harness as H
 import lqr_ctypes as L
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+budget = FC.Budget(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0)      # FUZZ_COUNT=n: exactly n cases, no wall-clock exit
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 verbose = len(sys.argv) > 3 and sys.argv[3] not in ("0", "")
 general = len(sys.argv) > 4
@@ -27,7 +28,6 @@ import os
 only = set(int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x)
 repeat = int(os.environ.get("FUZZ_REPEAT", "1"))
 force_modes = [int(x) for x in os.environ.get("FUZZ_MODES", "").split(",") if x]
-max_cases = int(os.environ.get("FUZZ_COUNT", "0"))       # stop after this many cases (a deterministic run for the tests)
 # FUZZ_EXTRAS=1: the plug-in's other switches too, drawn from a second stream (the cases themselves stay the same): seam-map
 # output, attached mask layers resized along, LqR-back, discard masks kept on enlargement, the enlargement step
 extras = np.random.default_rng(seed + 1000003) if os.environ.get("FUZZ_EXTRAS") else None
@@ -36,9 +36,9 @@ rng = np.random.default_rng(seed)
 o = L.oracle_api()
 e = L.engine_api()
 e.lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]
-t_end = time.time() + budget
-n = fails = 0
-while time.time() < t_end and not (max_cases and n >= max_cases):
+fails = FC.Failures(e.lib)
+n = 0
+while budget.more(n):
     img, nw, nh, kw, what = F.draw_case(rng)
     name, mode = list(F.MODES.items())[n % 3]
     if general:
@@ -78,10 +78,9 @@ while time.time() < t_end and not (max_cases and n >= max_cases):
                 H.assert_same(a, b, what)
                 if only:
                     print("ok   case %d mode %d rep %d" % (n, m, rep), flush=True)
-            except AssertionError as ex:
-                fails += 1
-                print("FAIL case %d mode %d rep %d" % (n, m, rep), what, str(ex)[-120:], flush=True)
+            except Exception as ex:
+                fails.record("%d mode %d rep %d" % (n, m, rep), what, ex)
     n += 1
 e.lib.lqrhip_set_update_mode(-1)
-print("fuzz: %d cases, %d failures, seed %d" % (n, fails, seed), flush=True)
-sys.exit(1 if fails else 0)
+FC.summary("fuzz", n, budget, fails, seed)
+sys.exit(1 if fails.total else 0)

@@ -6,21 +6,20 @@ last incremental update bit for bit.
 import ctypes, os, sys, time
 sys.path.insert(0, "tests")
 import numpy as np
-import datasets as D, fuzz_cases as F, harness as H, lqr_ctypes as L
+import datasets as D, fuzz_cases as F, fuzz_common as FC, harness as H, lqr_ctypes as L
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+budget = FC.Budget(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0)       # FUZZ_COUNT=n: exactly n cases, no wall-clock exit
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-max_cases = int(os.environ.get("FUZZ_COUNT", "0"))
 only = int(os.environ.get("FUZZ_ONLY", "-1"))            # replay: draw every case, run only this one (FUZZ_REPEAT times)
 repeat = int(os.environ.get("FUZZ_REPEAT", "1"))
 rng = np.random.default_rng(seed)
 o, e = L.oracle_api(), L.engine_api()
 lib = e.lib
 lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]; lib.lqrhip_set_band_tiles.argtypes = [ctypes.c_int]; lib.lqrhip_set_band_tiles_reserve.argtypes = [ctypes.c_int]
-t_end = time.time() + budget
-n = fails = 0
+fails = FC.Failures(lib)
+n = 0
 try:
-    while time.time() < t_end and not (max_cases and n >= max_cases):
+    while budget.more(n):
         img, nw, nh, kw, what = F.draw_case(rng)
         kw.pop("delta_x", None); kw.pop("rigmask", None)          # the plain kernels' domain
         if rng.random() < 0.5:
@@ -40,7 +39,7 @@ try:
                     o.lqrx_set_debug(1); e.lqrx_set_debug(1)
                 ca, _ = H.init_carver(o, img, nw, nh, **kw); cb, _ = H.init_carver(e, img, nw, nh, **kw)
                 ra, rb = ca.resize(nw, nh), cb.resize(nw, nh)
-                assert ra == rb == 1, (ra, rb)
+                assert ra == rb == 1, "resize returned %s (oracle) / %s (engine)" % (ra, rb)
                 va, vb = ca.vmap_dump(), cb.vmap_dump()
                 assert np.array_equal(va["data"], vb["data"]), "seam maps"
                 assert np.array_equal(ca.read_image(), cb.read_image()), "pixels"
@@ -48,13 +47,12 @@ try:
                     (ea, ma, da), (eb, mb, db) = ca.debug_snapshot(), cb.debug_snapshot()
                     assert np.array_equal(ea, eb) and np.array_equal(ma, mb) and np.array_equal(da[1:], db[1:]), "DP planes"
                 ca.destroy(); cb.destroy()
-            except AssertionError as ex:
-                fails += 1
-                print("FAIL case %d T=%d rsv=%d %s: %s" % (n, T, rsv, what, str(ex)[:120]), flush=True)
+            except Exception as ex:
+                fails.record(n, "T=%d rsv=%d %s" % (T, rsv, what), ex)
             finally:
                 o.lqrx_set_debug(0); e.lqrx_set_debug(0)
         n += 1
 finally:
     lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_tiles(-1); lib.lqrhip_set_band_tiles_reserve(-1)
-print("tiles fuzz: %d cases, %d failures, seed %d" % (n, fails, seed), flush=True)
-sys.exit(1 if fails else 0)
+FC.summary("tiles fuzz", n, budget, fails, seed)
+sys.exit(1 if fails.total else 0)

@@ -16,20 +16,22 @@ import sys
 
 import pytest
 
+import fuzz_common as FC
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run_fuzz(poison, seconds, seed, extra=(), only=None, count=0):
+    if count:           # count-bounded, every case asked for must have run (tests/fuzz_common.py)
+        return FC.run_script("fuzz_parity.py", [0, seed, *extra], dict(LQRHIP_POISON=poison), count)
     env = dict(os.environ, LQRHIP_POISON=poison)
     if only:
         env["FUZZ_ONLY"] = only
-    if count:
-        env["FUZZ_COUNT"] = str(count)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), str(seconds), str(seed), *extra],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, "exit %d\n--- stdout ---\n%s\n--- stderr ---\n%s" % (r.returncode, r.stdout, r.stderr)
     return r.stdout
 
 

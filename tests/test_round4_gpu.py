@@ -72,11 +72,8 @@ def test_band_tiles_seeded_cases_with_forced_tile_counts():
     """scripts/fuzz_tiles.py: the multi-CU band update with 1..12 tiles per image -- sets narrower than the band (coverage
     test, abort at the edge of the set and hand-over to the full-width sweep), sets wider than the image, both tie rules,
     rigidity; seam maps, pixels and the DP planes after the last incremental update against the oracle"""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_tiles.py"), "300", "4400"], cwd=root,
-                       env=dict(os.environ, FUZZ_COUNT="400"), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and " 0 failures" in r.stdout, (r.stdout[-3000:], r.stderr[-1000:])
+    import fuzz_common as FC
+    FC.run_script("fuzz_tiles.py", [0, 4400], {}, 400)          # count-bounded: all 400 cases must have run
 
 
 def test_band_tiles_batch_of_12_images(oracle, engine):
