@@ -41,14 +41,16 @@ itself under torch.distributed.run with N ranks (one per GPU, RCCL).
 Also on the JSON line:
   roofline      the dominant HBM kernel (k_carve), HIP-event timed per launch on its own stream(s) inside the timed
                 region.  achieved = algorithmic bytes per launch (8 B x W*H/2 per image) / the average
-                launch duration; frac = achieved / 8 TB/s.  (frac_while_active divides by the union of the overlapping
-                launches' intervals instead.)  traffic = HBM bytes per launch from the committed PMC passes of this
-                command (profiles/pmc_kernels.json, scripts/profile_r04.sh).  kernels = EVERY kernel of the step from one
+                launch duration, or -- when smaller -- the bytes on the side of the seam the carve really moves (18 B per
+                pixel, counted by k_vpath*: moved_bytes_per_launch); frac = achieved / 8 TB/s.  (frac_while_active divides by
+                the union of the overlapping launches' intervals instead.)  traffic = HBM bytes per launch from the committed PMC passes of this
+                command (profiles/pmc_kernels.json, scripts/profile_r05.sh).  kernels = EVERY kernel of the step from one
                 extra untimed step with all of them timed: launches, average duration, share of the kernel time,
                 algorithmic and PMC bytes, fraction of the roof.  end_to_end = the whole step against the roof:
                 value x (4 B carve + 9 B x full DPs per phase / seams per phase) / 8 TB/s.
-  configs       after the headline, BASELINE configs 2, 3 and 5 (fhd, single4k, config5: one carver, the plug-in's own
-                call shape), 3 steps each, with their own roofline.kernels, phases and cpu_baseline (--no-configs skips).
+  configs       after the headline: config 4's literal per-GPU shard (batch4k_8img: 8 x 4K) and BASELINE configs 2, 3 and 5
+                (fhd, single4k, config5: one carver, the plug-in's own call shape), 3 steps each, with their own
+                roofline.kernels, phases and cpu_baseline (--no-configs skips).  summary = every workload's value, last on the line.
   cpu_baseline  the CPU oracle (oracle/, a port of liblqr pinned against the genuine liblqr 0.4.1, oracle/REF_CHECK.md)
                 timed on this host: one image on one core, and one image per core on all cores for the batch workload
                 (nproc stated).
@@ -98,9 +100,6 @@ def parse():
                     help="tiles per image of the multi-CU band update k_band_tiles: -1 the engine's choice, 0 never (k_band_update_tw), n at most n")
     ap.add_argument("--band-tiles-reserve", type=int, default=-1, help="how many of those are reserve tiles (-1: a third)")
     ap.add_argument("--dp-px", type=int, default=0, help="pin the persistent tiled sweep's pixels per lane (2 or 4; 0: by batch size)")
-    ap.add_argument("--band-kernel", type=int, default=None,
-                    help="A/B hook (experiments build): 0 k_band_update_tw, 1 k_band_update_td<4 px>, 2 k_band_update_td<2 px>, 3 k_band_update_ls")
-    ap.add_argument("--band-variant", type=int, default=0, help="A/B hook for band-kernel experiments")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phases", action="store_true", help="skip the upload / read-out phase measurement")
     ap.add_argument("--no-gather", action="store_true")
@@ -284,13 +283,7 @@ def main():
     if args.dp_px:
         lib.lqrhip_set_dp_persistent_px.argtypes = [C.c_int]
         lib.lqrhip_set_dp_persistent_px(args.dp_px)
-    if args.band_kernel is not None or args.band_variant:      # only in a -DLQR_BAND_EXPERIMENTS build of the library
-        if not hasattr(lib, "lqrhip_set_band_kernel"):
-            raise SystemExit("bench.py: --band-kernel / --band-variant need a library built with -DLQR_BAND_EXPERIMENTS")
-        lib.lqrhip_set_band_kernel.argtypes = [C.c_int]
-        lib.lqrhip_set_band_kernel(args.band_kernel or 0)
-        lib.lqrhip_set_band_variant.argtypes = [C.c_int]
-        lib.lqrhip_set_band_variant(args.band_variant)
+    lib.lqrhip_moved_bytes.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -299,13 +292,14 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    def measure(wl, steps, warmup, headline):
+    def measure(wl, steps, warmup, headline, images=None):
         """one workload: set-up, `warmup` untimed + exactly `steps` timed steps, per-kernel breakdown, phases, CPU baseline;
-        `headline`: also the gather / strong / all-cores legs.  Returns the JSON object of the workload."""
+        `headline`: also the gather / strong / all-cores legs; `images`: images per GPU of a batch workload other than the
+        command line's.  Returns the JSON object of the workload."""
         W, H, NW, NH = WORKLOADS[wl]
         batch = wl == "batch4k"
-        nimg = args.images_per_gpu if batch else 1
-        if batch and args.strong:
+        nimg = (images or args.images_per_gpu) if batch else 1
+        if batch and args.strong and not images:
             nimg = strong_images_per_gpu(world)
         if args.seams is not None:
             NW = W - args.seams
@@ -384,16 +378,21 @@ def main():
             lib.lqrhip_prof_reset()
             lib.lqrhip_prof_enable(prof_mode)
             barrier(); sync()
+            lib.lqrhip_moved_bytes(C.byref(C.c_ulonglong(0)), 1)         # what the carves of the timed steps HAVE to move: from zero
             t0 = time.perf_counter()
             for _ in range(steps):
                 run_step(cs, ps)
             sync(); barrier()
             t1 = time.perf_counter()
             lib.lqrhip_prof_enable(0)
+            mv = C.c_ulonglong(0)
+            lib.lqrhip_moved_bytes(C.byref(mv), 0)
+            timed.moved_bytes = mv.value
             return max_over_ranks(t1 - t0)
 
         # ---- phase "resize" (render.c:314-316): W warm-up steps, then exactly K timed steps
         elapsed = timed(carvers, ptrs, steps, warmup, 1 if args.kernel_times else 2)
+        moved_total = timed.moved_bytes            # bytes the timed steps' carves had to move (k_vpath*'s count of the side that moves)
         used_gb, total_gb = mem_used_gb()
         streams = lib.lqrhip_sub_batches(nimg) if nimg > 1 else 1
 
@@ -414,20 +413,32 @@ def main():
             active_ms = un.value if un.value > 0 else c_ms
             avg_us = c_ms * 1e3 / c_n
             alg_launch = c_bytes / c_n
-            achieved = alg_launch / (avg_us * 1e-6) / 1e9                    # algorithmic bytes per launch / average launch duration
-            while_active = c_bytes / (active_ms * 1e-3) / 1e9                # ... / the time during which at least one carve was running
+            # The numerator of a roofline fraction must be bytes the kernel could not avoid.  SURVEY 8(d) prices the carve at one
+            # 4-byte plane over HALF a row, read + write (alg); the engine moves the SHORTER side of the seam, three planes
+            # (en, m, back pointer: 18 B per pixel moved, read + write; 8 B on the seams a full DP follows) -- `moved` is that,
+            # counted by k_vpath* for the seams it actually found.  frac takes the smaller of the two.
+            moved_launch = moved_total / c_n if moved_total else None
+            num_launch = min(alg_launch, moved_launch) if moved_launch else alg_launch
+            achieved = num_launch / (avg_us * 1e-6) / 1e9                    # bytes per launch / average launch duration
+            while_active = num_launch * c_n / (active_ms * 1e-3) / 1e9       # ... / the time during which at least one carve was running
             # HBM traffic per launch from the committed rocprofv3 PMC passes of this command (separate FETCH_SIZE / WRITE_SIZE
-            # runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note; scripts/profile_r04.sh), null if missing
-            traffic = pmc_traffic(wl, ["k_carve"], nimg, streams)
+            # runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note; scripts/profile_r05.sh), null if missing
+            traffic = pmc_traffic(wl if not images else "%s_%dimg" % (wl, nimg), ["k_carve"], nimg, streams)
             b_alg = alg_bytes_per_seam_px(W, H, NW, NH, args.switch_freq)
             roofline = {"bound": "hbm", "kernel": "k_carve", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                         "avg_launch_us": round(avg_us, 2), "launches": c_n, "streams": streams,
                         "alg_bytes_per_launch": round(alg_launch),
+                        "moved_bytes_per_launch": None if moved_launch is None else round(moved_launch),
+                        "frac_basis": "moved_bytes" if (moved_launch and moved_launch < alg_launch) else "alg_bytes",
+                        "frac_alg": round(alg_launch / (avg_us * 1e-6) / 8e12, 4),
+                        "traffic_ratio": None if not (traffic and moved_launch) else round(traffic / moved_launch, 3),
                         "achieved_while_active": round(while_active, 1), "frac_while_active": round(while_active / 8000.0, 4),
                         "carve_active_ms": round(active_ms, 3), "sum_of_launches_ms": round(c_ms, 3),
-                        "note": "frac = alg_bytes_per_launch / avg_launch_us / peak for k_carve, the HBM-bound kernel; launches of the "
-                                "sub-batch streams overlap, frac_while_active divides by the union of their intervals instead; "
+                        "note": "frac = min(alg_bytes, moved_bytes) per launch / avg_launch_us / peak for k_carve, the HBM-bound kernel: alg = SURVEY 8(d)'s "
+                                "8 B x W*H/2 per image, moved = 18 B x the pixels on the side of the seam the carve really moves (k_vpath*'s count; "
+                                "8 B on seams a full DP follows); traffic_ratio = PMC traffic / moved; frac_alg = the alg-only figure of earlier "
+                                "rounds; launches of the sub-batch streams overlap, frac_while_active divides by the union of their intervals; "
                                 "`kernels` lists every kernel of the step, `end_to_end` is the whole step against the roof",
                         "end_to_end": {"bytes_per_seam_px": round(b_alg, 4), "achieved": round(value * b_alg * 1e-3 / max(world, 1), 1),
                                        "unit": "GB/s per GPU", "frac": round(value * b_alg * 1e-3 / max(world, 1) / 8000.0, 4)}}
@@ -451,8 +462,10 @@ def main():
                 if not n:
                     continue
                 cand = KERNEL_NAMES[k][0 if nimg > 8 else 1]
-                pmc = pmc_traffic(wl, cand, nimg, streams)
+                pmc = pmc_traffic(wl if not images else "%s_%dimg" % (wl, nimg), cand, nimg, streams)
                 alg = by / n if by else None
+                if k == "carve" and alg and timed.moved_bytes and n:
+                    alg = min(alg, timed.moved_bytes / n)            # bytes it could not avoid (see roofline.note)
                 basis = alg if alg else pmc
                 roofline["kernels"].append({
                     "name": k, "kernel": cand[0], "launches": n, "avg_us": round(ms * 1e3 / n, 2), "share_of_kernel_time": round(ms / tot_ms, 4),
@@ -611,13 +624,23 @@ def main():
         st = (C.c_ulonglong * 8)()
         if lib.lqrhip_band_tiles_stats(st, 1) == 0 and any(st[i] for i in range(4)):
             result["band_tiles_stats"] = {"uncovered_images": st[0], "aborted_images": st[1], "reserve_tiles_woken": st[2], "requests_without_reserve": st[3]}
-    # ---- BASELINE configs 2, 3 and 5 -- the plug-in's own call shape, one carver (render.c:318) -- on the same line
-    if args.workload == "batch4k" and world == 1 and not args.no_configs and args.seams is None:
+    # ---- on the same line: config 4's LITERAL per-GPU shard (64 images over 8 GPUs = 8 per GPU: the strong-scaling end nobody
+    # can measure without the node), then BASELINE configs 2, 3 and 5 -- the plug-in's own call shape, one carver (render.c:318)
+    if args.workload == "batch4k" and world == 1 and not args.no_configs and args.seams is None and not args.strong:
         result["configs"] = {}
-        for name in ("fhd", "single4k", "config5"):
-            r = measure(name, 3, 1, False)
-            result["configs"][name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernels_ms", "phases",
-                                                          "cpu_baseline", "parity_vs_oracle", "hbm_used_gb") if k in r}
+        keep = ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernels_ms", "phases", "cpu_baseline", "parity_vs_oracle", "hbm_used_gb")
+        legs = [("batch4k_8img", "batch4k", 8), ("fhd", "fhd", None), ("single4k", "single4k", None), ("config5", "config5", None)]
+        for name, wl, images in legs:
+            if images and images == args.images_per_gpu:
+                continue
+            r = measure(wl, 3, 1, False, images=images)
+            for rk in (r.get("roofline") or {}, r.get("phases") or {}):
+                rk.pop("note", None)                      # said once, on the headline
+            result["configs"][name] = {k: r[k] for k in keep if k in r}
+        # the numbers a reader (or a log tail) wants first, LAST on the line: Mseams*px/s per workload, k_carve's fraction of the roof
+        result["summary"] = dict({"batch4k_%dimg" % args.images_per_gpu: result["value"], "k_carve_frac": (result.get("roofline") or {}).get("frac"),
+                                  "end_to_end_frac": ((result.get("roofline") or {}).get("end_to_end") or {}).get("frac")},
+                                 **{k: v["value"] for k, v in result["configs"].items()})
     if dist is not None:
         result["rccl_ranks"] = dist.get_world_size()
     if rank == 0:

@@ -2,7 +2,8 @@
 
 The product is the shared library ``liblqr-hip.so`` built from
 
-  csrc/lqr_hip.hip     hand-written gfx950 kernels + the lqrhip_* C-ABI shim
+  csrc/k_*.hip         hand-written gfx950 kernels, one translation unit per stage (csrc/lqr_common.h has the map)
+  csrc/lqr_shim.hip    the lqrhip_* C-ABI shim that launches them
   host/lqr_carver.c    the LqrCarver API (include/lqr.h) in plain C
 
 This Python package is only the build/load helper used by bench.py, the tests
@@ -24,7 +25,7 @@ LIB_PATH = os.path.join(HERE, "liblqr-hip.so")
 def build(verbose=False):
     """Cross-compile the engine for gfx950 (works without a GPU)."""
     out = None if verbose else subprocess.DEVNULL
-    subprocess.check_call(["make", "-C", HERE], stdout=out)
+    subprocess.check_call(["make", "-C", HERE, "-j8"], stdout=out)
     return LIB_PATH
 
 

@@ -1,0 +1,1649 @@
+// lqr_shim.hip -- the host side: the lqrhip_* C ABI of include/lqr_hip.h (plain pointers and sizes) on top of the kernels of
+// k_*.hip: device selection, the allocation cache, host <-> device transfers through a pinned ring, batches and their streams,
+// lqrhip_seam_step's per-seam launch sequence and the choice of update_mmap form, read-out, reset from device memory,
+// the copy ceiling and the seam-map colour ramp.  The three kernels that live here (k_poison_random, k_copy16, k_vmap_ramp)
+// are debugging / measuring / one-off aids next to their only callers.
+#include "lqr_common.h"
+#include "lqr_kernels.h"
+
+static thread_local std::string g_err;
+static int g_device = -1;
+
+static int *g_dev_err_host = nullptr;      // hipHostMalloc'ed, mapped
+static int *g_dev_err = nullptr;           // its device address
+
+#define HIPCK_VOID(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { g_err = std::string(#expr) + ": " + hipGetErrorString(e__); (void) hipGetLastError(); } } while (0)
+#define HIPCK(expr)                                                                   \
+    do {                                                                              \
+        hipError_t e__ = (expr);                                                      \
+        if (e__ != hipSuccess) {                                                      \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(e__);               \
+            (void) hipGetLastError();                                                 \
+            return (e__ == hipErrorOutOfMemory) ? LQRHIP_ENOMEM : LQRHIP_EHIP;        \
+        }                                                                             \
+    } while (0)
+
+// co-residency bounds for the spin waits of the persistent kernels, set from the occupancy queries in lqrhip_init (dpp_resident_workgroups)
+static int g_dpp_max_wgs = 0;
+static int g_dpp_max_wgs_plain = 0, g_dpp_max_wgs_general = 0;      // ... of the plain / the delta_x = 2..4, rigidity-mask instantiations
+static int g_dpp_max_wgs_px4 = 0;                                   // ... of the plain 4-px instantiations alone (fewer registers than the 2-px ones)
+static int g_dpp_max_wgs_tiles = 0;                                 // ... of k_band_tiles
+
+static int band_tiles_resident(int n_cu)
+{
+    int per_cu = 1 << 20;
+    auto q = [&](auto kern) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 128, 0) != hipSuccess) { (void) hipGetLastError(); n = 0; }
+        per_cu = std::min(per_cu, n);
+    };
+    q(k_band_tiles<false, false>); q(k_band_tiles<false, true>); q(k_band_tiles<true, false>); q(k_band_tiles<true, true>);
+    return std::max(0, per_cu - 1) * n_cu;
+}
+
+// ===========================================================================
+// host side of the shim
+// ===========================================================================
+struct LqrHipCarver {
+    int ch = 0;
+    int w0 = 0, h0 = 0;              // base layout dims
+    // base planes
+    uint8_t *rgb0 = nullptr;
+    int32_t *vs = nullptr;           // owned by roots only
+    float *bias0 = nullptr, *rig0 = nullptr;
+    // working planes
+    int active = 0;
+    int stride = 0, wk_h = 0;
+    uint32_t *pix = nullptr;
+    float *en = nullptr, *m = nullptr, *m2 = nullptr, *bias = nullptr, *rig = nullptr;
+    int8_t *least = nullptr, *least2 = nullptr;
+    int32_t *seam_x = nullptr, *seam_log = nullptr, *flags = nullptr;
+    int log_cap = 0, log_h = 0;
+    int frozen_epoch = 0;           // pix / bias are in the frame before seam `frozen_epoch` of the session
+    LqrHipCarver *root = nullptr;
+    std::vector<LqrHipCarver *> aux;
+    LqrHipBatch *batch = nullptr;
+};
+
+struct LqrHipBatch {
+    std::vector<LqrHipCarver *> cs;
+    DevCarver *d_desc = nullptr;
+    hipStream_t stream = nullptr;
+    unsigned long long *exch = nullptr;     // k_dp_tile_p: halo granules per image and tile + finished-tile counters
+    size_t exch_elems = 0;
+    int exch_ntiles = 0, exch_n = 0, exch_px = 0;      // geometry the exchange area was last laid out for
+    int tile_epoch = 0;                     // launches of k_dp_tile_p on this batch (part of the granule tags)
+    int bt_launches = 0;                    // launches of k_band_tiles on this batch (which of the two header sets)
+    bool dirty = true;
+    int shared_n = 1;                       // ... how many batches of the group there are (lqrhip_batch_set_shared)
+    bool shared = false;                    // other batches of the same group run concurrently on their own streams:
+                                            // no persistent (spin-waiting, co-residency-dependent) kernels
+};
+
+struct ProfRec {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    double bytes = 0;
+};
+static int g_prof = 0;                 // 0 off, 1 every kernel, 2 the roofline kernel (k_carve) only
+static std::map<std::string, ProfRec> g_profrec;
+static hipStream_t g_stream0 = nullptr;
+
+extern "C" const char *lqrhip_last_error(void) { return g_err.c_str(); }
+
+// Workgroups of k_dp_tile_p the device holds at once.  Its tiles spin on their neighbours, so the grid
+// must be co-resident: the bound comes from the occupancy query of every instantiation that can be
+// launched (the minimum over them), less one workgroup per CU of margin -- the API is known to answer
+// one block per CU too many at some SGPR counts (MI355X_MICROARCH.md, residency) -- times the CU count.
+// A grid above the bound goes to k_dp_tile (kernel boundaries instead of spin waits).
+static int dpp_resident_workgroups(int dev)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return 0;
+    int per_cu = 1 << 20;
+    auto q = [&](auto kern) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 64 * DPP_W, 0) != hipSuccess) { (void) hipGetLastError(); n = 0; }
+        per_cu = std::min(per_cu, n);
+    };
+    q(k_dp_tile_p<4, false, false, false>); q(k_dp_tile_p<4, false, true, false>); q(k_dp_tile_p<4, true, false, false>); q(k_dp_tile_p<4, true, true, false>);
+    q(k_dp_tile_p<4, false, false, true>); q(k_dp_tile_p<4, false, true, true>); q(k_dp_tile_p<4, true, false, true>); q(k_dp_tile_p<4, true, true, true>);
+    // the 2-px instantiations stage a whole 32-row block (193 VGPRs): their bound is lower, and a grid that is too large for
+    // them but fits the 4-px ones must not be sent to k_dp_tile for it
+    g_dpp_max_wgs_px4 = std::max(0, per_cu - 1) * prop.multiProcessorCount;
+    q(k_dp_tile_p<2, false, false, false>); q(k_dp_tile_p<2, false, true, false>); q(k_dp_tile_p<2, true, false, false>); q(k_dp_tile_p<2, true, true, false>);
+    q(k_dp_tile_p<2, false, false, true>); q(k_dp_tile_p<2, false, true, true>); q(k_dp_tile_p<2, true, false, true>); q(k_dp_tile_p<2, true, true, true>);
+    g_dpp_max_wgs_plain = std::max(0, per_cu - 1) * prop.multiProcessorCount;
+    // the delta_x = 2 / rigidity-mask instantiations (2 px per lane only) hold more registers
+    per_cu = 1 << 20;
+#define QG(LRV, UPD) q(k_dp_tile_p<2, LRV, true, UPD, 1, true>); q(k_dp_tile_p<2, LRV, false, UPD, 2, false>); q(k_dp_tile_p<2, LRV, true, UPD, 2, false>); q(k_dp_tile_p<2, LRV, true, UPD, 2, true>); \
+    q(k_dp_tile_p<2, LRV, false, UPD, 3, false>); q(k_dp_tile_p<2, LRV, true, UPD, 3, false>); q(k_dp_tile_p<2, LRV, true, UPD, 3, true>); \
+    q(k_dp_tile_p<2, LRV, false, UPD, 4, false>); q(k_dp_tile_p<2, LRV, true, UPD, 4, false>); q(k_dp_tile_p<2, LRV, true, UPD, 4, true>)
+    QG(false, false); QG(false, true); QG(true, false); QG(true, true);
+#undef QG
+    g_dpp_max_wgs_general = std::max(0, per_cu - 1) * prop.multiProcessorCount;
+    g_dpp_max_wgs_tiles = band_tiles_resident(prop.multiProcessorCount);
+    return g_dpp_max_wgs_plain;
+}
+
+// Large lock-step groups are carved on 4 streams, and those need hardware queues of their own: the HIP runtime's
+// GPU_MAX_HW_QUEUES, default 4 per process, read ONCE when the runtime initialises (lqrhip_sub_batches below).  A host
+// that has never heard of the variable (the plug-in) would silently get one stream and 10 % less.  So when this library
+// is loaded into a process that has not brought the GPU runtime up yet -- no descriptor of /dev/kfd is open -- and the
+// variable is not set, it is set to 8 here, before the library's own first HIP call initialises the runtime.  A host that
+// set it (to anything) keeps its value; a host whose runtime is already up keeps one stream.
+static bool kfd_is_open(void)
+{
+    DIR *d = opendir("/proc/self/fd");
+    if (!d) return true;                      // cannot tell: leave the environment alone
+    bool open_ = false;
+    while (struct dirent *e = readdir(d)) {
+        if (e->d_name[0] == '.') continue;
+        char path[64], link[64];
+        snprintf(path, sizeof path, "/proc/self/fd/%s", e->d_name);
+        const ssize_t n = readlink(path, link, sizeof link - 1);
+        if (n <= 0) continue;
+        link[n] = 0;
+        if (strcmp(link, "/dev/kfd") == 0) { open_ = true; break; }
+    }
+    closedir(d);
+    return open_;
+}
+__attribute__((constructor)) static void lqrhip_on_load(void)
+{
+    if (getenv("GPU_MAX_HW_QUEUES") || kfd_is_open()) return;
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
+extern "C" int lqrhip_init(void)
+{
+    if (g_device >= 0) return g_device;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        g_err = "no HIP device visible: the MI355X engine needs a gfx950 GPU (there is no CPU fallback)";
+        (void) hipGetLastError();
+        return LQRHIP_EHIP;
+    }
+    int dev = 0;
+    const char *lr = getenv("LOCAL_RANK");
+    if (lr) dev = atoi(lr) % n;
+    HIPCK(hipSetDevice(dev));
+    HIPCK(hipStreamCreateWithFlags(&g_stream0, hipStreamNonBlocking));
+    HIPCK(hipHostMalloc((void **) &g_dev_err_host, sizeof(int), hipHostMallocMapped));
+    *g_dev_err_host = 0;
+    HIPCK(hipHostGetDevicePointer((void **) &g_dev_err, g_dev_err_host, 0));
+    g_dpp_max_wgs = dpp_resident_workgroups(dev);
+    g_device = dev;
+    return dev;
+}
+
+// A kernel recorded a failure (dev_fail): report it once, as an error return, and clear the word.  The word is one per
+// process and whoever synchronises first finds it -- not necessarily the batch whose kernel failed.  A persistent sweep that
+// gave up half way leaves its batch's exchange area (tags, finished-tile counter) and, for an update, the plane pointers
+// in the device descriptors in an unknown state, so EVERY live batch is marked for a fresh lay-out of both.
+static std::vector<LqrHipBatch *> g_live_batches;
+static void invalidate_all_batches(void);
+static int check_dev_error(void)
+{
+    if (!g_dev_err_host || *g_dev_err_host == 0) return 0;
+    const int code = *g_dev_err_host;
+    *g_dev_err_host = 0;
+    invalidate_all_batches();
+    g_err = code == DEVERR_TILE_TIMEOUT ? "persistent tiled DP sweep: a neighbour tile never became resident (GPU shared or partitioned?); "
+                                          "results of this resize are invalid"
+                                        : "band update: activity prediction failed; results of this resize are invalid";
+    return LQRHIP_EHIP;
+}
+
+// Device allocations go through a small size-class cache: the carve path allocates and frees
+// image-sized planes for every inflate / flatten / read-out, and hipMalloc / hipFree (which
+// synchronises the device) would otherwise cost more than the kernels between them.  A block is
+// only returned to the cache after the stream that used it has been synchronised.
+static std::multimap<size_t, void *> g_pool_free;
+static std::map<void *, size_t> g_pool_size;
+static size_t g_pool_cached = 0;
+static const size_t POOL_MAX_CACHED = (size_t) 24 << 30;
+
+// LQRHIP_POISON=<byte> in the environment (debugging aid, scripts/fuzz_parity.py): every block handed out is first filled
+// with that byte and the device synchronised, so that a kernel that reads memory nothing wrote yet fails the same way every
+// time instead of depending on what the block held before
+// LQRHIP_POISON=r1 / r2 / r3: pseudo-random words that look like what a recycled block holds -- floats in [0, 100),
+// integers in [0, 2048), arbitrary bits
+__global__ void k_poison_random(unsigned *p, size_t n, int mode, int stride, int c0, int c1, int r0, int r1)
+{
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+        if (stride > 0) {       // LQRHIP_POISON_WINDOW=stride:c0:c1:r0:r1 -- only that window of a plane, zero elsewhere
+            const int col = (int) (i % stride), row = (int) (i / stride);
+            if (col < c0 || col >= c1 || row < r0 || row >= r1) { p[i] = 0; continue; }
+        }
+        unsigned hsh = (unsigned) i * 2654435761u + 0x9e3779b9u;
+        hsh ^= hsh >> 15; hsh *= 0x85ebca6bu; hsh ^= hsh >> 13; hsh *= 0xc2b2ae35u; hsh ^= hsh >> 16;
+        p[i] = mode == 1 ? __float_as_uint((float) (hsh >> 8) * (100.0f / 16777216.0f)) : mode == 2 ? (hsh >> 21) : hsh;
+    }
+}
+static const char *g_alloc_name = "";      // what the allocation is for (LQRHIP_POISON_LOG)
+static int g_poison = -2;
+static unsigned g_poison32 = 0;
+static int pool_poison(void *p, size_t sz)
+{
+    if (g_poison == -2) {
+        const char *e = getenv("LQRHIP_POISON");
+        g_poison = -1;
+        if (e && e[0] == '0' && e[1] == 'x') { g_poison = 256; g_poison32 = (unsigned) strtoul(e, nullptr, 16); }     // a 32-bit word
+        else if (e && e[0] == 'r') g_poison = 256 + atoi(e + 1);
+        else if (e && *e) g_poison = atoi(e) & 255;
+    }
+    if (g_poison < 0) return 0;
+    {   // LQRHIP_POISON_RANGE=a:b poisons only the allocations numbered a .. b-1 of the process (LQRHIP_POISON_LOG lists them)
+        static long seq = 0, lo = 0, hi = -1;
+        static int logit = -1;
+        if (logit < 0) {
+            logit = getenv("LQRHIP_POISON_LOG") != nullptr;
+            const char *r = getenv("LQRHIP_POISON_RANGE");
+            if (r) sscanf(r, "%ld:%ld", &lo, &hi);
+        }
+        const long me = seq++;
+        if (logit) fprintf(stderr, "alloc %ld %zu %s\n", me, sz, g_alloc_name);
+        if (hi >= 0 && (me < lo || me >= hi)) { HIPCK(hipMemset(p, 0, sz)); HIPCK(hipDeviceSynchronize()); return 0; }
+    }
+    if (g_poison > 256) {
+        static int win[5] = {0, 0, 0, 0, 0};
+        static bool once = false;
+        if (!once) { once = true; const char *wv = getenv("LQRHIP_POISON_WINDOW"); if (wv) sscanf(wv, "%d:%d:%d:%d:%d", win, win + 1, win + 2, win + 3, win + 4); }
+        hipLaunchKernelGGL(k_poison_random, dim3(1024), dim3(256), 0, 0, (unsigned *) p, sz / 4, g_poison - 256, win[0], win[1], win[2], win[3], win[4]);
+    }
+    else if (g_poison == 256) HIPCK(hipMemsetD32((hipDeviceptr_t) p, (int) g_poison32, sz / 4));
+    else HIPCK(hipMemset(p, g_poison, sz));
+    HIPCK(hipDeviceSynchronize());
+    return 0;
+}
+
+static int pool_alloc(void **p, size_t bytes)
+{
+    const size_t sz = (bytes + ((size_t) 1 << 20) - 1) & ~(((size_t) 1 << 20) - 1);      // 1 MiB classes
+    auto it = g_pool_free.find(sz);
+    if (it != g_pool_free.end()) {
+        *p = it->second;
+        g_pool_free.erase(it);
+        g_pool_cached -= sz;
+        return pool_poison(*p, sz);
+    }
+    hipError_t e = hipMalloc(p, sz);
+    if (e == hipErrorOutOfMemory && !g_pool_free.empty()) {       // give the cache back and retry once
+        (void) hipGetLastError();
+        for (auto &kv : g_pool_free) { (void) hipFree(kv.second); g_pool_size.erase(kv.second); }
+        g_pool_free.clear();
+        g_pool_cached = 0;
+        e = hipMalloc(p, sz);
+    }
+    HIPCK(e);
+    g_pool_size[*p] = sz;
+    return pool_poison(*p, sz);
+}
+static void pool_free(void *p)
+{
+    auto it = g_pool_size.find(p);
+    if (it == g_pool_size.end()) { (void) hipFree(p); return; }
+    if (g_pool_cached + it->second > POOL_MAX_CACHED) {
+        (void) hipFree(p);
+        g_pool_size.erase(it);
+        return;
+    }
+    g_pool_free.emplace(it->second, p);
+    g_pool_cached += it->second;
+}
+
+template <typename T>
+static int dmalloc_(T **p, size_t n, const char *name)
+{
+    *p = nullptr;
+    g_alloc_name = name;
+    return pool_alloc((void **) p, (n ? n : 1) * sizeof(T));
+}
+#define dmalloc(p, n) dmalloc_((p), (n), #p)
+template <typename T>
+static void dfree(T *&p)
+{
+    if (p) pool_free((void *) p);
+    p = nullptr;
+}
+
+// zero device memory and wait: hipMemset on the null stream is asynchronous for device memory and the
+// engine's streams are non-blocking, so a null-stream memset is not ordered with the kernels after it
+static hipError_t dzero(void *p, size_t bytes)
+{
+    hipError_t e = hipMemsetAsync(p, 0, bytes, g_stream0);
+    return e != hipSuccess ? e : hipStreamSynchronize(g_stream0);
+}
+
+// Host <-> device copies of whole images.  The plug-in hands over and takes back PAGEABLE memory (a g_malloc'ed buffer at
+// lqr_carver_new, render.c:222; the scan-line buffer at read-out, io_functions.c:155-164); hipMemcpy on pageable memory
+// runs at ~1-2 GB/s here (it pins and unpins as it goes).  These go through a ring of pinned bounce buffers instead, and
+// the CPU side of the bounce -- memcpy between the caller's pageable buffer and the ring, page faults of a freshly
+// allocated destination included -- is done by a few helper threads in parallel while the DMA engine moves other chunks
+// (round 3: one thread, two 8 MB buffers: 8.6 GB/s up, 4.2 GB/s down; a single core's memcpy and its page faults were
+// the limit, not PCIe).  The helpers touch host memory only; every HIP call stays on the caller's thread.
+// Both functions return with the transfer complete, also on error (the stream is drained before they return).
+static const size_t STAGE_BYTES = (size_t) 4 << 20;
+static const int STAGE_SLOTS = 16;
+static uint8_t *g_stage[STAGE_SLOTS];
+static hipEvent_t g_stage_ev[STAGE_SLOTS];
+static bool g_stage_ready = false;
+
+struct CopyPool {
+    struct Job { void *dst; const void *src; size_t n; };
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::deque<std::pair<int, Job>> q;      // (ticket, job)
+    std::vector<char> done;                 // per ticket of the current transfer
+    size_t pending = 0;                     // submitted and not finished
+    bool stop = false;
+    void start(int n)
+    {
+        for (int i = 0; i < n; i++) th.emplace_back([this] { run(); });
+    }
+    void run()
+    {
+        for (;;) {
+            std::pair<int, Job> j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [this] { return stop || !q.empty(); });
+                if (stop && q.empty()) return;
+                j = q.front(); q.pop_front();
+            }
+            memcpy(j.second.dst, j.second.src, j.second.n);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                done[j.first] = 1;
+                pending--;
+            }
+            cv_done.notify_all();
+        }
+    }
+    void begin(size_t tickets) { std::lock_guard<std::mutex> lk(mu); done.assign(tickets, 0); }
+    void submit(int ticket, void *dst, const void *src, size_t n)
+    {
+        { std::lock_guard<std::mutex> lk(mu); q.emplace_back(ticket, Job{dst, src, n}); pending++; }
+        cv_job.notify_one();
+    }
+    void drain()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [this] { return pending == 0; });
+    }
+    void wait(int ticket)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return done[ticket] != 0; });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_job.notify_all();
+        for (auto &t : th) t.join();
+    }
+};
+static CopyPool *g_copy_pool = nullptr;
+
+static int stage_init(void)
+{
+    if (g_stage_ready) return 0;
+    // all or nothing: a partial set of buffers / events is released again, so a later call starts over
+    int made = 0;
+    hipError_t e = hipSuccess;
+    for (; made < STAGE_SLOTS; made++) {
+        g_stage[made] = nullptr; g_stage_ev[made] = nullptr;
+        if ((e = hipHostMalloc((void **) &g_stage[made], STAGE_BYTES, hipHostMallocDefault)) != hipSuccess) break;
+        if ((e = hipEventCreateWithFlags(&g_stage_ev[made], hipEventDisableTiming)) != hipSuccess) { (void) hipHostFree(g_stage[made]); break; }
+    }
+    if (made < STAGE_SLOTS) {
+        for (int i = 0; i < made; i++) { (void) hipHostFree(g_stage[i]); (void) hipEventDestroy(g_stage_ev[i]); g_stage[i] = nullptr; }
+        g_err = std::string("staging buffers: ") + hipGetErrorString(e);
+        (void) hipGetLastError();
+        return e == hipErrorOutOfMemory ? LQRHIP_ENOMEM : LQRHIP_EHIP;
+    }
+    if (!g_copy_pool) {
+        unsigned hw = std::thread::hardware_concurrency();
+        g_copy_pool = new CopyPool();
+        g_copy_pool->start(hw >= 16 ? 8 : hw >= 4 ? (int) hw / 2 : 1);
+    }
+    g_stage_ready = true;
+    return 0;
+}
+static int h2d_staged(void *dst, const void *src, size_t bytes)
+{
+    int rc = stage_init();
+    if (rc) return rc;
+    const size_t nchunk = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
+    CopyPool &cp = *g_copy_pool;
+    cp.begin(nchunk);
+    auto body = [&]() -> int {
+        size_t submitted = 0;
+        for (size_t i = 0; i < nchunk; i++) {
+            // keep the helpers a ring ahead: chunk j goes into slot j % STAGE_SLOTS once the DMA that last read it is done
+            for (; submitted < nchunk && submitted < i + STAGE_SLOTS; submitted++) {
+                const int slot = (int) (submitted % STAGE_SLOTS);
+                HIPCK(hipEventSynchronize(g_stage_ev[slot]));
+                const size_t off = submitted * STAGE_BYTES;
+                cp.submit((int) submitted, g_stage[slot], (const uint8_t *) src + off, std::min(STAGE_BYTES, bytes - off));
+            }
+            const int slot = (int) (i % STAGE_SLOTS);
+            const size_t off = i * STAGE_BYTES;
+            cp.wait((int) i);
+            HIPCK(hipMemcpyAsync((uint8_t *) dst + off, g_stage[slot], std::min(STAGE_BYTES, bytes - off), hipMemcpyHostToDevice, g_stream0));
+            HIPCK(hipEventRecord(g_stage_ev[slot], g_stream0));
+        }
+        return 0;
+    };
+    rc = body();
+    cp.drain();         // whatever happened, nobody touches the caller's buffer or the ring after we return
+    hipError_t e = hipStreamSynchronize(g_stream0);
+    if (!rc && e != hipSuccess) { g_err = std::string("upload: ") + hipGetErrorString(e); rc = LQRHIP_EHIP; }
+    return rc;
+}
+static int d2h_staged(void *dst, const void *src, size_t bytes)
+{
+    int rc = stage_init();
+    if (rc) return rc;
+    const size_t nchunk = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
+    CopyPool &cp = *g_copy_pool;
+    cp.begin(nchunk);
+    size_t copied_out = 0;      // chunks handed to the helpers
+    auto hand_over = [&](size_t j) -> int {
+        const int slot = (int) (j % STAGE_SLOTS);
+        const size_t off = j * STAGE_BYTES;
+        HIPCK(hipEventSynchronize(g_stage_ev[slot]));
+        cp.submit((int) j, (uint8_t *) dst + off, g_stage[slot], std::min(STAGE_BYTES, bytes - off));
+        return 0;
+    };
+    auto body = [&]() -> int {
+        for (size_t i = 0; i < nchunk; i++) {
+            if (i >= (size_t) STAGE_SLOTS) {              // slot reuse: the helper must have emptied it
+                for (; copied_out <= i - STAGE_SLOTS; copied_out++) { int r = hand_over(copied_out); if (r) return r; }
+                cp.wait((int) (i - STAGE_SLOTS));
+            }
+            const int slot = (int) (i % STAGE_SLOTS);
+            const size_t off = i * STAGE_BYTES;
+            HIPCK(hipMemcpyAsync(g_stage[slot], (const uint8_t *) src + off, std::min(STAGE_BYTES, bytes - off), hipMemcpyDeviceToHost, g_stream0));
+            HIPCK(hipEventRecord(g_stage_ev[slot], g_stream0));
+            // hand over whatever has landed already, without waiting for it
+            while (copied_out < i && hipEventQuery(g_stage_ev[copied_out % STAGE_SLOTS]) == hipSuccess) { int r = hand_over(copied_out); if (r) return r; copied_out++; }
+        }
+        for (; copied_out < nchunk; copied_out++) { int r = hand_over(copied_out); if (r) return r; }
+        return 0;
+    };
+    rc = body();
+    cp.drain();         // the helpers are done with the caller's buffer
+    if (rc) (void) hipStreamSynchronize(g_stream0);
+    return rc;
+}
+
+static int batch_sync_of(LqrHipCarver *c)
+{
+    LqrHipCarver *r = c->root ? c->root : c;
+    if (r->batch) HIPCK(hipStreamSynchronize(r->batch->stream));
+    return 0;
+}
+
+extern "C" LqrHipCarver *lqrhip_carver_create(const unsigned char *rgb, int w, int h, int channels)
+{
+    if (lqrhip_init() < 0) return nullptr;
+    LqrHipCarver *c = new LqrHipCarver();
+    c->ch = channels; c->w0 = w; c->h0 = h;
+    size_t n = (size_t) w * h;
+    if (dmalloc(&c->rgb0, n * channels) || dmalloc(&c->vs, n)) { lqrhip_carver_destroy(c); return nullptr; }
+    // the visibility map is cleared on the same stream, under the upload: one synchronisation for both
+    if (hipMemsetAsync(c->vs, 0, n * sizeof(int32_t), g_stream0) != hipSuccess || h2d_staged(c->rgb0, rgb, n * channels) != 0) {
+        g_err = "upload failed";
+        lqrhip_carver_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+static void free_working(LqrHipCarver *c)
+{
+    dfree(c->pix); dfree(c->en); dfree(c->m); dfree(c->least); dfree(c->m2); dfree(c->least2); dfree(c->bias); dfree(c->rig);
+    dfree(c->seam_x); dfree(c->seam_log); dfree(c->flags);
+    c->log_cap = 0;
+}
+
+extern "C" void lqrhip_carver_destroy(LqrHipCarver *c)
+{
+    if (!c) return;
+    // its planes may still be in use by kernels on the owning batch's stream or by the shim's own stream (resets, mask
+    // uploads, read-outs): wait for those two, not for the device (tearing a batch down was 64 device synchronisations)
+    {
+        LqrHipCarver *r = c->root ? c->root : c;
+        if (r->batch && r->batch->stream) (void) hipStreamSynchronize(r->batch->stream);
+        if (c->batch && c->batch != r->batch && c->batch->stream) (void) hipStreamSynchronize(c->batch->stream);
+        if (g_stream0) (void) hipStreamSynchronize(g_stream0);
+        (void) hipGetLastError();
+    }
+    dfree(c->rgb0);
+    if (!c->root) dfree(c->vs);
+    dfree(c->bias0); dfree(c->rig0);
+    free_working(c);
+    delete c;
+}
+
+extern "C" int lqrhip_carver_attach(LqrHipCarver *root, LqrHipCarver *aux)
+{
+    if (root->w0 != aux->w0 || root->h0 != aux->h0) return LQRHIP_EARG;
+    dfree(aux->vs);
+    aux->vs = root->vs;
+    aux->root = root;
+    root->aux.push_back(aux);
+    if (root->batch) root->batch->dirty = true;
+    return 0;
+}
+
+// (re)allocate the working planes for a w x h carved frame
+static int ensure_working(LqrHipCarver *c, int w, int h)
+{
+    int stride = ((w + 16) + 63) & ~63;
+    bool need_bias = c->bias0 != nullptr, need_rig = c->rig0 != nullptr;
+    if (c->pix && c->stride == stride && c->wk_h == h && (!!c->bias == need_bias) && (!!c->rig == need_rig)) return 0;
+    free_working(c);
+    c->stride = 0; c->wk_h = 0;
+    size_t n = (size_t) stride * (h + 1) + 1024;
+    int rc;
+    if ((rc = dmalloc(&c->pix, n)) || (rc = dmalloc(&c->en, n)) || (rc = dmalloc(&c->m, n)) || (rc = dmalloc(&c->least, n)) ||
+        (rc = dmalloc(&c->seam_x, (size_t) h + 8)) || (rc = dmalloc(&c->flags, (size_t) FLAG_WORDS)) ||
+        (need_bias && (rc = dmalloc(&c->bias, n))) || (need_rig && (rc = dmalloc(&c->rig, n)))) {
+        free_working(c);            // never leave a half-allocated set behind: a retry must not pass the early-out above
+        return rc;
+    }
+    // all on the shim's stream, one synchronisation
+    hipError_t e = hipMemsetAsync(c->least, 0, n, g_stream0);
+    if (e == hipSuccess) e = hipMemsetAsync(c->m, 0, n * sizeof(float), g_stream0);
+    if (e == hipSuccess) e = hipMemsetAsync(c->en, 0, n * sizeof(float), g_stream0);
+    if (e == hipSuccess) e = hipMemsetAsync(c->pix, 0, n * sizeof(uint32_t), g_stream0);
+    if (e == hipSuccess) e = hipMemsetAsync(c->flags, 0, (size_t) FLAG_WORDS * sizeof(int32_t), g_stream0);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream0);
+    if (e != hipSuccess) { free_working(c); HIPCK(e); }
+    c->stride = stride; c->wk_h = h;
+    if (c->batch) c->batch->dirty = true;
+    return 0;
+}
+
+static int ensure_log(LqrHipCarver *c, int n_seams, int h)
+{
+    if (c->seam_log && c->log_cap >= n_seams && c->log_h == h) return 0;
+    dfree(c->seam_log);
+    int rc = dmalloc(&c->seam_log, (size_t) n_seams * h);
+    if (rc) return rc;
+    c->log_cap = n_seams; c->log_h = h;
+    if (c->batch) c->batch->dirty = true;
+    return 0;
+}
+
+extern "C" int lqrhip_carver_activate(LqrHipCarver *c)
+{
+    c->active = 1;
+    // E1 lqr_carver_init allocates the DP maps: do the same here, so that the first resize does
+    // not pay for hipMalloc (re-done lazily by lqrhip_wk_init if the geometry changes)
+    return ensure_working(c, c->w0, c->h0);
+}
+
+extern "C" int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int channels, int width, int height, int x_off,
+                               int y_off, int transposed, int is_rigmask, int bias_factor)
+{
+    int rc = batch_sync_of(c);
+    if (rc) return rc;
+    size_t n = (size_t) c->w0 * c->h0;
+    float **plane = is_rigmask ? &c->rig0 : &c->bias0;
+    if (!*plane) {
+        if ((rc = dmalloc(plane, n))) return rc;
+        HIPCK(dzero(*plane, n * sizeof(float)));
+        if (c->batch) c->batch->dirty = true;
+    }
+    int wt = transposed ? c->h0 : c->w0, ht = transposed ? c->w0 : c->h0;
+    int x0 = x_off < 0 ? x_off : 0, y0 = y_off < 0 ? y_off : 0;
+    int x1 = x_off > 0 ? x_off : 0, y1 = y_off > 0 ? y_off : 0;
+    int x2 = wt < width + x_off ? wt : width + x_off, y2 = ht < height + y_off ? ht : height + y_off;
+    int nx = x2 - x1, ny = y2 - y1;
+    if (nx <= 0 || ny <= 0) return 0;
+    uint8_t *dmask = nullptr;
+    size_t mbytes = (size_t) width * height * channels;
+    if ((rc = dmalloc(&dmask, mbytes))) return rc;
+    auto run = [&]() -> int {
+        int rcu = h2d_staged(dmask, mask, mbytes);
+        if (rcu) return rcu;
+        dim3 grid((nx + 255) / 256, ny);
+        hipLaunchKernelGGL(k_mask_add, grid, dim3(256), 0, g_stream0, *plane, c->w0, dmask, channels, width, x0, y0, x1, y1, nx, ny,
+                           transposed, is_rigmask, bias_factor);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(g_stream0));
+        return 0;
+    };
+    rc = run();
+    if (rc) (void) hipStreamSynchronize(g_stream0);
+    dfree(dmask);
+    return rc;
+}
+
+// ---- batch -----------------------------------------------------------------
+// A lock-step group can be split over several HIP streams (sub-batches) that advance seam by seam side by side: a seam
+// round is a latency-bound chain (backtrack, energy update, band update: ~0.7 ms at 4K whatever the batch size, on a
+// few CUs) followed by the bandwidth-bound carve, so one sub-batch's chain runs under another's carve.  Measured at
+// 64 x 4K with 4 streams: +12 % throughput (424k vs 377k Mseams*px/s), but every kernel then shares the chip -- a carve
+// launch of 16 images takes 0.20 ms next to the others' kernels (2.6 TB/s algorithmic) instead of 0.13 ms alone -- and
+// it needs a hardware queue per stream: with the HIP runtime's default of 4 queues per process (GPU_MAX_HW_QUEUES) the
+// streams share queues and the same split is 30 % SLOWER.  lqrhip_set_sub_batches (bench.py --sub-batches) pins the
+// number of streams; the default is automatic (lqrhip_sub_batches below).  DESIGN.md 4.11.
+static int g_sub_batches = 0;           // 0: automatic (below)
+extern "C" void lqrhip_set_sub_batches(int n) { g_sub_batches = n > 0 ? n : 0; }
+// Streams a lock-step group of n carvers is split over.  Automatic: 4 for groups of 32 and more WHEN the process has the
+// hardware queues for them -- the HIP runtime's GPU_MAX_HW_QUEUES (default 4, read when HIP initialises, shared with every
+// other stream of the process) must be 8 or more; with fewer, streams share queues and the split is 30 % slower than
+// one stream, so it is not made.
+extern "C" int lqrhip_sub_batches(int n)
+{
+    int nb = g_sub_batches;
+    if (nb == 0) {
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        nb = (n >= 32 && q && atoi(q) >= 8) ? 4 : 1;
+    }
+    return n >= 2 * nb ? nb : 1;
+}
+
+extern "C" void lqrhip_batch_set_shared(LqrHipBatch *b, int shared) { b->shared = shared != 0; b->shared_n = shared > 1 ? shared : 1; }
+
+extern "C" LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n)
+{
+    if (lqrhip_init() < 0 || n <= 0) return nullptr;
+    LqrHipBatch *b = new LqrHipBatch();
+    for (int i = 0; i < n; i++) {
+        b->cs.push_back(carvers[i]);
+        carvers[i]->batch = b;
+    }
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **) &b->d_desc, sizeof(DevCarver) * n) != hipSuccess) {
+        g_err = "batch_create failed";
+        if (b->stream) (void) hipStreamDestroy(b->stream);
+        for (auto *c : b->cs) if (c->batch == b) c->batch = nullptr;
+        delete b;
+        return nullptr;
+    }
+    g_live_batches.push_back(b);
+    return b;
+}
+
+static void invalidate_all_batches(void)
+{
+    for (auto *b : g_live_batches) { b->exch_ntiles = 0; b->dirty = true; }
+}
+
+// after a failed resize: drain the stream, drop whatever the kernels recorded (it belongs to the failed call, the next
+// resize must not report it), lay everything out afresh
+extern "C" void lqrhip_batch_abort(LqrHipBatch *b)
+{
+    if (!b) return;
+    (void) hipStreamSynchronize(b->stream);
+    (void) hipGetLastError();
+    if (g_dev_err_host) *g_dev_err_host = 0;
+    invalidate_all_batches();
+}
+
+extern "C" void lqrhip_batch_destroy(LqrHipBatch *b)
+{
+    if (!b) return;
+    g_live_batches.erase(std::remove(g_live_batches.begin(), g_live_batches.end(), b), g_live_batches.end());
+    if (b->stream) { (void) hipStreamSynchronize(b->stream); (void) hipStreamDestroy(b->stream); }
+    dfree(b->exch);
+    for (auto *c : b->cs) if (c->batch == b) c->batch = nullptr;
+    if (b->d_desc) (void) hipFree(b->d_desc);
+    delete b;
+}
+
+extern "C" int lqrhip_batch_sync(LqrHipBatch *b)
+{
+    HIPCK(hipStreamSynchronize(b->stream));
+    return check_dev_error();
+}
+extern "C" void *lqrhip_batch_stream(LqrHipBatch *b) { return (void *) b->stream; }
+
+static DevCarver make_desc(const LqrHipCarver *c)
+{
+    DevCarver d;
+    d.rgb0 = c->rgb0; d.vs = c->vs; d.bias0 = c->bias0; d.rig0 = c->rig0;
+    d.pix = c->pix; d.en = c->en; d.m = c->m; d.least = c->least; d.m2 = c->m2; d.least2 = c->least2; d.bias = c->bias; d.rig = c->rig;
+    d.seam_x = c->seam_x; d.seam_log = c->seam_log; d.flags = c->flags;
+    return d;
+}
+
+static int batch_upload(LqrHipBatch *b)
+{
+    if (!b->dirty) return 0;
+    std::vector<DevCarver> h;
+    for (auto *c : b->cs) h.push_back(make_desc(c));
+    HIPCK(hipStreamSynchronize(b->stream));
+    HIPCK(hipMemcpy(b->d_desc, h.data(), sizeof(DevCarver) * h.size(), hipMemcpyHostToDevice));
+    b->dirty = false;
+    return 0;
+}
+
+static DpK make_dpk(const LqrHipDpParams *p, int ch)
+{
+    DpK k;
+    k.delta = p->delta_x; k.use_rig = p->use_rigidity;
+    memcpy(k.rigmap, p->rigidity_map, sizeof k.rigmap);
+    k.nrg = p->nrg_func; k.radius = p->nrg_radius; k.w_start = p->w_start; k.ch = ch;
+    return k;
+}
+
+struct ProfScope {
+    ProfRec *rec = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t s;
+    ProfScope(const char *name, hipStream_t stream, double bytes) : s(stream)
+    {
+        // every timed scope costs ~10 us of queue time (two event packets): mode 2 keeps that to the one
+        // kernel whose launch time the bench line needs
+        if (!g_prof || (g_prof == 2 && strcmp(name, "carve") != 0)) return;
+        rec = &g_profrec[name];
+        rec->bytes += bytes;
+        (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
+        (void) hipEventRecord(e0, s);
+    }
+    ~ProfScope()
+    {
+        if (!rec) return;
+        (void) hipEventRecord(e1, s);
+        rec->ev.emplace_back(e0, e1);
+    }
+};
+
+extern "C" void lqrhip_prof_enable(int on) { g_prof = on; }
+static int g_update_mode = -1;
+// -1: by batch size (g_tiled_update_px); 0: band kernel (k_band_update_tw); 1: tiled full-width update whenever its
+// grid fits; 2: the per-row-barrier band kernel (k_band_update_mw); 3: the generic one-wave band kernel + sweep
+// (what delta_x > 2 runs on), whatever the parameters
+extern "C" void lqrhip_set_update_mode(int mode) { g_update_mode = mode; }
+static int g_dpp_limit_override = -1;
+static int g_dpp_px_override = 0;       // test hook: 2 or 4 pins the persistent sweep's pixels per lane (0 = by batch size)
+extern "C" void lqrhip_set_dp_persistent_px(int px) { g_dpp_px_override = (px == 2 || px == 4) ? px : 0; }
+// -1: the occupancy-derived bound (dpp_resident_workgroups); >= 0: at most that many workgroups for the persistent
+// tiled sweep -- 0 sends every full DP to k_dp_tile and every incremental update to a band kernel
+extern "C" void lqrhip_set_dp_persistent_limit(int workgroups) { g_dpp_limit_override = workgroups; }
+extern "C" void lqrhip_prof_reset(void)
+{
+    for (auto &kv : g_profrec) for (auto &e : kv.second.ev) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
+    g_profrec.clear();
+}
+extern "C" int lqrhip_prof_get(const char *kernel, double *ms_total, long long *launches, double *bytes_total)
+{
+    auto it = g_profrec.find(kernel);
+    *ms_total = 0; *launches = 0; *bytes_total = 0;
+    if (it == g_profrec.end()) return 0;
+    (void) hipDeviceSynchronize();
+    for (auto &e : it->second.ev) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) *ms_total += ms;
+    }
+    *launches = (long long) it->second.ev.size();
+    *bytes_total = it->second.bytes;
+    return 0;
+}
+
+// Time during which at least one launch of `kernel` was running: with sub-batch streams launches overlap each other and
+// other kernels, and bytes / (sum of launch times) would count the overlapped time twice.  Event times are taken relative
+// to the first recorded event of the kernel (the GPU's clock is common to all streams).
+extern "C" int lqrhip_prof_get_union(const char *kernel, double *ms_union)
+{
+    *ms_union = 0;
+    auto it = g_profrec.find(kernel);
+    if (it == g_profrec.end() || it->second.ev.empty()) return 0;
+    (void) hipDeviceSynchronize();
+    const hipEvent_t base = it->second.ev[0].first;
+    std::vector<std::pair<float, float>> iv;
+    for (auto &e : it->second.ev) {
+        float a = 0, b = 0;
+        // an event recorded before `base` on another stream gives a negative time: both orders are tried
+        if (hipEventElapsedTime(&a, base, e.first) != hipSuccess) { (void) hipGetLastError(); float t = 0; if (hipEventElapsedTime(&t, e.first, base) == hipSuccess) a = -t; else (void) hipGetLastError(); }
+        if (hipEventElapsedTime(&b, base, e.second) != hipSuccess) { (void) hipGetLastError(); float t = 0; if (hipEventElapsedTime(&t, e.second, base) == hipSuccess) b = -t; else (void) hipGetLastError(); }
+        iv.emplace_back(a, b);
+    }
+    std::sort(iv.begin(), iv.end());
+    float end = -1e30f;
+    for (auto &p : iv) {
+        if (p.first > end) { *ms_union += p.second - p.first; end = p.second; }
+        else if (p.second > end) { *ms_union += p.second - end; end = p.second; }
+    }
+    return 0;
+}
+
+extern "C" int lqrhip_wk_init(LqrHipBatch *b)
+{
+    LqrHipCarver *c0 = b->cs[0];
+    int w = c0->w0, h = c0->h0, rc;
+    for (auto *c : b->cs) {
+        if (c->w0 != w || c->h0 != h || c->ch != c0->ch) return LQRHIP_EARG;
+        if ((rc = ensure_working(c, w, h))) return rc;
+    }
+    if ((rc = batch_upload(b))) return rc;
+    for (auto *c : b->cs) c->frozen_epoch = 0;
+    dim3 grid((c0->stride + 255) / 256, h, (unsigned) b->cs.size());
+    hipLaunchKernelGGL(k_wk_init, grid, dim3(256), 0, b->stream, b->d_desc, w, h, c0->stride, c0->ch);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lqrhip_emap_build(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h)
+{
+    int rc;
+    if ((rc = batch_upload(b))) return rc;
+    LqrHipCarver *c0 = b->cs[0];
+    dim3 grid((w + 255) / 256, h, (unsigned) b->cs.size());
+    DpK k = make_dpk(p, c0->ch);
+#define LAUNCH_EMAP(N) hipLaunchKernelGGL((k_emap_full<N>), grid, dim3(256), 0, b->stream, b->d_desc, k, w, h, c0->stride)
+    NRG_DISPATCH(p->nrg_func, LAUNCH_EMAP)
+#undef LAUNCH_EMAP
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+
+// E5 as H/32 dependent launches of one wave per 192-column tile (any batch size)
+static int launch_dp_tiled(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
+{
+    LqrHipCarver *c0 = b->cs[0];
+    const dim3 grid((w + DPT_OWN - 1) / DPT_OWN, (unsigned) b->cs.size());
+#define LAUNCH_TILE(LRV, RIGV) hipLaunchKernelGGL((k_dp_tile<LRV, RIGV>), grid, dim3(64), 0, b->stream, b->d_desc, k, w, h, c0->stride, y0)
+    for (int y0 = 0; y0 < h; y0 += DPT_ROWS) {
+        if (lr) { if (k.use_rig) LAUNCH_TILE(true, true); else LAUNCH_TILE(true, false); }
+        else { if (k.use_rig) LAUNCH_TILE(false, true); else LAUNCH_TILE(false, false); }
+    }
+#undef LAUNCH_TILE
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+// can the persistent tiled sweep (k_dp_tile_p) take this batch?  Its tiles spin on each other, so the
+// whole grid has to be resident at once.
+// Pixels per lane of the persistent sweep for this batch: 2 while twice the tiles still fit the residency bound (the row
+// chain is then ~33 instructions per wave instead of ~58; measured per 4K seam round, 2 vs 4 px per lane:
+// 1 image 0.40 / 0.50 ms, 4: 0.45 / 0.55, 8: 0.58 / 0.62, 12: 0.76 / 0.77), else 4, 0 = not at all.
+// `general`: delta_x = 2 and / or a rigidity mask (with rigidity): those instantiations exist for 2 px per lane only
+static int dp_persistent_px(const LqrHipBatch *b, int w, bool general = false, int delta = 1)
+{
+    if (b->shared) return 0;
+    const int bound = general ? g_dpp_max_wgs_general : g_dpp_max_wgs;
+    const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, bound) : bound;
+    const size_t n = b->cs.size();
+    const int hh = b->cs[0]->wk_h;                            // the block index is DPP_BLK_BITS bits of the granule tag
+    const int maxblk = (1 << DPP_BLK_BITS) - 1;
+    if ((general || g_dpp_px_override != 4) && hh <= maxblk * dpp_rb(2, delta) && (size_t) ((w + dpp_own(2) - 1) / dpp_own(2)) * n <= (size_t) limit) return 2;
+    const int limit4 = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_px4) : g_dpp_max_wgs_px4;
+    if (!general && g_dpp_px_override != 2 && hh <= maxblk * dpp_halo(4) && (size_t) ((w + dpp_own(4) - 1) / dpp_own(4)) * n <= (size_t) limit4) return 4;
+    return 0;
+}
+static bool dp_persistent_ok(const LqrHipBatch *b, int w) { return dp_persistent_px(b, w) != 0; }
+// How many images of frame width `w` (the direction being carved) one lock-step batch may hold and still run delta_x = 2 /
+// rigidity-mask carvers on the tiled kernels (k_dp_tile_p's general instantiations: one workgroup per 64 columns per image,
+// all co-resident).  Beyond it such a batch would fall to the one-wave-per-image band kernel (~30x slower), so the host
+// carves larger batches of such carvers group after group (host/lqr_carver.c, lqrx_carver_resize_batch).  0: no bound known.
+extern "C" int lqrhip_general_batch_limit(int w)
+{
+    if (lqrhip_init() < 0 || w < 1) return 0;
+    const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_general) : g_dpp_max_wgs_general;
+    return limit / ((w + dpp_own(2) - 1) / dpp_own(2));
+}
+
+// E5 (UPDATE = false) or the full-width form of E9 (UPDATE = true) as one persistent launch
+template <bool UPDATE>
+static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
+{
+    LqrHipCarver *c0 = b->cs[0];
+    const size_t n = b->cs.size();
+    bool rigm = false;
+    for (auto *c : b->cs) rigm |= (c->rig != nullptr);
+    rigm = rigm && k.use_rig;                                  // without rigidity the mask multiplies nothing
+    const bool general = k.delta != 1 || rigm;
+    if (k.delta < 1 || k.delta > 4) return LQRHIP_EARG;
+    const int px = dp_persistent_px(b, w, general, k.delta);
+    if (!px) return LQRHIP_EARG;
+    const int ntiles = (w + dpp_own(px) - 1) / dpp_own(px);
+    int rc;
+    const size_t need_elems = ((size_t) ntiles * dpp_ex_tile(px) + 8) * n;
+    if (b->exch_elems < need_elems) {
+        HIPCK(hipStreamSynchronize(b->stream));
+        dfree(b->exch);
+        b->exch_elems = 0;
+        if ((rc = dmalloc(&b->exch, need_elems))) return rc;
+        b->exch_elems = need_elems;
+        b->exch_ntiles = 0;
+    }
+    if (b->exch_ntiles != ntiles || b->exch_n != (int) n || b->exch_px != px) {
+        // (re)lay the exchange area out: tags and finished-tile counters start at 0 (afterwards nothing is ever
+        // cleared: tags carry the launch epoch, the last tile re-arms the counter)
+        HIPCK(hipMemsetAsync(b->exch, 0, need_elems * sizeof(unsigned long long), b->stream));
+        b->exch_ntiles = ntiles; b->exch_n = (int) n; b->exch_px = px;
+    }
+    if (UPDATE) {
+        // second planes, allocated on first use -- per carver: a batch may mix carvers that already went
+        // through a tiled update on their own with fresh ones
+        bool grew = false;
+        for (auto *c : b->cs) {
+            if (c->m2 && c->least2) continue;
+            if (!grew) { HIPCK(hipStreamSynchronize(b->stream)); grew = true; }
+            const size_t pe = (size_t) c->stride * (c->wk_h + 1) + 1024;
+            const bool fresh_m2 = !c->m2, fresh_l2 = !c->least2;
+            if (!c->m2 && (rc = dmalloc(&c->m2, pe))) return rc;
+            if (!c->least2 && (rc = dmalloc(&c->least2, pe))) return rc;
+            // like the first planes (ensure_working): nothing in them depends on what the block held before
+            if (fresh_m2) HIPCK(hipMemsetAsync(c->m2, 0, pe * sizeof(float), b->stream));
+            if (fresh_l2) HIPCK(hipMemsetAsync(c->least2, 0, pe, b->stream));
+        }
+        if (grew) {
+            b->dirty = true;
+            if ((rc = batch_upload(b))) return rc;
+        }
+    }
+    const int epoch = 1 + ((b->tile_epoch++) % ((1 << (31 - DPP_BLK_BITS)) - 2));          // never 0; above the block index in the 32-bit tag
+    const dim3 grid(ntiles, (unsigned) n);
+#define LAUNCH_TILE(PXV, LRV, RIGV) hipLaunchKernelGGL((k_dp_tile_p<PXV, LRV, RIGV, UPDATE>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
+#define LAUNCH_TILE_PX(PXV)                                                                 \
+    do {                                                                                    \
+        if (lr) { if (k.use_rig) LAUNCH_TILE(PXV, true, true); else LAUNCH_TILE(PXV, true, false); }     \
+        else { if (k.use_rig) LAUNCH_TILE(PXV, false, true); else LAUNCH_TILE(PXV, false, false); }      \
+    } while (0)
+#define LAUNCH_TILE_G(LRV, RIGV, DV, RMV) hipLaunchKernelGGL((k_dp_tile_p<2, LRV, RIGV, UPDATE, DV, RMV>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
+#define LAUNCH_TILE_G_LR(RIGV, DV, RMV) do { if (lr) LAUNCH_TILE_G(true, RIGV, DV, RMV); else LAUNCH_TILE_G(false, RIGV, DV, RMV); } while (0)
+    if (general) {
+#define LAUNCH_TILE_G_D(DV) do { if (!k.use_rig) LAUNCH_TILE_G_LR(false, DV, false); else if (!rigm) LAUNCH_TILE_G_LR(true, DV, false); else LAUNCH_TILE_G_LR(true, DV, true); } while (0)
+        if (k.delta == 1) LAUNCH_TILE_G_LR(true, 1, true);
+        else if (k.delta == 2) LAUNCH_TILE_G_D(2);
+        else if (k.delta == 3) LAUNCH_TILE_G_D(3);
+        else LAUNCH_TILE_G_D(4);
+#undef LAUNCH_TILE_G_D
+    }
+    else if (px == 2) LAUNCH_TILE_PX(2); else LAUNCH_TILE_PX(4);
+#undef LAUNCH_TILE_G_LR
+#undef LAUNCH_TILE_G
+#undef LAUNCH_TILE_PX
+#undef LAUNCH_TILE
+    HIPCK(hipGetLastError());
+    if (UPDATE)       // the kernel's last tile swapped the pointers in the device descriptors: mirror it
+        for (auto *c : b->cs) { std::swap(c->m, c->m2); std::swap(c->least, c->least2); }
+    return 0;
+}
+
+template <bool UPDATE>
+static int launch_dp(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
+{
+    LqrHipCarver *c0 = b->cs[0];
+    if (!UPDATE) {
+        bool rigm = false;
+        for (auto *c : b->cs) rigm |= (c->rig != nullptr);
+        rigm = rigm && k.use_rig;
+        if (k.delta == 1 && !rigm) return dp_persistent_ok(b, w) ? launch_dp_persistent<false>(b, k, w, h, lr) : launch_dp_tiled(b, k, w, h, lr);
+        if (k.delta >= 1 && k.delta <= 4 && dp_persistent_px(b, w, true, k.delta)) return launch_dp_persistent<false>(b, k, w, h, lr);
+    }
+    int pxt = (w + DP_THREADS - 1) / DP_THREADS;
+    size_t lds = (size_t) 2 * ((w + 3) & ~3) * sizeof(float);
+    dim3 grid((unsigned) b->cs.size()), block(DP_THREADS);
+#define LAUNCH_DP(P)                                                                                                  \
+    do {                                                                                                              \
+        if (lds > 64 * 1024)                                                                                          \
+            HIPCK(hipFuncSetAttribute((const void *) k_dp_sweep<P, UPDATE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int) lds));                                                                    \
+        hipLaunchKernelGGL((k_dp_sweep<P, UPDATE>), grid, block, lds, b->stream, b->d_desc, k, w, h, c0->stride, lr); \
+    } while (0)
+    if (pxt <= 1) LAUNCH_DP(1);
+    else if (pxt <= 2) LAUNCH_DP(2);
+    else if (pxt <= 4) LAUNCH_DP(4);
+    else if (pxt <= 8) LAUNCH_DP(8);
+    else if (pxt <= 16) LAUNCH_DP(16);
+    else { g_err = "image wider than 16384 px is not supported"; return LQRHIP_EARG; }
+#undef LAUNCH_DP
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lqrhip_mmap_build(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int leftright)
+{
+    int rc;
+    if ((rc = batch_upload(b))) return rc;
+    if (p->delta_x > LQRHIP_MAX_DELTA) return LQRHIP_EARG;
+    ProfScope ps("dp_sweep", b->stream, 9.0 * w * h * b->cs.size());
+    return launch_dp<false>(b, make_dpk(p, b->cs[0]->ch), w, h, leftright);
+}
+
+#ifndef FROZEN_LAG_MAX
+#define FROZEN_LAG_MAX 128      // seams the frozen planes may lag behind before they are compacted
+#endif
+
+// remove seams [epoch, to) from the frozen planes of every carver of the batch
+static int frozen_catchup(LqrHipBatch *b, int to, int w_at_to, int h)
+{
+    LqrHipCarver *c0 = b->cs[0];
+    const int from = c0->frozen_epoch;
+    if (to <= from) return 0;
+    const int w_from = w_at_to + (to - from);
+    size_t lds = (size_t) (to - from) * sizeof(int) + (size_t) w_from + 16;
+    hipLaunchKernelGGL(k_frozen_catchup, dim3(h, (unsigned) b->cs.size()), dim3(256), lds, b->stream, b->d_desc, from, to, w_from, h,
+                       c0->stride);
+    HIPCK(hipGetLastError());
+    for (auto *c : b->cs) c->frozen_epoch = to;
+    return 0;
+}
+
+// batches up to this many pixels use the tiled full-width update (measured break-even with the band kernel at 4K, Mseams*px/s
+// tiled / band: 7 images 118 k / 97 k, 8: 130 / 109, 9: 119 / 121, 12: 130 / 139+, 16: 158 / 175+)
+// Tiles per image for k_band_tiles (0: not usable here).  All of a group's sub-batches run side by side, each with a
+// persistent grid of its own: together they must fit the residency bound of the 2-px tiled instantiations (same register
+// budget: the occupancy query below covers k_band_tiles).
+static int g_band_tiles = -1;            // -1: automatic; 0: never; n: force n tiles per image (tests)
+extern "C" void lqrhip_set_band_tiles(int t) { g_band_tiles = t; }
+static int band_tiles_T(const LqrHipBatch *b, int h)
+{
+    if (g_band_tiles == 0 || (h + 31) / 32 > BT_MAX_BLK) return 0;
+    const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_tiles) : g_dpp_max_wgs_tiles;
+    const int per_batch = limit / std::max(b->shared_n, 1);
+    int T = std::min(BT_T_MAX, per_batch / (int) std::max<size_t>(b->cs.size(), 1));
+    if (g_band_tiles > 0) T = std::min(T, g_band_tiles);
+    return T >= (g_band_tiles > 0 ? 1 : 8) ? T : 0;
+}
+// T workgroups per image: two thirds of them base tiles around the seam, the rest reserve tiles that an edge tile wakes
+// when the band comes near the edge of the set (lqrhip_set_band_tiles_reserve pins the number of reserves for tests)
+static int g_band_tiles_rsv = -1;
+extern "C" void lqrhip_set_band_tiles_reserve(int n) { g_band_tiles_rsv = n; }
+static int launch_band_tiles(LqrHipBatch *b, const DpK &k, int w, int h, int lr, int T)
+{
+    LqrHipCarver *c0 = b->cs[0];
+    const size_t n = b->cs.size();
+    int rc;
+    int n_rsv = g_band_tiles_rsv >= 0 ? std::min(g_band_tiles_rsv, T - 1) : T / 3;
+    n_rsv = std::max(0, std::min(n_rsv, BT_HDR - 2));
+    const int t_base = T - n_rsv;
+    const int ntiles_img = (w + 63) / 64;
+    const size_t need_elems = ((size_t) ntiles_img * dpp_ex_tile(2) + 2 * BT_HDR) * n;
+    if (b->exch_elems < need_elems) {
+        HIPCK(hipStreamSynchronize(b->stream));
+        dfree(b->exch);
+        b->exch_elems = 0;
+        if ((rc = dmalloc(&b->exch, need_elems))) return rc;
+        b->exch_elems = need_elems;
+        b->exch_ntiles = 0;
+    }
+    if (b->exch_ntiles != ntiles_img || b->exch_n != (int) n || b->exch_px != 102) {       // 102: this kernel's layout and tags
+        HIPCK(hipMemsetAsync(b->exch, 0, need_elems * sizeof(unsigned long long), b->stream));
+        b->exch_ntiles = ntiles_img; b->exch_n = (int) n; b->exch_px = 102;
+    }
+    // (the images' headers -- tiles finished, tickets drawn, requests -- start every launch at zero: there are two sets, a launch
+    // uses one and clears the other for the next launch; granules and request words carry the epoch)
+    const int hset = (b->bt_launches++) & 1;
+    const int epoch = 1 + ((b->tile_epoch++) % ((1 << 19) - 2));           // never 0; 19 bits above changed / active bits and block index
+    const dim3 grid(T, (unsigned) n);
+#define LAUNCH_BT(LRV, RIGV) hipLaunchKernelGGL((k_band_tiles<LRV, RIGV>), grid, dim3(128), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err, t_base, hset)
+    if (lr) { if (k.use_rig) LAUNCH_BT(true, true); else LAUNCH_BT(true, false); }
+    else { if (k.use_rig) LAUNCH_BT(false, true); else LAUNCH_BT(false, false); }
+#undef LAUNCH_BT
+    HIPCK(hipGetLastError());
+    return 0;
+}
+static const long long g_tiled_update_px = 8LL * 3840 * 2160;
+
+// One seam of a lock-step batch: k_vpath* (pick + backtrack, publishes the side to move) -> k_carve ->
+// k_emap_update -> one form of update_mmap (or the full DP after a side switch), all on the batch's stream.
+static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
+                          int full_rebuild, int leftright_next);
+// LQRHIP_DUMP=<prefix> (debugging aid): after every seam step the first image's seam, flags and DP planes go to
+// <prefix>_<call>.bin -- header {w, h, stride, log_index, FLAG_COUNT}, flags, seam_x[h], m[stride * h], least[stride * h]
+extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
+                                int full_rebuild, int leftright_next)
+{
+    const int rc = seam_step_impl(b, p, w, h, log_index, leftright_pick, full_rebuild, leftright_next);
+    static const char *dump = getenv("LQRHIP_DUMP");
+    if (rc == 0 && dump) {
+        static int call = 0;
+        LqrHipCarver *c = b->cs[0];
+        HIPCK(hipStreamSynchronize(b->stream));
+        const size_t np = (size_t) c->stride * h;
+        std::vector<int> hdr = {w, h, c->stride, log_index, FLAG_COUNT}, flags(FLAG_COUNT), seam(h);
+        std::vector<float> m(np);
+        std::vector<int8_t> least(np);
+        HIPCK(hipMemcpy(flags.data(), c->flags, FLAG_COUNT * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(seam.data(), c->seam_x, (size_t) h * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(m.data(), c->m, np * sizeof(float), hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(least.data(), c->least, np, hipMemcpyDeviceToHost));
+        char path[512];
+        snprintf(path, sizeof path, "%s_%04d.bin", dump, call++);
+        if (FILE *f = fopen(path, "wb")) {
+            fwrite(hdr.data(), sizeof(int), hdr.size(), f); fwrite(flags.data(), sizeof(int), flags.size(), f);
+            fwrite(seam.data(), sizeof(int), seam.size(), f); fwrite(m.data(), sizeof(float), np, f); fwrite(least.data(), 1, np, f);
+            fclose(f);
+        }
+    }
+    return rc;
+}
+
+static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
+                          int full_rebuild, int leftright_next)
+{
+    int rc;
+    LqrHipCarver *c0 = b->cs[0];
+    for (auto *c : b->cs)
+        if (log_index >= c->log_cap) return LQRHIP_EARG;
+    if ((rc = batch_upload(b))) return rc;
+    const unsigned n = (unsigned) b->cs.size();
+    DpK k = make_dpk(p, c0->ch);
+    const int stride = c0->stride;
+    const int wnew = w - 1;
+    const int move_dp = (wnew > 1 && !full_rebuild) ? 1 : 0;
+    bool has_rigmask = false;
+    for (auto *c : b->cs) has_rigmask |= (c->rig != nullptr);
+    // bytes the carve moves per pixel of the side it moves, read + write: en 4 (+ m 4 + back pointer 1 unless a full DP follows,
+    // + the rigidity mask 4) -- k_vpath* knows how many pixels that is for the seam it finds and keeps the sum (lqrhip_moved_bytes)
+    const int moved_unit = 2 * (4 + (move_dp ? 5 : 0) + (has_rigmask ? 4 : 0));
+    {
+        ProfScope ps("vpath", b->stream, 0);
+        if (p->delta_x == 1)
+            hipLaunchKernelGGL(k_vpath1<1>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit);
+        else if (p->delta_x == 2)
+            hipLaunchKernelGGL(k_vpath1<2>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit);
+        else if (p->delta_x == 3)
+            hipLaunchKernelGGL(k_vpath1<3>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit);
+        else if (p->delta_x == 4)
+            hipLaunchKernelGGL(k_vpath1<4>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit);
+        else
+            hipLaunchKernelGGL(k_vpath, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, p->delta_x,
+                               log_index, moved_unit);
+    }
+    {
+        // algorithmic bytes of one carve launch: read + write of one 4-byte
+        // plane over the half of each row right of the seam = 8 B * w*h/2 per image
+        ProfScope ps("carve", b->stream, 4.0 * (double) w * h * n);
+        hipLaunchKernelGGL(k_carve, dim3((h + 3) / 4, n), dim3(256), 0, b->stream, b->d_desc, w, h, stride, p->delta_x, move_dp);
+    }
+    if (wnew <= 1) {            // liblqr's finish_vsmap case: nothing left to update
+        HIPCK(hipGetLastError());
+        return 0;
+    }
+    {
+        ProfScope ps("emap_update", b->stream, 0);
+        // the energy update walks the seam log back to the frozen frame (O(lag) per sample); compacting the frozen planes
+        // costs a pass over them.  Few images: the walk is on the critical path and the pass is cheap -> short lag
+        const int lag_max = n <= 4 ? FROZEN_LAG_MAX / 4 : FROZEN_LAG_MAX;
+        if (log_index + 1 - c0->frozen_epoch > lag_max && (rc = frozen_catchup(b, log_index + 1, wnew, h))) return rc;
+        const int epoch = c0->frozen_epoch;
+#define LAUNCH_EUPD_NT(N, NT) hipLaunchKernelGGL((k_emap_update<N, NT>), dim3((h + EU_ROWS - 1) / EU_ROWS, n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, log_index, epoch)
+#define LAUNCH_EUPD(N) do { if (p->delta_x <= 2) LAUNCH_EUPD_NT(N, 12); else if (p->delta_x <= 8) LAUNCH_EUPD_NT(N, 36); else LAUNCH_EUPD_NT(N, 68); } while (0)
+        NRG_DISPATCH(p->nrg_func, LAUNCH_EUPD)
+#undef LAUNCH_EUPD
+#undef LAUNCH_EUPD_NT
+    }
+    if (full_rebuild) {
+        ProfScope ps("dp_sweep", b->stream, 9.0 * wnew * h * n);
+        if ((rc = launch_dp<false>(b, k, wnew, h, leftright_next))) return rc;
+        HIPCK(hipGetLastError());
+        return 0;
+    }
+    // How E9 (update_mmap) runs.  Small batches: the whole chip recomputing every row (tiled full-width keep-rule
+    // sweep) beats the one-workgroup-per-image band walk; for large batches its 14 B/px of traffic would not.
+    // "plain": delta_x = 1 and no rigidity mask that matters -- every fast kernel.  delta_x = 2 and rigidity masks run on the
+    // tiled full-width update (k_dp_tile_p's general instantiations) whenever its grid fits; only beyond that do they fall
+    // to the one-wave-per-image band kernel and the one-workgroup-per-image sweep (measured at 8K: 37x slower)
+    const bool rigm = has_rigmask && p->use_rigidity;
+    const bool fast_ok = p->delta_x == 1 && !rigm && g_update_mode != 3;
+    const bool tiled_update = fast_ok ? ((g_update_mode < 0 ? (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px : g_update_mode == 1) &&
+                                         dp_persistent_ok(b, w))
+                                      : (p->delta_x >= 1 && p->delta_x <= 4 && g_update_mode != 0 && g_update_mode != 2 && g_update_mode != 3 && dp_persistent_px(b, w, true, p->delta_x) != 0);
+    // Batches of 8 to ~40 images: the band spread over several CUs per image (k_band_tiles).  Measured (Mseams*px/s, 4K, tiles /
+    // k_band_update_tw or the full-width tiled update): 4 images 80 k / 93 k (the full-width tiled update stays), 8: 145 / 127,
+    // 12: 195 / 152, 16: 246 / 193, 24: 294 / 260, 32: 382 / 341, 40: 423 / 398, 48: 434 / 448, 64: 488 / 510-540 -- beyond ~500
+    // resident tile workgroups the carves of the sibling streams are starved of registers, so large groups
+    // keep k_band_update_tw.
+    {
+        const int T = (fast_ok && (g_update_mode < 0 || g_update_mode == 4)) ? band_tiles_T(b, h) : 0;
+        const size_t group_images = (size_t) n * (size_t) std::max(b->shared_n, 1);
+        if (T > 0 && (g_update_mode == 4 || (group_images >= 8 && group_images * (size_t) T <= 480))) {
+            {
+                ProfScope ps("band_update", b->stream, 0);
+                if ((rc = launch_band_tiles(b, k, wnew, h, leftright_next, T))) return rc;
+            }
+            ProfScope ps("dp_update", b->stream, 0);
+            if ((rc = launch_dp<true>(b, k, wnew, h, leftright_next))) return rc;
+            HIPCK(hipGetLastError());
+            return 0;
+        }
+    }
+    if (tiled_update) {
+        ProfScope ps("dp_update_tiled", b->stream, 0);
+        if ((rc = launch_dp_persistent<true>(b, k, wnew, h, leftright_next))) return rc;
+        HIPCK(hipGetLastError());
+        return 0;
+    }
+    const bool fast_band = fast_ok && (size_t) h * sizeof(int) <= 60 * 1024;
+    // the trapezoid-wave band kernel takes rows up to ~4200 px (wider rows: the changes outgrow its 896-column window
+    // too often, and an 8-slot build spills registers); beyond that, and in update mode 2, k_band_update_mw
+    const bool band_tw = fast_band && g_update_mode != 2 && wnew <= 4200 && (size_t) 2 * h * sizeof(int) <= 64 * 1024;
+    if (band_tw) {
+        ProfScope ps("band_update", b->stream, 0);
+#define LAUNCH_TW(LRV, RIGV) hipLaunchKernelGGL((k_band_update_tw<4, LRV, RIGV>), dim3(n), dim3(128 * 4), (size_t) 2 * h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, g_dev_err)
+        if (leftright_next) { if (p->use_rigidity) LAUNCH_TW(true, true); else LAUNCH_TW(true, false); }
+        else { if (p->use_rigidity) LAUNCH_TW(false, true); else LAUNCH_TW(false, false); }
+#undef LAUNCH_TW
+    } else if (fast_band) {
+        ProfScope ps("band_update", b->stream, 0);
+#define LAUNCH_MW(NWV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_mw<2, NWV, 8, LRV, RIGV>), dim3(n), dim3(64 * NWV), (size_t) h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride)
+#define LAUNCH_MW_N(LRV, RIGV) do { if (wnew > 4200) LAUNCH_MW(16, LRV, RIGV); /* 8K: dirty regions up to ~900 px */ else LAUNCH_MW(8, LRV, RIGV); } while (0)
+        if (leftright_next) { if (p->use_rigidity) LAUNCH_MW_N(true, true); else LAUNCH_MW_N(true, false); }
+        else { if (p->use_rigidity) LAUNCH_MW_N(false, true); else LAUNCH_MW_N(false, false); }
+#undef LAUNCH_MW_N
+#undef LAUNCH_MW
+    } else {
+        ProfScope ps("band_update", b->stream, 0);
+        hipLaunchKernelGGL(k_band_update, dim3(n), dim3(64), 0, b->stream, b->d_desc, k, wnew, h, stride, leftright_next);
+    }
+    {
+        // rows the band kernel handed over (flags[FLAG_OVF_ROW] .. h): the keep rule over the full width
+        ProfScope ps("dp_update", b->stream, 0);
+        if ((rc = launch_dp<true>(b, k, wnew, h, leftright_next))) return rc;
+    }
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lqrhip_seam_log_reserve(LqrHipBatch *b, int n_seams, int h)
+{
+    int rc;
+    for (auto *c : b->cs) if ((rc = ensure_log(c, n_seams, h))) return rc;
+    return 0;
+}
+
+extern "C" int lqrhip_vs_commit(LqrHipBatch *b, int w0, int h0, int wc0, int n_seams, int first_level, int finish)
+{
+    int rc;
+    if ((rc = batch_upload(b))) return rc;
+    size_t lds = ((size_t) n_seams + wc0) * sizeof(int);
+    if (lds > 150 * 1024) { g_err = "vs_commit: session too large for LDS"; return LQRHIP_EARG; }
+    if (lds > 64 * 1024)
+        HIPCK(hipFuncSetAttribute((const void *) k_vs_commit, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    hipLaunchKernelGGL(k_vs_commit, dim3(h0, (unsigned) b->cs.size()), dim3(256), lds, b->stream, b->d_desc, w0, h0, wc0, n_seams,
+                       first_level, finish);
+    HIPCK(hipGetLastError());
+    // the session is over: bring the frozen planes to the carved frame, the log restarts at 0
+    if ((rc = frozen_catchup(b, n_seams, wc0 - n_seams, h0))) return rc;
+    for (auto *c : b->cs) c->frozen_epoch = 0;
+    return 0;
+}
+
+// E14 / E11: every carver of the batch (roots and their attached carvers) goes through ONE launch (a job table in device
+// memory, one grid slice of blocks per job); the new planes replace the old ones after its synchronisation.  Everything
+// staged for the pass is owned by a PlaneJobs object until then: any error return gives all of it back to the pool.
+struct PlaneJob {
+    LqrHipCarver *c;
+    uint8_t *nrgb;
+    float *nbias, *nrig;
+};
+struct PlaneJobs {
+    std::vector<PlaneJob> jobs;
+    std::vector<InflateDev> dev;
+    std::vector<int32_t *> new_vs;          // one per root (may be null)
+    InflateDev *d_jobs = nullptr;
+    bool committed = false;
+    ~PlaneJobs()
+    {
+        dfree(d_jobs);
+        if (committed) return;
+        for (auto &j : jobs) { dfree(j.nrgb); dfree(j.nbias); dfree(j.nrig); }
+        for (auto *&v : new_vs) dfree(v);
+    }
+    // stage the output planes of carver c: n1 pixels each
+    int add(LqrHipCarver *c, const int32_t *vs_old, int32_t *nvs, size_t n1)
+    {
+        PlaneJob j{c, nullptr, nullptr, nullptr};
+        int rc = dmalloc(&j.nrgb, n1 * c->ch);
+        if (!rc && c->bias0) rc = dmalloc(&j.nbias, n1);
+        if (!rc && c->rig0) rc = dmalloc(&j.nrig, n1);
+        jobs.push_back(j);                  // owned from here on, also when rc != 0
+        if (rc) return rc;
+        dev.push_back(InflateDev{c->rgb0, vs_old, c->bias0, c->rig0, j.nrgb, nvs, j.nbias, j.nrig, c->ch});
+        return 0;
+    }
+    int upload(hipStream_t s)
+    {
+        int rc = dmalloc(&d_jobs, dev.size());
+        if (rc) return rc;
+        HIPCK(hipMemcpyAsync(d_jobs, dev.data(), dev.size() * sizeof(InflateDev), hipMemcpyHostToDevice, s));
+        return 0;
+    }
+    // after the pass has completed: the new base planes become the carvers'
+    void commit()
+    {
+        for (auto &j : jobs) {
+            dfree(j.c->rgb0); j.c->rgb0 = j.nrgb;
+            if (j.nbias) { dfree(j.c->bias0); j.c->bias0 = j.nbias; }
+            if (j.nrig) { dfree(j.c->rig0); j.c->rig0 = j.nrig; }
+        }
+        committed = true;
+    }
+};
+
+extern "C" int lqrhip_inflate(LqrHipBatch *b, int w0, int h0, int l, int max_level)
+{
+    int rc;
+    const int w1 = w0 + l - max_level + 1;
+    PlaneJobs pj;
+    for (auto *c : b->cs) {
+        int32_t *nvs = nullptr;
+        if ((rc = dmalloc(&nvs, (size_t) w1 * h0))) return rc;
+        pj.new_vs.push_back(nvs);
+        for (auto *a : c->aux)
+            if ((rc = pj.add(a, c->vs, nullptr, (size_t) w1 * h0))) return rc;
+        if ((rc = pj.add(c, c->vs, nvs, (size_t) w1 * h0))) return rc;
+    }
+    if ((rc = pj.upload(b->stream))) return rc;
+    hipLaunchKernelGGL(k_inflate, dim3(h0, (unsigned) pj.dev.size()), dim3(256), 0, b->stream, pj.d_jobs, w0, w1, l, max_level);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(b->stream));
+    pj.commit();
+    for (auto &j : pj.jobs) j.c->w0 = w1;
+    size_t i = 0;
+    for (auto *c : b->cs) {
+        dfree(c->vs);
+        c->vs = pj.new_vs[i++];
+        for (auto *a : c->aux) a->vs = c->vs;
+    }
+    b->dirty = true;
+    return 0;
+}
+
+extern "C" int lqrhip_flatten(LqrHipBatch *b, int w0, int h0, int w, int level)
+{
+    int rc;
+    PlaneJobs pj;
+    for (auto *c : b->cs) {
+        int32_t *nvs = nullptr;                 // the flat carver's visibility map: all zero
+        if ((rc = dmalloc(&nvs, (size_t) w * h0))) return rc;
+        pj.new_vs.push_back(nvs);
+        HIPCK(hipMemsetAsync(nvs, 0, (size_t) w * h0 * sizeof(int32_t), b->stream));
+        for (auto *a : c->aux)
+            if ((rc = pj.add(a, c->vs, nullptr, (size_t) w * h0))) return rc;
+        if ((rc = pj.add(c, c->vs, nullptr, (size_t) w * h0))) return rc;
+    }
+    if ((rc = pj.upload(b->stream))) return rc;
+    hipLaunchKernelGGL(k_compact_jobs, dim3(h0, (unsigned) pj.dev.size()), dim3(256), 0, b->stream, pj.d_jobs, w0, w, level);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(b->stream));
+    pj.commit();
+    for (auto &j : pj.jobs) j.c->w0 = w;
+    size_t i = 0;
+    for (auto *c : b->cs) {
+        dfree(c->vs);
+        c->vs = pj.new_vs[i++];
+        for (auto *a : c->aux) a->vs = c->vs;
+    }
+    b->dirty = true;
+    return 0;
+}
+
+extern "C" int lqrhip_transpose(LqrHipBatch *b, int w, int h)
+{
+    int rc;
+    PlaneJobs pj;
+    for (auto *c : b->cs) {
+        for (auto *a : c->aux)
+            if ((rc = pj.add(a, nullptr, nullptr, (size_t) w * h))) return rc;
+        if ((rc = pj.add(c, nullptr, nullptr, (size_t) w * h))) return rc;
+        HIPCK(hipMemsetAsync(c->vs, 0, (size_t) w * h * sizeof(int32_t), b->stream));   // flat carver: all zero already
+    }
+    if ((rc = pj.upload(b->stream))) return rc;
+    hipLaunchKernelGGL(k_transpose, dim3((w + 31) / 32, (h + 31) / 32, (unsigned) pj.dev.size()), dim3(32, 8), 0, b->stream, pj.d_jobs, w, h);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(b->stream));
+    pj.commit();
+    for (auto &j : pj.jobs) { j.c->w0 = h; j.c->h0 = w; }
+    b->dirty = true;
+    return 0;
+}
+
+// ---- read-back ---------------------------------------------------------------
+extern "C" int lqrhip_read_visible(LqrHipCarver *c, int w0, int h0, int w, int level, unsigned char *out)
+{
+    int rc = batch_sync_of(c);
+    if (rc) return rc;
+    uint8_t *d = nullptr;
+    size_t n = (size_t) w * h0 * c->ch;
+    if ((rc = dmalloc(&d, n))) return rc;
+    auto run = [&]() -> int {
+        hipLaunchKernelGGL(k_compact, dim3(h0), dim3(256), 0, g_stream0, c->rgb0, c->vs, (const float *) nullptr, (const float *) nullptr,
+                           d, (float *) nullptr, (float *) nullptr, (int32_t *) nullptr, w0, w, c->ch, level, 0);
+        HIPCK(hipGetLastError());
+        return d2h_staged(out, d, n);
+    };
+    rc = run();
+    if (rc) (void) hipStreamSynchronize(g_stream0);
+    dfree(d);
+    return rc;
+}
+
+extern "C" int lqrhip_read_visible_device(LqrHipCarver *c, int w0, int h0, int w, int level, void *device_out)
+{
+    int rc = batch_sync_of(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_compact, dim3(h0), dim3(256), 0, g_stream0, c->rgb0, c->vs, (const float *) nullptr, (const float *) nullptr,
+                       (uint8_t *) device_out, (float *) nullptr, (float *) nullptr, (int32_t *) nullptr, w0, w, c->ch, level, 0);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(g_stream0));
+    return 0;
+}
+
+extern "C" int lqrhip_mask_line_max(const unsigned char *mask, int channels, int width, int height, int a0, int b0, int n_lines,
+                                    int line_len, int direction)
+{
+    if (lqrhip_init() < 0) return LQRHIP_EHIP;
+    if (n_lines <= 0 || line_len <= 0) return 0;
+    uint8_t *d = nullptr;
+    int *dout = nullptr;
+    int rc, result = 0;
+    size_t bytes = (size_t) width * height * channels;
+    if ((rc = dmalloc(&d, bytes)) || (rc = dmalloc(&dout, 1))) { dfree(d); return rc; }
+    auto run = [&]() -> int {
+        HIPCK(hipMemcpyAsync(d, mask, bytes, hipMemcpyHostToDevice, g_stream0));
+        HIPCK(hipMemsetAsync(dout, 0, sizeof(int), g_stream0));
+        hipLaunchKernelGGL(k_mask_line_max, dim3(n_lines), dim3(256), 0, g_stream0, d, channels, width, a0, b0, line_len, direction, dout);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(&result, dout, sizeof(int), hipMemcpyDeviceToHost, g_stream0));
+        HIPCK(hipStreamSynchronize(g_stream0));
+        return 0;
+    };
+    rc = run();
+    if (rc) (void) hipStreamSynchronize(g_stream0);
+    dfree(d); dfree(dout);
+    return rc ? rc : result;
+}
+
+extern "C" void lqrhip_pool_trim(void)
+{
+    (void) hipDeviceSynchronize();
+    for (auto &kv : g_pool_free) { (void) hipFree(kv.second); g_pool_size.erase(kv.second); }
+    g_pool_free.clear();
+    g_pool_cached = 0;
+}
+
+extern "C" int lqrhip_device_sync(void)
+{
+    HIPCK(hipDeviceSynchronize());
+    return check_dev_error();
+}
+
+extern "C" int lqrhip_read_vmap(LqrHipCarver *c, int w0, int h0, int w, int level, int depth, int *out)
+{
+    int rc = batch_sync_of(c);
+    if (rc) return rc;
+    int32_t *d = nullptr;
+    size_t n = (size_t) w * h0;
+    if ((rc = dmalloc(&d, n))) return rc;
+    auto run = [&]() -> int {
+        hipLaunchKernelGGL(k_compact, dim3(h0), dim3(256), 0, g_stream0, (const uint8_t *) nullptr, c->vs, (const float *) nullptr,
+                           (const float *) nullptr, (uint8_t *) nullptr, (float *) nullptr, (float *) nullptr, d, w0, w, c->ch, level,
+                           depth);
+        HIPCK(hipGetLastError());
+        return d2h_staged(out, d, n * sizeof(int32_t));
+    };
+    rc = run();
+    if (rc) (void) hipStreamSynchronize(g_stream0);
+    dfree(d);
+    return rc;
+}
+
+extern "C" int lqrhip_read_working(LqrHipCarver *c, int w, int h, float *en, float *m, int *least_dx)
+{
+    int rc = batch_sync_of(c);
+    if (rc) return rc;
+    if (!c->pix) return LQRHIP_EARG;
+    int32_t fl[FLAG_COUNT];
+    HIPCK(hipMemcpy(fl, c->flags, sizeof fl, hipMemcpyDeviceToHost));
+    const int org = fl[FLAG_ORG];                 // the carved planes start `org` elements into each row
+    size_t n = (size_t) c->stride * h;
+    std::vector<float> t(n);
+    std::vector<int8_t> tl(n);
+    if (en) {
+        HIPCK(hipMemcpy(t.data(), c->en, n * sizeof(float), hipMemcpyDeviceToHost));
+        for (int y = 0; y < h; y++) memcpy(en + (size_t) y * w, t.data() + (size_t) y * c->stride + org, (size_t) w * sizeof(float));
+    }
+    if (m) {
+        HIPCK(hipMemcpy(t.data(), c->m, n * sizeof(float), hipMemcpyDeviceToHost));
+        for (int y = 0; y < h; y++) memcpy(m + (size_t) y * w, t.data() + (size_t) y * c->stride + org, (size_t) w * sizeof(float));
+    }
+    if (least_dx) {
+        HIPCK(hipMemcpy(tl.data(), c->least, n, hipMemcpyDeviceToHost));
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) least_dx[(size_t) y * w + x] = y == 0 ? 0 : (int) tl[(size_t) y * c->stride + org + x];
+    }
+    return 0;
+}
+
+// ---- start over from a device-resident image ---------------------------------------------------
+extern "C" int lqrhip_carver_reset(LqrHipCarver *c, const void *device_rgb, int w, int h)
+{
+    if (!c || c->root || !c->aux.empty() || w < 1 || h < 1) return LQRHIP_EARG;
+    int rc = batch_sync_of(c);
+    if (rc) return rc;
+    const size_t n = (size_t) w * h;
+    dfree(c->rgb0); dfree(c->vs); dfree(c->bias0); dfree(c->rig0);
+    // a carver that had masks carries bias / rig working planes: the fresh carver has none
+    if (c->bias || c->rig) { free_working(c); c->stride = 0; c->wk_h = 0; }
+    c->w0 = w; c->h0 = h;
+    c->frozen_epoch = 0;
+    if ((rc = dmalloc(&c->rgb0, n * c->ch)) || (rc = dmalloc(&c->vs, n))) return rc;
+    HIPCK(hipMemcpyAsync(c->rgb0, device_rgb, n * c->ch, hipMemcpyDeviceToDevice, g_stream0));
+    HIPCK(hipMemsetAsync(c->vs, 0, n * sizeof(int32_t), g_stream0));
+    if (c->batch) c->batch->dirty = true;
+    if (c->active && (rc = ensure_working(c, w, h))) return rc;        // synchronises g_stream0 when it allocates
+    return 0;
+}
+
+// order everything the shim enqueued on its own stream (resets, mask uploads) before the caller goes on
+extern "C" int lqrhip_reset_sync(void)
+{
+    if (g_stream0) HIPCK(hipStreamSynchronize(g_stream0));
+    return 0;
+}
+
+extern "C" int lqrhip_mem_info(unsigned long long *free_bytes, unsigned long long *total_bytes, unsigned long long *cached_bytes)
+{
+    if (lqrhip_init() < 0) return LQRHIP_EHIP;
+    size_t f = 0, t = 0;
+    HIPCK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    if (cached_bytes) *cached_bytes = g_pool_cached;
+    return 0;
+}
+
+// ---- measured HBM ceiling: streaming copy, ONE 16-byte element per thread, non-temporal -- the form that measured
+// fastest on this device (6.5 TB/s read + write at 2 GiB; grid-stride loops with 1-8 loads in flight per thread and
+// 1k-64k workgroups: 4.4-5.8 TB/s; scripts/dbg/t_copy.hip)
+__global__ __launch_bounds__(256) void k_copy16(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t n16)
+{
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load((const GLOBAL_AS u32x4 *) src + i), (GLOBAL_AS u32x4 *) dst + i);
+}
+
+extern "C" int lqrhip_copy_bandwidth(unsigned long long bytes, int iters, double *gbps)
+{
+    if (lqrhip_init() < 0) return LQRHIP_EHIP;
+    if (iters < 1 || bytes < 4096) return LQRHIP_EARG;
+    uint8_t *a = nullptr, *b = nullptr;
+    int rc;
+    if ((rc = dmalloc(&a, bytes)) || (rc = dmalloc(&b, bytes))) { dfree(a); return rc; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0;
+    const size_t n16 = bytes / 16;
+    auto run = [&]() -> int {
+        HIPCK(hipMemsetAsync(a, 1, bytes, g_stream0));
+        HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
+        const dim3 grid((unsigned) ((n16 + 255) / 256));
+        hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, g_stream0, (const u32x4 *) a, (u32x4 *) b, n16);     // warm-up
+        HIPCK(hipEventRecord(e0, g_stream0));
+        for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, g_stream0, (const u32x4 *) a, (u32x4 *) b, n16);
+        HIPCK(hipEventRecord(e1, g_stream0));
+        HIPCK(hipStreamSynchronize(g_stream0));
+        HIPCK(hipEventElapsedTime(&ms, e0, e1));
+        return 0;
+    };
+    rc = run();
+    if (rc) (void) hipStreamSynchronize(g_stream0);
+    if (e0) (void) hipEventDestroy(e0);
+    if (e1) (void) hipEventDestroy(e1);
+    dfree(a); dfree(b);
+    if (rc) return rc;
+    if (gbps) *gbps = 2.0 * (double) (n16 * 16) * iters / (ms * 1e-3) / 1e9;
+    return 0;
+}
+
+// ---- seam-map colour ramp -----------------------------------------------------
+// write_vmap_to_layer's per-pixel arithmetic, src/io_functions.c:249-279, in double with every
+// operation individually rounded; (guchar)(255 * x) truncates.  One thread per pixel, streaming.
+__global__ __launch_bounds__(256) void k_vmap_ramp(const int32_t *__restrict__ vmap, uint32_t *__restrict__ out, size_t n, int depth,
+                                                   double sr, double sg, double sb, double er, double eg, double eb)
+{
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int vs = vmap[i];
+    uint32_t px = 0;                                                     // vs == 0: all four bytes 0 (:253-259)
+    if (vs != 0) {
+        const double value = __ddiv_rn((double) (depth + 1 - vs), (double) (depth + 1));        // :263
+        const double inv = __dsub_rn(1.0, value);
+        const double rd = __dadd_rn(__dmul_rn(value, sr), __dmul_rn(inv, er));                    // :264
+        const double gr = __dadd_rn(__dmul_rn(value, sg), __dmul_rn(inv, eg));                    // :265
+        const double bl = __dadd_rn(__dmul_rn(value, sb), __dmul_rn(inv, eb));                    // :266
+        const double al = __dmul_rn(0.5, __dadd_rn(1.0, value));                                  // :267
+        // (guchar) of a double: truncation towards zero, then the low 8 bits (values are in [0, 255])
+        const uint32_t r8 = (uint32_t) (int) __dmul_rn(255.0, rd) & 0xffu, g8 = (uint32_t) (int) __dmul_rn(255.0, gr) & 0xffu;
+        const uint32_t b8 = (uint32_t) (int) __dmul_rn(255.0, bl) & 0xffu, a8 = (uint32_t) (int) __dmul_rn(255.0, al) & 0xffu;
+        px = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
+    }
+    out[i] = px;
+}
+
+extern "C" int lqrhip_vmap_to_rgba(const int *vmap, int w, int h, int depth, const double col_start[3], const double col_end[3],
+                                   unsigned char *out_rgba)
+{
+    if (lqrhip_init() < 0) return LQRHIP_EHIP;
+    if (!vmap || !out_rgba || w < 1 || h < 1) return LQRHIP_EARG;
+    const size_t n = (size_t) w * h;
+    int32_t *dv = nullptr;
+    uint32_t *dout = nullptr;
+    int rc;
+    if ((rc = dmalloc(&dv, n)) || (rc = dmalloc(&dout, n))) { dfree(dv); return rc; }
+    auto run = [&]() -> int {
+        HIPCK(hipMemcpyAsync(dv, vmap, n * sizeof(int32_t), hipMemcpyHostToDevice, g_stream0));
+        hipLaunchKernelGGL(k_vmap_ramp, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, g_stream0, dv, dout, n, depth, col_start[0], col_start[1],
+                           col_start[2], col_end[0], col_end[1], col_end[2]);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(out_rgba, dout, n * 4, hipMemcpyDeviceToHost, g_stream0));
+        HIPCK(hipStreamSynchronize(g_stream0));
+        return 0;
+    };
+    rc = run();
+    if (rc) (void) hipStreamSynchronize(g_stream0);      // nothing may still use the blocks when they go back to the pool
+    dfree(dv); dfree(dout);
+    return rc;
+}

@@ -292,6 +292,13 @@ static void set_width_tree(LqrCarver *r, int w1)
     for (l = r->attached; l; l = l->next) set_width_tree(l->current, w1);
 }
 
+/* delta_x = 2 .. 4, or a rigidity mask that matters: the carver runs on the tiled kernels' general instantiations, which need
+ * the whole group co-resident on ONE stream */
+static int is_general(const LqrCarver *c)
+{
+    return (c->delta_x >= 2 && c->delta_x <= 4) || (c->delta_x == 1 && c->has_rigmask && c->rigidity != 0);
+}
+
 static LqrRetVal group_open(Group *g, LqrCarver **rs, int n)
 {
     int i, k;
@@ -307,7 +314,10 @@ static LqrRetVal group_open(Group *g, LqrCarver **rs, int n)
         g->nb = 1;
     } else {
         LqrHipCarver **ds = (LqrHipCarver **) malloc((size_t) n * sizeof *ds);
-        int nb = lqrhip_sub_batches(n);
+        /* sub-batch streams are for the plain kernels: a shared batch never runs the persistent tiled kernels, and a general
+         * group of 32 or more (small images: the limit of lqrx_carver_resize_batch is in tiles, not images) would fall to the
+         * one-wave-per-image kernels, ~30x slower */
+        int nb = is_general(rs[0]) ? 1 : lqrhip_sub_batches(n);
         if (nb < 1) nb = 1;
         if (nb > MAX_SUB) nb = MAX_SUB;
         if (nb > n) nb = n;
@@ -678,15 +688,19 @@ LqrRetVal lqrx_carver_resize_batch(LqrCarver **carvers, gint n, gint w1, gint h1
          * co-resident; a larger group would fall to the one-wave-per-image kernels (~30x slower).  The images are
          * independent, so such a group is carved in consecutive sub-groups that fit. */
         const LqrCarver *c = carvers[0];
-        const int general = (c->delta_x >= 2 && c->delta_x <= 4) || (c->delta_x == 1 && c->has_rigmask && c->rigidity != 0);
-        if (general) {
+        if (is_general(c)) {
             int wmax = c->w_start > c->h_start ? c->w_start : c->h_start, lim;   /* either direction may be carved, shrinking or enlarging */
             if (w1 > wmax) wmax = w1;
             if (h1 > wmax) wmax = h1;
             lim = lqrhip_general_batch_limit(wmax);
             if (lim >= 1 && n > lim) {
-                for (i = 0; i < n; i += lim) LQR_CATCH(group_resize(carvers + i, n - i < lim ? n - i : lim, w1, h1));
-                return LQR_OK;
+                /* every sub-group is carved whatever the others returned (the images are independent); the first error is reported */
+                LqrRetVal first = LQR_OK;
+                for (i = 0; i < n; i += lim) {
+                    const LqrRetVal r = group_resize(carvers + i, n - i < lim ? n - i : lim, w1, h1);
+                    if (first == LQR_OK) first = r;
+                }
+                return first;
             }
         }
         return group_resize(carvers, n, w1, h1);

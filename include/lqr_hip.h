@@ -186,6 +186,13 @@ void lqrhip_prof_reset(void);
 int lqrhip_prof_get(const char *kernel, double *ms_total, long long *launches, double *bytes_total);
 /* time during which at least one launch of `kernel` was running (launches of sub-batch streams overlap) */
 int lqrhip_prof_get_union(const char *kernel, double *ms_union);
+/* Bytes the carves of this process HAD to move (read + write) since the last reset: k_vpath* knows, for the seam it found, how
+ * many pixels lie on the side the carve will move, and sums pixels x bytes per pixel (en; m and back pointer unless a full DP
+ * follows; the rigidity mask) over images and seams.  The roofline's numerator next to SURVEY 8(d)'s half-row figure. */
+int lqrhip_moved_bytes(unsigned long long *bytes, int reset);
+/* k_band_tiles' rare events since the last reset: [0] images not covered by their tile set, [1] images aborted at an edge,
+ * [2] reserve tiles woken, [3] requests that found no reserve left */
+int lqrhip_band_tiles_stats(unsigned long long *out8, int reset);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,4 @@
-"""per-phase cycle accounting of k_dp_tile_p<UPDATE> (library built with -DLQR_TILE_TIMING), one image: the middle tile's two waves"""
+"""per-phase cycle accounting of k_dp_tile_p<UPDATE> (library built with make -C gimp-lqr-plugin_amd EXTRA=-DLQR_TIMING), one image: the middle tile's two waves"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,4 +1,4 @@
-"""Where a k_band_tiles launch goes (a -DLQR_BT_TIMING build: make -C gimp-lqr-plugin_amd SCHED="-mllvm -amdgpu-sched-strategy=max-ilp -DLQR_BT_TIMING"):
+"""Where a k_band_tiles launch goes (a timing build: make -C gimp-lqr-plugin_amd EXTRA=-DLQR_TIMING):
 cycles per phase, per tile slot of image 0 and wave, of the LAST launch.   python scripts/exp_tile_timing_bt.py [images]"""
 import ctypes as C, os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

@@ -30,8 +30,4 @@ def engine():
     or the GPU is missing."""
     import lqr_ctypes
     api = lqr_ctypes.engine_api()
-    if os.environ.get("LQR_BAND_KERNEL"):          # A/B runs of the suite against one band-kernel variant (-DLQR_BAND_EXPERIMENTS builds)
-        import ctypes
-        api.lib.lqrhip_set_band_kernel.argtypes = [ctypes.c_int]
-        api.lib.lqrhip_set_band_kernel(int(os.environ["LQR_BAND_KERNEL"]))
     return api

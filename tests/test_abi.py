@@ -52,8 +52,10 @@ def test_engine_does_not_link_or_reference_the_oracle():
     assert "oracle" not in out
     syms = os.popen("nm -D '%s'" % L.ENGINE_LIB).read()
     assert "olqr_" not in syms
-    for src in ("gimp-lqr-plugin_amd/host/lqr_carver.c", "gimp-lqr-plugin_amd/csrc/lqr_hip.hip", "gimp-lqr-plugin_amd/__init__.py",
-                "gimp-lqr-plugin_amd/binding.py"):
+    import glob
+    csrc = sorted(os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROOT, "gimp-lqr-plugin_amd", "csrc", "*")))
+    assert "gimp-lqr-plugin_amd/csrc/lqr_shim.hip" in csrc and len(csrc) >= 9          # every translation unit and both headers
+    for src in ["gimp-lqr-plugin_amd/host/lqr_carver.c", "gimp-lqr-plugin_amd/__init__.py", "gimp-lqr-plugin_amd/binding.py"] + csrc:
         text = open(os.path.join(ROOT, src)).read()
         assert "oracle/" not in text and "olqr_" not in text and "liblqr_oracle" not in text, src
 

@@ -1,0 +1,95 @@
+"""Round 5 (-m gpu).
+* A lock-step group of 32 or more delta_x = 2 / rigidity-mask carvers that fits the tiled kernels' residency bound is NOT split
+  over sub-batch streams (shared batches never run the persistent kernels: ADVICE r4 -- such a group fell to the
+  one-wave-per-image kernels, ~30x slower, now that the library sets GPU_MAX_HW_QUEUES=8 itself).
+* lqrhip_moved_bytes: the bytes the carves had to move, as k_vpath* counts them, against a count made from the seam maps.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import datasets as D
+import harness as H
+import lqr_ctypes as L
+
+pytestmark = pytest.mark.gpu
+
+
+def prof_launches(lib, name):
+    ms, n, by = ctypes.c_double(0), ctypes.c_longlong(0), ctypes.c_double(0)
+    lib.lqrhip_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by))
+    return n.value
+
+
+@pytest.mark.parametrize("variant", ["delta2", "rigmask"])
+def test_general_group_of_36_small_images_stays_on_the_tiled_kernels(oracle, engine, variant):
+    lib = engine.lib
+    lib.lqrhip_sub_batches.argtypes = [ctypes.c_int]
+    lib.lqrhip_set_sub_batches.argtypes = [ctypes.c_int]
+    lib.lqrhip_general_batch_limit.argtypes = [ctypes.c_int]
+    w, h, n = 150, 70, 36
+    kw = dict(delta2=dict(delta_x=2), rigmask=dict(rigidity=5.0))[variant]
+    rigm = D.top_half_mask(w, h) if variant == "rigmask" else None
+    assert lib.lqrhip_general_batch_limit(w) >= n, "the group must fit the residency bound for this test to mean anything"
+    imgs = [D.photo_like(w, h, 5100 + i) if i % 3 else D.noise(w, h, 5100 + i) for i in range(n)]
+    lib.lqrhip_set_sub_batches(4)            # what a plain group of this size gets (and what the automatic choice is with 8 queues)
+    try:
+        assert lib.lqrhip_sub_batches(n) == 4
+        cs = []
+        for im in imgs:
+            c = L.Carver(engine, im, delta_x=kw.get("delta_x", 1), rigidity=(3 * kw.get("rigidity", 0.0) if rigm is not None else kw.get("rigidity", 0.0)))
+            if rigm is not None:
+                assert c.rigmask_add(rigm) == L.LQR_OK
+            cs.append(c.configure())
+        lib.lqrhip_prof_reset(); lib.lqrhip_prof_enable(1)
+        assert L.resize_batch(engine, cs, w - 21, h - 6) == L.LQR_OK
+        lib.lqrhip_prof_enable(0)
+        assert prof_launches(lib, "dp_update_tiled") > 0 and prof_launches(lib, "band_update") == 0, "the group fell to the band kernels"
+        for c, im in zip(cs, imgs):
+            ref = H.run_case(oracle, im, w - 21, h - 6, rigmask=rigm, **kw)
+            assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"])
+            assert np.array_equal(c.read_image(), ref["image"])
+        for c in cs:
+            c.destroy()
+    finally:
+        lib.lqrhip_prof_enable(0)
+        lib.lqrhip_set_sub_batches(0)
+
+
+def test_moved_bytes_equal_the_shorter_side_of_every_seam(oracle, engine):
+    """One 400x90 image, 30 vertical seams, no side switch (one full DP at the start, 30 incremental updates): the engine's count
+    must be 18 B x (pixels on the side of each seam that is shorter over the whole image), as read off the seam map."""
+    lib = engine.lib
+    lib.lqrhip_moved_bytes.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    w, h, ns = 400, 90, 30
+    img = D.photo_like(w, h, 77)
+    c = L.Carver(engine, img).configure(switch_freq=0)
+    z = ctypes.c_ulonglong(0)
+    assert lib.lqrhip_moved_bytes(ctypes.byref(z), 1) == 0
+    assert c.resize(w - ns, h) == L.LQR_OK
+    got = ctypes.c_ulonglong(0)
+    assert lib.lqrhip_moved_bytes(ctypes.byref(got), 1) == 0
+    vm = c.vmap_dump()["data"].astype(np.int64)          # 0 = never carved, else the seam's level (in carving order, from the deepest)
+    c.destroy()
+    levels = sorted(set(int(v) for v in np.unique(vm)) - {0})
+    assert len(levels) == ns
+    # replay the carving order: the seam carved k-th has the k-th value in the order the engine numbered them; its x in the frame of
+    # its own time = the number of not-yet-carved pixels to its left
+    order = sorted(levels, reverse=True) if vm.max() > 0 else levels
+    # which end of the value range is carved first does not matter for the SUM below only if we replay in the true order: try both
+    def total(order):
+        alive = np.ones((h, w), bool)
+        tot = 0
+        cur_w = w
+        for lv in order:
+            xs = []
+            for y in range(h):
+                col = int(np.flatnonzero(vm[y] == lv)[0])
+                xs.append(int(alive[y, :col].sum()))
+                alive[y, col] = False
+            left = sum(xs); right = h * (cur_w - 1) - left
+            tot += 18 * (left if 2 * left < h * (cur_w - 1) else right)
+            cur_w -= 1
+        return tot
+    assert got.value in (total(order), total(order[::-1])), (got.value, total(order), total(order[::-1]))
