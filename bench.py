@@ -95,10 +95,12 @@ def parse():
                     help="HIP streams the batch is split over (chain kernels of one sub-batch under the carve of another); "
                          "0 = the engine's choice: 4 for 32 images and more, given GPU_MAX_HW_QUEUES >= 8 (set above)")
     ap.add_argument("--update-mode", type=int, default=-1,
-                    help="update_mmap kernel: -1 the engine's choice, 0 band, 1 tiled full width, 2 band-mw")
+                    help="update_mmap kernel: -1 the engine's choice, 0 band (k_band_update_tw), 1 tiled full width, 2 band-mw, 4 k_band_tiles, 5 k_band_levels")
     ap.add_argument("--band-tiles", type=int, default=-1,
                     help="tiles per image of the multi-CU band update k_band_tiles: -1 the engine's choice, 0 never (k_band_update_tw), n at most n")
     ap.add_argument("--band-tiles-reserve", type=int, default=-1, help="how many of those are reserve tiles (-1: a third)")
+    ap.add_argument("--band-levels", type=int, default=-1,
+                    help="slots per image of k_band_levels (update mode 5): -1 the engine's choice, 0 never, n exactly n")
     ap.add_argument("--dp-px", type=int, default=0, help="pin the persistent tiled sweep's pixels per lane (2 or 4; 0: by batch size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phases", action="store_true", help="skip the upload / read-out phase measurement")
@@ -280,6 +282,8 @@ def main():
     lib.lqrhip_set_band_tiles(args.band_tiles)
     lib.lqrhip_set_band_tiles_reserve.argtypes = [C.c_int]
     lib.lqrhip_set_band_tiles_reserve(args.band_tiles_reserve)
+    lib.lqrhip_set_band_levels.argtypes = [C.c_int]
+    lib.lqrhip_set_band_levels(args.band_levels)
     if args.dp_px:
         lib.lqrhip_set_dp_persistent_px.argtypes = [C.c_int]
         lib.lqrhip_set_dp_persistent_px(args.dp_px)
@@ -624,6 +628,10 @@ def main():
         st = (C.c_ulonglong * 8)()
         if lib.lqrhip_band_tiles_stats(st, 1) == 0 and any(st[i] for i in range(4)):
             result["band_tiles_stats"] = {"uncovered_images": st[0], "aborted_images": st[1], "reserve_tiles_woken": st[2], "requests_without_reserve": st[3]}
+    if hasattr(lib, "lqrhip_band_levels_stats"):
+        st = (C.c_ulonglong * 8)()
+        if lib.lqrhip_band_levels_stats(st, 1) == 0 and any(st[i] for i in range(4)):
+            result["band_levels_stats"] = {"images_stopped_by_a_collision": st[0], "synchronous_loads": st[1], "tile_levels_processed": st[2], "slot_levels_idle": st[3]}
     # ---- on the same line: config 4's LITERAL per-GPU shard (64 images over 8 GPUs = 8 per GPU: the strong-scaling end nobody
     # can measure without the node), then BASELINE configs 2, 3 and 5 -- the plug-in's own call shape, one carver (render.c:318)
     if args.workload == "batch4k" and world == 1 and not args.no_configs and args.seams is None and not args.strong:

@@ -8,6 +8,7 @@
 //   k_carve.hip      E8              k_carve
 //   k_band.hip       E5/E9           k_dp_sweep, k_band_update, k_band_update_mw, k_band_update_tw (one workgroup per image)
 //   k_tiles.hip      E5/E9           k_dp_tile, k_dp_tile_p, k_band_tiles (an image spread over several compute units)
+//   k_levels.hip     E9              k_band_levels (the band on several compute units, tiles assigned level by level)
 //   k_oneoff.hip     E8(vs)/E11/E12/E14, auto-size  k_vs_commit, k_inflate, k_compact(_jobs), k_transpose, k_mask_line_max
 //   lqr_shim.hip     the lqrhip_* C ABI of include/lqr_hip.h: allocation cache, batches, the per-seam launch sequence
 // lqr_kernels.h declares every kernel for the shim; each kernel file instantiates the templates the shim launches.
@@ -471,6 +472,9 @@ constexpr int BT_T_MAX = 12;              // workgroups per image: base tiles + 
 constexpr int BT_HDR = 16;                // 8-byte words of an image's header in the exchange area: [0] base tiles finished,
                                           // [1] requests made, [2 ..] the requests {epoch << 32 | side << 31 | start block << 16 | tile}
 constexpr int BT_NEVER = 1 << 30;
+// k_band_levels (k_levels.hip): slots per image at most, tiles per image at most (two 64-bit masks)
+constexpr int LV_PMAX = 16;
+constexpr int LV_MAX_TILES = 128;
 
 // a job of the one-launch plane passes (inflate, flatten, transpose): one carver (root or attached) of a batch
 struct InflateDev {

@@ -28,6 +28,7 @@ static int g_dpp_max_wgs = 0;
 static int g_dpp_max_wgs_plain = 0, g_dpp_max_wgs_general = 0;      // ... of the plain / the delta_x = 2..4, rigidity-mask instantiations
 static int g_dpp_max_wgs_px4 = 0;                                   // ... of the plain 4-px instantiations alone (fewer registers than the 2-px ones)
 static int g_dpp_max_wgs_tiles = 0;                                 // ... of k_band_tiles
+static int g_dpp_max_wgs_levels = 0;                                // ... of k_band_levels
 
 static int band_tiles_resident(int n_cu)
 {
@@ -122,6 +123,16 @@ static int dpp_resident_workgroups(int dev)
 #undef QG
     g_dpp_max_wgs_general = std::max(0, per_cu - 1) * prop.multiProcessorCount;
     g_dpp_max_wgs_tiles = band_tiles_resident(prop.multiProcessorCount);
+    {
+        int per_cu = 1 << 20;
+        auto ql = [&](auto kern) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 128, 0) != hipSuccess) { (void) hipGetLastError(); n = 0; }
+            per_cu = std::min(per_cu, n);
+        };
+        ql(k_band_levels<false, false>); ql(k_band_levels<false, true>); ql(k_band_levels<true, false>); ql(k_band_levels<true, true>);
+        g_dpp_max_wgs_levels = std::max(0, per_cu - 1) * prop.multiProcessorCount;
+    }
     return g_dpp_max_wgs_plain;
 }
 
@@ -1085,6 +1096,51 @@ static int launch_band_tiles(LqrHipBatch *b, const DpK &k, int w, int h, int lr,
     HIPCK(hipGetLastError());
     return 0;
 }
+// Slots (workgroups) per image for k_band_levels (0: not usable here): as many as the group's images leave room for within the
+// residency bound, at most LV_PMAX; lqrhip_set_band_levels pins it (tests, experiments).  The default for large groups is 6:
+// the active tiles of a 4K level are 4.5 on average, a window of 6 consecutive tiles never collides, and 64 x 6 workgroups hold
+// half the registers of round 4's 64 x 12.
+static int g_band_levels = -1;           // -1: automatic; 0: never; n: n slots per image
+extern "C" void lqrhip_set_band_levels(int slots) { g_band_levels = slots; }
+static int band_levels_P(const LqrHipBatch *b, int w, int h)
+{
+    if (g_band_levels == 0 || (h + 31) / 32 > BT_MAX_BLK || (w + 63) / 64 > LV_MAX_TILES) return 0;
+    const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_levels) : g_dpp_max_wgs_levels;
+    const int per_batch = limit / std::max(b->shared_n, 1);
+    int P = std::min(LV_PMAX, per_batch / (int) std::max<size_t>(b->cs.size(), 1));
+    const size_t group_images = b->cs.size() * (size_t) std::max(b->shared_n, 1);
+    const int want = g_band_levels > 0 ? g_band_levels : group_images > 40 ? 6 : group_images > 20 ? 8 : 12;
+    P = std::min(P, want);
+    return P >= (g_band_levels > 0 ? 1 : 4) ? P : 0;
+}
+static int launch_band_levels(LqrHipBatch *b, const DpK &k, int w, int h, int lr, int P)
+{
+    LqrHipCarver *c0 = b->cs[0];
+    const size_t n = b->cs.size();
+    int rc;
+    const int ntiles = (w + 63) / 64;
+    const size_t need_elems = ((size_t) 2 * LV_PMAX + (size_t) 2 * ntiles * 64) * n;
+    if (b->exch_elems < need_elems) {
+        HIPCK(hipStreamSynchronize(b->stream));
+        dfree(b->exch);
+        b->exch_elems = 0;
+        if ((rc = dmalloc(&b->exch, need_elems))) return rc;
+        b->exch_elems = need_elems;
+        b->exch_ntiles = 0;
+    }
+    if (b->exch_ntiles != ntiles || b->exch_n != (int) n || b->exch_px != 103) {       // 103: this kernel's layout and tags
+        HIPCK(hipMemsetAsync(b->exch, 0, need_elems * sizeof(unsigned long long), b->stream));
+        b->exch_ntiles = ntiles; b->exch_n = (int) n; b->exch_px = 103;
+    }
+    const int epoch = 1 + ((b->tile_epoch++) % ((1 << 23) - 2));           // never 0; 23 bits above the 9 bits of level + 1
+    const dim3 grid(P, (unsigned) n);
+#define LAUNCH_LV(LRV, RIGV) hipLaunchKernelGGL((k_band_levels<LRV, RIGV>), grid, dim3(128), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
+    if (lr) { if (k.use_rig) LAUNCH_LV(true, true); else LAUNCH_LV(true, false); }
+    else { if (k.use_rig) LAUNCH_LV(false, true); else LAUNCH_LV(false, false); }
+#undef LAUNCH_LV
+    HIPCK(hipGetLastError());
+    return 0;
+}
 static const long long g_tiled_update_px = 8LL * 3840 * 2160;
 
 // One seam of a lock-step batch: k_vpath* (pick + backtrack, publishes the side to move) -> k_carve ->
@@ -1197,6 +1253,20 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     // 12: 195 / 152, 16: 246 / 193, 24: 294 / 260, 32: 382 / 341, 40: 423 / 398, 48: 434 / 448, 64: 488 / 510-540 -- beyond ~500
     // resident tile workgroups the carves of the sibling streams are starved of registers, so large groups
     // keep k_band_update_tw.
+    {
+        // round 5: the band on P slots per image, tiles assigned level by level (k_band_levels, update mode 5)
+        const int PL = (fast_ok && g_update_mode == 5) ? band_levels_P(b, wnew, h) : 0;
+        if (PL > 0) {
+            {
+                ProfScope ps("band_update", b->stream, 0);
+                if ((rc = launch_band_levels(b, k, wnew, h, leftright_next, PL))) return rc;
+            }
+            ProfScope ps("dp_update", b->stream, 0);
+            if ((rc = launch_dp<true>(b, k, wnew, h, leftright_next))) return rc;
+            HIPCK(hipGetLastError());
+            return 0;
+        }
+    }
     {
         const int T = (fast_ok && (g_update_mode < 0 || g_update_mode == 4)) ? band_tiles_T(b, h) : 0;
         const size_t group_images = (size_t) n * (size_t) std::max(b->shared_n, 1);

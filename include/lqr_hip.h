@@ -173,7 +173,7 @@ void lqrhip_prof_enable(int on);
 /* how E9 (update_mmap) runs: -1 by batch size (tiled full-width keep-rule sweep up to 8 4K images, the band
  * kernel k_band_update_tw above), 0 band kernel always, 1 tiled sweep whenever its grid fits the device,
  * 2 the per-row-barrier band kernel k_band_update_mw (the default for rows wider than 4200 px), 3 the generic
- * one-wave band kernel k_band_update + k_dp_sweep (what delta_x > 2 runs on) whatever the parameters */
+ * one-wave band kernel k_band_update + k_dp_sweep (what delta_x > 2 runs on) whatever the parameters, 4 k_band_tiles, 5 k_band_levels */
 void lqrhip_set_update_mode(int mode);
 /* Cap on the workgroups of the persistent tiled DP sweep (k_dp_tile_p), whose tiles spin on their neighbours and
  * must all be resident: -1 = the bound derived from the occupancy query at lqrhip_init, n >= 0 = min(n, that bound).
@@ -190,6 +190,11 @@ int lqrhip_prof_get_union(const char *kernel, double *ms_union);
  * many pixels lie on the side the carve will move, and sums pixels x bytes per pixel (en; m and back pointer unless a full DP
  * follows; the rigidity mask) over images and seams.  The roofline's numerator next to SURVEY 8(d)'s half-row figure. */
 int lqrhip_moved_bytes(unsigned long long *bytes, int reset);
+/* Test hook: slots (workgroups) per image of k_band_levels (-1 automatic, 0 never, n exactly n). */
+void lqrhip_set_band_levels(int slots);
+/* k_band_levels' events since the last reset: [0] images stopped by two active tiles on one slot (the full-width sweep took over),
+ * [1] synchronous (mispredicted) loads, [2] tile-levels processed, [3] slot-levels idle */
+int lqrhip_band_levels_stats(unsigned long long *out8, int reset);
 /* k_band_tiles' rare events since the last reset: [0] images not covered by their tile set, [1] images aborted at an edge,
  * [2] reserve tiles woken, [3] requests that found no reserve left */
 int lqrhip_band_tiles_stats(unsigned long long *out8, int reset);

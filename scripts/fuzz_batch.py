@@ -20,6 +20,7 @@ import lqr_ctypes as L
 budget = FC.Budget(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0)      # FUZZ_COUNT=n: exactly n cases, no wall-clock exit
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
+rng_lv = np.random.default_rng(seed + 500009)        # round 5: a third of the cases on k_band_levels, drawn from a stream of its own (the cases stay the same)
 o = L.oracle_api()
 e = L.engine_api()
 lib = e.lib
@@ -49,6 +50,8 @@ while budget.more(n):
     masks = rng.random() < 0.2
     mode = int(rng.choice([-1, 0, 1, 2, 4, 4]))
     sub = int(rng.choice([1, 1, 2, 3]))
+    if rng_lv.random() < 0.34:
+        mode = 5
     what = "%d x %dx%d ch%d -> %dx%d %s%s mode %d sub %d" % (nimg, w, h, ch, w + dw, h + dh, kw, " +masks" if masks else "", mode, sub)
     lib.lqrhip_set_update_mode(mode); lib.lqrhip_set_sub_batches(sub)
     mk = dict(pres=D.ellipse_mask(w, h), disc=D.band_mask(w, h, w // 5, w // 3)) if masks else {}

@@ -41,6 +41,8 @@ n = 0
 while budget.more(n):
     img, nw, nh, kw, what = F.draw_case(rng)
     name, mode = list(F.MODES.items())[n % 3]
+    if n % 4 == 3:                       # round 5: every fourth case on k_band_levels (the cases themselves stay what the seed made them)
+        name, mode = "levels", 5
     if general:
         name, mode = "auto", -1
         h_, w_ = img.shape[:2]

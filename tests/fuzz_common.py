@@ -60,6 +60,13 @@ class Failures:
                     stats = " bt_stats[uncovered,aborted,woken,no_reserve]=%s" % [int(x) for x in out[:4]]
             except Exception:
                 pass
+            try:
+                out = (ctypes.c_ulonglong * 8)()
+                self.lib.lqrhip_band_levels_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+                if self.lib.lqrhip_band_levels_stats(out, 0) == 0:
+                    stats += " lv_stats[collisions,sync_loads,processed,idle]=%s" % [int(x) for x in out[:4]]
+            except Exception:
+                pass
         if "never became resident" in err or "never became resident" in msg:
             kind = "timeout"
         elif "prediction failed" in err or "prediction failed" in msg:
