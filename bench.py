@@ -284,6 +284,9 @@ def main():
     lib.lqrhip_set_band_tiles_reserve(args.band_tiles_reserve)
     lib.lqrhip_set_band_levels.argtypes = [C.c_int]
     lib.lqrhip_set_band_levels(args.band_levels)
+    if os.environ.get("LQR_LV_DBG"):
+        lib.lqrhip_band_levels_debug.argtypes = [C.c_int]
+        lib.lqrhip_band_levels_debug(int(os.environ["LQR_LV_DBG"]))
     if args.dp_px:
         lib.lqrhip_set_dp_persistent_px.argtypes = [C.c_int]
         lib.lqrhip_set_dp_persistent_px(args.dp_px)
@@ -296,14 +299,14 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    def measure(wl, steps, warmup, headline, images=None):
+    def measure(wl, steps, warmup, headline, n_images=None):
         """one workload: set-up, `warmup` untimed + exactly `steps` timed steps, per-kernel breakdown, phases, CPU baseline;
-        `headline`: also the gather / strong / all-cores legs; `images`: images per GPU of a batch workload other than the
+        `headline`: also the gather / strong / all-cores legs; `n_images`: images per GPU of a batch workload other than the
         command line's.  Returns the JSON object of the workload."""
         W, H, NW, NH = WORKLOADS[wl]
         batch = wl == "batch4k"
-        nimg = (images or args.images_per_gpu) if batch else 1
-        if batch and args.strong and not images:
+        nimg = (n_images or args.images_per_gpu) if batch else 1
+        if batch and args.strong and not n_images:
             nimg = strong_images_per_gpu(world)
         if args.seams is not None:
             NW = W - args.seams
@@ -427,7 +430,7 @@ def main():
             while_active = num_launch * c_n / (active_ms * 1e-3) / 1e9       # ... / the time during which at least one carve was running
             # HBM traffic per launch from the committed rocprofv3 PMC passes of this command (separate FETCH_SIZE / WRITE_SIZE
             # runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note; scripts/profile_r05.sh), null if missing
-            traffic = pmc_traffic(wl if not images else "%s_%dimg" % (wl, nimg), ["k_carve"], nimg, streams)
+            traffic = pmc_traffic(wl if not n_images else "%s_%dimg" % (wl, nimg), ["k_carve"], nimg, streams)
             b_alg = alg_bytes_per_seam_px(W, H, NW, NH, args.switch_freq)
             roofline = {"bound": "hbm", "kernel": "k_carve", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
@@ -466,7 +469,7 @@ def main():
                 if not n:
                     continue
                 cand = KERNEL_NAMES[k][0 if nimg > 8 else 1]
-                pmc = pmc_traffic(wl if not images else "%s_%dimg" % (wl, nimg), cand, nimg, streams)
+                pmc = pmc_traffic(wl if not n_images else "%s_%dimg" % (wl, nimg), cand, nimg, streams)
                 alg = by / n if by else None
                 if k == "carve" and alg and timed.moved_bytes and n:
                     alg = min(alg, timed.moved_bytes / n)            # bytes it could not avoid (see roofline.note)
@@ -641,7 +644,7 @@ def main():
         for name, wl, images in legs:
             if images and images == args.images_per_gpu:
                 continue
-            r = measure(wl, 3, 1, False, images=images)
+            r = measure(wl, 3, 1, False, n_images=images)
             for rk in (r.get("roofline") or {}, r.get("phases") or {}):
                 rk.pop("note", None)                      # said once, on the headline
             result["configs"][name] = {k: r[k] for k in keep if k in r}

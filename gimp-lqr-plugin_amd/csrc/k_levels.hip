@@ -16,13 +16,15 @@
 //     Nothing else can change (any superset of the pixels with changed inputs leaves liblqr's memory),
 //     so inactive tiles are not computed, not stored, not resident -- they cost nothing.
 //   * tile t is processed by slot t mod P: own 64 columns + 32-column halos recomputed from the stored inputs, 2 px per
-//     lane, the 32 rows staged in registers (exactly k_band_tiles' row loop).  Two active tiles on one slot in one level
-//     (a band wider than P tiles, or two distant clusters): every slot sees that in the same A_L and the image stops
-//     there -- flags[FLAG_OVF_ROW] = 32 L, k_dp_sweep<UPDATE> redoes the rows below (rare; counted).
+//     lane, the 32 rows staged in registers (exactly k_band_tiles' row loop).  The tiles of a level do not depend on each
+//     other, so when a slot has TWO active tiles in a level (a band wider than P tiles) its two waves take one each, side by
+//     side (the second with a synchronous load: its prefetch was for the next level).  THREE on one slot: every slot sees
+//     that in the same A_L and the image stops there -- flags[FLAG_OVF_ROW] = 32 L, k_dp_sweep<UPDATE> redoes the rows
+//     below (a band wider than 2 P tiles; counted).
 //   * a LEVEL BARRIER through memory replaces the pairwise hand-over AND the in-place rule: after its level a slot
 //     publishes the last row of its tile's own columns as data-tagged granules ({m, tag}, one write-through store each)
-//     and ONE word {tag, tile, changed: own / left 32 / right 32}; the wave that takes the slot's next level polls all P
-//     words (one load, lanes 0 .. P - 1) -- when they carry the level's tag every slot has finished the level: that is the
+//     and one word per tile {tag, tile, changed: own / left 32 / right 32}; the wave that takes the slot's next level polls all
+//     2 P words (one load, lanes 0 .. 2 P - 1; the granules it expects to need ride along in the same poll) -- when they carry the level's tag every slot has finished the level: that is the
 //     barrier, the words give A_{L+1}, and the granules of the neighbouring active tiles give the halo's row above.
 //     Columns whose tile was not active in level L come from memory (nothing changed there).  Level L's results are
 //     stored only after the partner wave has passed that barrier: every slot has then CONSUMED its inputs of level L, so
@@ -34,21 +36,32 @@
 // costs a synchronous load, never a result.
 // Grid (P, images), all co-resident (bounded spins, DEVERR_TILE_TIMEOUT as in k_dp_tile_p).
 // ---------------------------------------------------------------------------
-// [0] images stopped by two active tiles on one slot, [1] synchronous (mispredicted) loads, [2] tile-levels processed,
-// [3] slot-levels idle
+// [0] images stopped by three active tiles on one slot, [1] synchronous (mispredicted or second-tile) loads, [2] tile-levels
+// processed, [3] slot-levels idle, [4] levels in which a slot had two tiles
 __device__ unsigned long long g_lv_stats[8];
+#ifdef LQR_TIMING
+// per slot of image 0 and wave: cycles in [0] barrier poll (wait_level), [1] active set + tile choice, [2] waiting for the partner's poll,
+// [3] stores, [4] loads (issue; synchronous ones include the wait), [5] row above, [6] the 32 rows, [7] publish, [8] LDS barrier, [9] whole kernel
+__device__ unsigned long long g_lv_time[16][2][10];
+#define LTT(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); ltt[i] += t__ - ltprev; ltprev = t__; } while (0)
+extern "C" int lqrhip_band_levels_timing(unsigned long long *out) { (void) hipDeviceSynchronize(); return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lv_time), sizeof(unsigned long long) * 320) == hipSuccess ? 0 : -1; }
+#else
+#define LTT(i) do { } while (0)
+#endif
+__device__ int g_lv_dbg;               // experiment switches (lqrhip_band_levels_debug): 1 no speculative granule fetch, 2 sleep longer in the poll
 
-struct LvMask {                       // a set of tiles (uniform over the wave)
-    unsigned long long lo, hi;
-    __device__ __forceinline__ void set(int t) { if (t < 64) lo |= 1ull << t; else hi |= 1ull << (t - 64); }
-    __device__ __forceinline__ bool has(int t) const { return t >= 0 && t < LV_MAX_TILES && ((t < 64 ? lo >> t : hi >> (t - 64)) & 1ull); }
-    __device__ __forceinline__ void set_range(int a, int b)          // [a, b], 0 <= a, b < LV_MAX_TILES
-    {
-        for (int t = a; t <= b; t++) set(t);
-    }
-    __device__ __forceinline__ int first() const { return lo ? __builtin_ctzll(lo) : hi ? 64 + __builtin_ctzll(hi) : -1; }
-    __device__ __forceinline__ int last() const { return hi ? 127 - __builtin_clzll(hi) : lo ? 63 - __builtin_clzll(lo) : -1; }
-    __device__ __forceinline__ int count() const { return __popcll(lo) + __popcll(hi); }
+// a value every lane holds (read from LDS), as a scalar
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
+{
+    return ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (v >> 32)) << 32) | (unsigned) __builtin_amdgcn_readfirstlane((int) v);
+}
+struct LvMask {                       // a set of tiles (uniform over the wave); LV_MAX_TILES = 64: one word
+    unsigned long long lo;
+    __device__ __forceinline__ void set(int t) { lo |= 1ull << t; }
+    __device__ __forceinline__ bool has(int t) const { return t >= 0 && t < LV_MAX_TILES && ((lo >> t) & 1ull); }
+    __device__ __forceinline__ void set_range(int a, int b) { lo |= ((b - a >= 63) ? ~0ull : ((1ull << (b - a + 1)) - 1ull)) << a; }          // [a, b], 0 <= a <= b < 64
+    __device__ __forceinline__ int first() const { return lo ? __builtin_ctzll(lo) : -1; }
+    __device__ __forceinline__ int last() const { return lo ? 63 - __builtin_clzll(lo) : -1; }
 };
 
 template <bool LR, bool RIG>
@@ -62,21 +75,23 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     typedef GLOBAL_AS LV GLV;
     typedef GLOBAL_AS unsigned long long gu64;
     __shared__ int s_tlo[BT_MAX_BLK], s_thi[BT_MAX_BLK];      // per level: columns the carve touched on its rows
-    __shared__ FV s_mp[64];                       // last row of the slot's tile, handed from wave to wave
     __shared__ int s_fail;                        // 1: a spin timed out (results invalid), 2: the image stopped (collision): leave at the next barrier
     __shared__ volatile int s_polled;             // last level whose barrier this workgroup has passed
-    __shared__ unsigned long long s_A[2][2];      // the active set of a level (by parity), from the wave that received it to its partner
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ unsigned long long s_A[2];         // the active set of a level (by parity), from the wave that received it to its partner
+        const int tid = threadIdx.x, lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P = (int) gridDim.x, slot = (int) blockIdx.x;
     const int nblk = (h + R - 1) / R;
     const int ntiles = (w + OWN - 1) / OWN;
     const GCarver c = gview(cs[blockIdx.y]);
-    gu64 *ex_img = (gu64 *) exch + (size_t) blockIdx.y * ((size_t) 2 * LV_PMAX + (size_t) 2 * ntiles * OWN);
-    gu64 *flagw = ex_img;                                    // [2][LV_PMAX]
-    gu64 *gran = ex_img + 2 * LV_PMAX;                       // [2][ntiles][OWN]
+    gu64 *ex_img = (gu64 *) exch + (size_t) blockIdx.y * ((size_t) 4 * LV_PMAX + (size_t) 2 * ntiles * OWN);
+    gu64 *flagw = ex_img;                                    // [2 parities][LV_PMAX slots][2 tiles]
+    gu64 *gran = ex_img + 4 * LV_PMAX;                       // [2 parities][ntiles][OWN]
     const float INF = __int_as_float(0x7f800000);
     const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
+    const int dbg = __builtin_amdgcn_readfirstlane(g_lv_dbg);
+    // which lanes of the barrier poll hold the words of the slot of tile `lane`, of tile `lane + 1`, of tile `lane - 1`
+    const int ix_own = 2 * (lane % P), ix_right = 2 * ((lane + 1) % P), ix_left = 2 * ((lane + P - 1) % P);
 
     // ---- carve-touched columns per level (as k_band_tiles / k_band_update_tw)
     for (int i = tid; i < nblk; i += 128) { s_tlo[i] = 1 << 30; s_thi[i] = -1; }
@@ -88,38 +103,51 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
         atomicMin(&s_tlo[y / R], t0); atomicMax(&s_thi[y / R], t1);
     }
     __syncthreads();
-    // tiles within reach of a level's touched columns: own_hi + HALO + 2 >= lo  and  own_lo - HALO - 2 <= hi
-    auto touch_first = [&](int L) -> int { const int lo = s_tlo[L]; return max(0, (lo - (OWN - 1 + HALO + 2) + OWN - 1) / OWN); };
-    auto touch_last = [&](int L) -> int { const int hi = s_thi[L]; return min(ntiles - 1, (hi + HALO + 2) / OWN); };
+    // tiles within reach of a level's touched columns (own_hi + HALO + 2 >= lo  and  own_lo - HALO - 2 <= hi), as one mask per
+    // level, worked out once (the level loop reads one LDS word)
+    __shared__ unsigned long long s_tm[BT_MAX_BLK + 2];
+    for (int L = tid; L < nblk + 2; L += 128) {
+        unsigned long long m = 0ull;
+        if (L < nblk && s_thi[L] >= s_tlo[L]) {
+            const int a = max(0, (s_tlo[L] - (OWN - 1 + HALO + 2) + OWN - 1) / OWN), b = min(ntiles - 1, (s_thi[L] + HALO + 2) / OWN);
+            m = ((b - a >= 63) ? ~0ull : ((1ull << (b - a + 1)) - 1ull)) << a;
+        }
+        s_tm[L] = m;
+    }
+    __syncthreads();
     auto touch_mask = [&](int L) -> LvMask {
-        LvMask m = {0ull, 0ull};
-        if (L < nblk && s_thi[L] >= s_tlo[L]) m.set_range(touch_first(L), touch_last(L));
+        LvMask m;
+        m.lo = uni64(s_tm[L]);
         return m;
     };
-    // the tile of this slot's residue in a set (-1: none; collision = a second one)
-    auto my_tile = [&](const LvMask &A, bool &collision) -> int {
-        int found = -1;
-        collision = false;
-        const int a = A.first(), b = A.last();
-        if (a < 0) return -1;
-        for (int t = a + ((slot - a) % P + P) % P; t <= b; t += P)
-            if (A.has(t)) { if (found < 0) found = t; else collision = true; }
-        return found;
+    // tiles of this slot's residue (t mod P == slot), and of residue 0: no integer division inside the level loop (a lone wave pays
+    // ~40 instructions x 4-5 cycles for each: five of them were 2 000 cycles per level)
+    unsigned long long res_mine = 0ull, res_zero = 0ull;
+    for (int t = slot; t < LV_MAX_TILES; t += P) res_mine |= 1ull << t;
+    for (int t = 0; t < LV_MAX_TILES; t += P) res_zero |= 1ull << t;
+    res_mine = uni64(res_mine); res_zero = uni64(res_zero);
+    // the which-th (0, 1) tile of this slot's residue in a set, -1: none
+    auto my_tile = [&](const LvMask &A, int which) -> int {
+        unsigned long long m = A.lo & res_mine;
+        if (which && m) m &= m - 1ull;
+        return m ? __builtin_ctzll(m) : -1;
     };
-    // does ANY slot have two tiles in the set?  (identical decision in every slot)
+    // does ANY slot have three tiles in the set?  (identical decision in every slot)
     auto any_collision = [&](const LvMask &A) -> bool {
         const int a = A.first(), b = A.last();
-        if (a < 0 || b - a < P) return false;               // a window of P consecutive tiles: all residues distinct
-        unsigned seen = 0;
-        for (int t = a; t <= b; t++)
-            if (A.has(t)) { const unsigned bit = 1u << (t % P); if (seen & bit) return true; seen |= bit; }
+        if (a < 0 || b - a < 2 * P) return false;            // a window of 2 P consecutive tiles: at most two per residue
+        for (int r = 0; r < P; r++)
+            if (__popcll(A.lo & (res_zero << r)) > 2) return true;
         return false;
     };
-    // the tile of this slot's residue nearest to [a, b]
+    // the tile of this slot's residue nearest to [a, b] (-1: the slot has no tile in the image)
     auto nearest_tile = [&](int a, int b) -> int {
-        int t1 = a + ((slot - a) % P + P) % P;              // first one >= a
-        if (t1 <= b || t1 - P < 0) return t1 < ntiles ? t1 : (t1 - P >= 0 ? t1 - P : -1);
-        return (t1 - b <= a - (t1 - P) && t1 < ntiles) ? t1 : t1 - P;
+        const unsigned long long up_m = res_mine & (~0ull << a), dn_m = res_mine & (b >= 63 ? ~0ull : ((1ull << (b + 1)) - 1ull));
+        const int up = up_m ? __builtin_ctzll(up_m) : -1, dn = dn_m ? 63 - __builtin_clzll(dn_m) : -1;
+        if (up >= 0 && up <= b) return up;                   // inside
+        if (up < 0 || up >= ntiles) return dn;
+        if (dn < 0) return up;
+        return (up - b <= a - dn) ? up : dn;
     };
 
     // ---- geometry of the tile staged in this wave's registers
@@ -137,6 +165,9 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
         own = own_lane && x0 < w;
         interior = (x0 - PX * lane >= 0) && (x0 - PX * lane + TILE <= w);
     };
+    // the tile that owns this lane's columns when the wave works on tile t, and the lane's first column inside that tile
+    auto owner_of = [&](int t) -> int { return lane < HL ? t - 1 : lane >= 64 - HL ? t + 1 : t; };
+    const int owner_col = lane < HL ? HALO + PX * lane : lane >= 64 - HL ? PX * (lane - (64 - HL)) : PX * (lane - HL);
     FV q_e[R], q_mo[R], q_ab;
     LV q_lo[R];
     q_ab[0] = q_ab[1] = INF;
@@ -193,168 +224,198 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
             }
         }
     };
-    // The barrier that ends level L - 1 (L >= 1): wait until all P slots' words carry its tag; returns 0, or 1 on a time-out.
-    // fw: this lane's word (lanes < P).
-    auto wait_level = [&](int L, unsigned long long &fw) -> int {
+    // The barrier that ends level L - 1 (L >= 1): wait until all 2 P words of the slots carry its tag.  With spec_t >= 0 the
+    // granules of the row above level L for tile spec_t (the tile this wave expects to have) are fetched in the same poll, so
+    // that barrier, active set and halo cost ONE round trip through memory; prev = A_{L-1} says which tiles published.
+    // Returns 0, or 1 on a time-out.  fw: this lane's word (lanes < 2 P); g: this lane's granules (valid if spec_t was right).
+    auto wait_level = [&](int L, int spec_t, const LvMask &prev, unsigned long long &fw, unsigned long long (&g)[PX]) -> int {
         const unsigned want = ((unsigned) epoch << 9) | (unsigned) L;
-        gu64 *src = flagw + ((L - 1) & 1) * LV_PMAX + (lane < P ? lane : 0);
+        gu64 *fsrc = flagw + (size_t) ((L - 1) & 1) * 2 * LV_PMAX + (lane < 2 * P ? lane : 0);
+        const bool need_g = spec_t >= 0 && prev.has(owner_of(spec_t)) && (in[0] || in[1]);
+        gu64 *gsrc = gran + ((size_t) ((L - 1) & 1) * ntiles + (need_g ? owner_of(spec_t) : 0)) * OWN + (need_g ? owner_col : 0);
         int sp = 0;
         while (true) {
-            fw = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all(lane >= P || (unsigned) (fw >> 32) == want)) return 0;
-            if (sp < 8) __builtin_amdgcn_s_sleep(1); else if (sp < 64) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(48);
+            fw = __hip_atomic_load(fsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (spec_t >= 0) {
+#pragma unroll
+                for (int k = 0; k < PX; k++) g[k] = __hip_atomic_load(gsrc + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const bool okf = __all(lane >= 2 * P || (unsigned) (fw >> 32) == want);
+            bool okg = true;
+#pragma unroll
+            for (int k = 0; k < PX; k++) okg &= (unsigned) (g[k] >> 32) == want;
+            if (okf && __all(!need_g || okg)) return 0;
+            if (dbg & 2) __builtin_amdgcn_s_sleep(16); else if (okf || sp < 8) __builtin_amdgcn_s_sleep(1); else if (sp < 64) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(48);
             ++sp;
             if ((sp & 255) == 0 && dev_failed(dev_err)) return 1;
             if (sp > (1 << 18)) { if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); return 1; }
         }
     };
-
-    unsigned long long n_proc = 0, n_idle = 0, n_sync = 0;
-    // ---- first prefetch: wave q takes levels q, q + 2, ...; level 0's active set is its touched tiles, level 1 is guessed
-    {
-        const int L0 = q;
-        if (L0 < nblk) {
-            LvMask g = touch_mask(L0);
-            if (L0 == 1) { const LvMask g0 = touch_mask(0); g.lo |= g0.lo; g.hi |= g0.hi; }
-            bool coll;
-            const int t = my_tile(g, coll);
-            if (t >= 0) { set_tile(t); issue_full(L0); cur_t = t; cur_L = L0; cur_full = true; }
+    // the row above level L (L >= 1) for the tile set_tile() chose: per column from its tile's granules if that tile was active
+    // in level L - 1, else from memory (q_ab: nothing changed there).  have_g: g holds this tile's granules already.
+    auto row_above = [&](int L, int t, const LvMask &prev, bool have_g, unsigned long long (&g)[PX]) -> int {
+        const int u = owner_of(t);
+        const bool from_gran = prev.has(u) && (in[0] || in[1]);
+        if (!have_g) {
+            gu64 *src = gran + ((size_t) ((L - 1) & 1) * ntiles + (from_gran ? u : 0)) * OWN + (from_gran ? owner_col : 0);
+            const unsigned want = ((unsigned) epoch << 9) | (unsigned) L;
+            int sp = 0;
+            while (true) {
+#pragma unroll
+                for (int k = 0; k < PX; k++) g[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < PX; k++) ok &= (unsigned) (g[k] >> 32) == want;
+                if (__all(ok || !from_gran)) break;
+                __builtin_amdgcn_s_sleep(1);                 // (the words were there: the granules are on their way)
+                if (++sp > (1 << 16)) { if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); return 1; }
+            }
         }
-    }
-    LvMask A_prev = {0ull, 0ull};               // A_{L-1}, as this wave knows it
-    for (int L = 0; L < nblk; L++) {
+#pragma unroll
+        for (int k = 0; k < PX; k++) mp[k] = !in[k] ? INF : from_gran ? __uint_as_float((unsigned) g[k]) : q_ab[k];
+        return 0;
+    };
+    // ---- the level loop.  ONE site each for the loads, the 32 rows and the stores of the staging registers (a second site of any of
+    // them makes the register allocator keep two sets: 330 spilled VGPRs).  Wave q receives the barrier of the levels of its
+    // parity and takes the slot's FIRST tile there; in the other levels it stores what it holds, takes the slot's SECOND tile if
+    // there is one, else prefetches its own next level.  Iteration nblk only closes the last level.
+    unsigned long long n_proc = 0, n_idle = 0, n_sync = 0, n_two = 0;
+    int hold_L = -1;                            // the level whose (unstored) results sit in this wave's registers
+#ifdef LQR_TIMING
+    unsigned long long ltt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ltprev = __builtin_readcyclecounter();
+    const unsigned long long ltstart = ltprev;
+#endif
+    for (int L = 0; L <= nblk; L++) {
         const bool mine = (L & 1) == q;
         int t = -1;
-        bool processed = false;
-        LvMask A = {0ull, 0ull};
+        bool have_g = false, passed = false;
+        unsigned long long g[PX] = {0ull, 0ull};
+        LvMask A = {0ull}, A_prev = {0ull};
+        if (L > 0) A_prev.lo = uni64(s_A[(L - 1) & 1]);       // (written before the barrier that ended iteration L - 1)
+        LTT(8);
         if (mine) {
             // ---- the barrier of level L - 1 and the active set of level L
             unsigned long long fw = 0;
             A = touch_mask(L);
+            passed = true;
             if (L > 0) {
-                A_prev.lo = s_A[(L - 1) & 1][0]; A_prev.hi = s_A[(L - 1) & 1][1];
-                if (wait_level(L, fw)) { s_fail = 1; }
-                else {
-                    for (int pp = 0; pp < P; pp++) {
-                        const unsigned wlo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) fw, pp);
-                        if (wlo & 0x800u) {
-                            const int tt = (int) (wlo & 0xffu);
-                            if (wlo & 0x100u) A.set(tt);
-                            if ((wlo & 0x200u) && tt > 0) A.set(tt - 1);
-                            if ((wlo & 0x400u) && tt + 1 < ntiles) A.set(tt + 1);
-                        }
+                const int spec_t = (hold_L < 0 && cur_full && cur_L == L && L < nblk && !(dbg & 1)) ? cur_t : -1;
+                const int wl_rc = wait_level(L, spec_t, A_prev, fw, g);
+                LTT(0);
+                if (wl_rc) { s_fail = 1; passed = false; }
+                else if (L < nblk) {
+                    // tile `lane` is active in level L iff its own slot's words say "own pixels changed", or the tile to its right says
+                    // "left 32 changed", or the tile to its left "right 32 changed" (six words, fetched across the lanes; one ballot)
+                    const int wl = (int) (unsigned) fw;
+                    bool act = false;
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        const unsigned wo = (unsigned) __builtin_amdgcn_ds_bpermute((ix_own + i) << 2, wl);
+                        const unsigned wr = (unsigned) __builtin_amdgcn_ds_bpermute((ix_right + i) << 2, wl);
+                        const unsigned wlf = (unsigned) __builtin_amdgcn_ds_bpermute((ix_left + i) << 2, wl);
+                        act |= (wo & 0x900u) == 0x900u && (int) (wo & 0xffu) == lane;
+                        act |= (wr & 0xa00u) == 0xa00u && (int) (wr & 0xffu) == lane + 1;
+                        act |= (wlf & 0xc00u) == 0xc00u && (int) (wlf & 0xffu) == lane - 1;
                     }
+                    A.lo |= __ballot(act && lane < ntiles);
+                    have_g = spec_t >= 0;
                 }
             }
-            if (lane == 0) { s_A[L & 1][0] = A.lo; s_A[L & 1][1] = A.hi; if (!s_fail) s_polled = L; }        // level L - 1 may be stored now (not after a time-out)
-            if (!s_fail && any_collision(A)) {
-                // two active tiles on one slot: the image stops here (every slot decides the same); rows from 32 L on are the sweep's
-                if (slot == 0 && lane == 0) { __hip_atomic_fetch_min(c.flags + FLAG_OVF_ROW, L * R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicAdd(&g_lv_stats[0], 1ull); }
-                s_fail = 2;
-            }
-            bool coll = false;
-            if (!s_fail) t = my_tile(A, coll);
+            if (lane == 0) { s_A[L & 1] = A.lo; if (passed) s_polled = L; }        // level L - 1 may be stored now (not after a time-out)
+        } else {
+            int spins = 0;
+            while (s_polled < L && *(volatile int *) &s_fail != 1 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
+            passed = s_polled >= L;
+            if (passed) A.lo = uni64(s_A[L & 1]);
+            LTT(2);
+        }
+        // ---- STORE: level L - 1 is final and every slot has consumed its inputs
+        LTT(1);
+        if (hold_L >= 0 && passed) { store_u(hold_L * R); hold_L = -1; }
+        LTT(3);
+        if (L == nblk) break;
+        if (mine && passed && any_collision(A)) {
+            // three active tiles on one slot: the image stops here (every slot decides the same); rows from 32 L on are the sweep's
+            if (slot == 0 && lane == 0) { __hip_atomic_fetch_min(c.flags + FLAG_OVF_ROW, L * R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicAdd(&g_lv_stats[0], 1ull); }
+            s_fail = 2;
+            passed = false;
+        }
+        if (passed && *(volatile int *) &s_fail == 0) t = my_tile(A, mine ? 0 : 1);
+        if (!mine && t < 0 && passed && lane == 0 && *(volatile int *) &s_fail == 0) {       // no second tile: said right away
+            const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 9) | (unsigned) (L + 1)) << 32;
+            __hip_atomic_store(flagw + (size_t) (L & 1) * 2 * LV_PMAX + 2 * slot + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- LOAD: the tile of this level if it is not what was prefetched (synchronous), else -- the other wave -- the prefetch for
+        // its next level: the tile this slot is expected to have then
+        {
+            int ld_t = -1, ld_L = L;
             if (t >= 0) {
-                processed = true;
-                n_proc++;
-                if (!(cur_t == t && cur_L == L && cur_full)) { set_tile(t); issue_full(L); cur_t = t; cur_L = L; cur_full = true; n_sync++; }
-                // ---- the row above the level: per column from its tile's granules if that tile was active in level L - 1
-                // (this slot's own tile: from LDS, its partner wave left it there), else from memory (nothing changed there)
-                if (L > 0) {
-                    const int u = lane < HL ? t - 1 : lane >= 64 - HL ? t + 1 : t;
-                    const bool from_gran = !own_lane && A_prev.has(u) && (in[0] || in[1]);
-                    const int col = lane < HL ? HALO + PX * lane : PX * (lane - (64 - HL));             // the neighbour's own column of this lane's first pixel
-                    gu64 *src = gran + ((size_t) ((L - 1) & 1) * ntiles + (from_gran ? u : 0)) * OWN + (from_gran ? col : 0);
-                    const unsigned want = ((unsigned) epoch << 9) | (unsigned) L;
-                    unsigned long long g[PX] = {0ull, 0ull};
-                    int sp = 0;
-                    while (true) {
-#pragma unroll
-                        for (int k = 0; k < PX; k++) g[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        bool ok = true;
-#pragma unroll
-                        for (int k = 0; k < PX; k++) ok &= (unsigned) (g[k] >> 32) == want;
-                        if (__all(ok || !from_gran)) break;
-                        __builtin_amdgcn_s_sleep(1);                 // (the words were there: the granules are on their way)
-                        if (++sp > (1 << 16)) { if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); s_fail = 1; break; }
-                    }
-                    const bool own_prev = A_prev.has(t);             // this slot processed the tile in level L - 1: its last row is in LDS
-                    const FV v = s_mp[lane];
-#pragma unroll
-                    for (int k = 0; k < PX; k++)
-                        mp[k] = !in[k] ? INF : from_gran ? __uint_as_float((unsigned) g[k]) : (own_lane && own_prev) ? v[k] : q_ab[k];
-                }
-                if (!interior) {
-                    // outside the image the energy AND the old value become +inf (see k_dp_tile_p)
-#pragma unroll
-                    for (int r = 0; r < R; r++)
-#pragma unroll
-                        for (int k = 0; k < PX; k++) { q_e[r][k] = in[k] ? q_e[r][k] : INF; q_mo[r][k] = in[k] ? q_mo[r][k] : INF; }
-                }
-                batch_u(L * R);
-                {
-                    FV v;
-                    v[0] = mp[0]; v[1] = mp[1];
-                    s_mp[lane] = v;
-                }
-                // ---- publish: the last row of the own columns, then the slot's word
-                if (L + 1 < nblk && own_lane) {
-                    gu64 *dst = gran + ((size_t) (L & 1) * ntiles + t) * OWN + PX * (lane - HL);
-                    const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 9) | (unsigned) (L + 1)) << 32;
-#pragma unroll
-                    for (int k = 0; k < PX; k++) __hip_atomic_store(dst + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else if (!s_fail) n_idle++;
-            {
-                const bool chg = own_lane && processed && (acc_l0 | acc_l1) != 0;
-                const bool any_o = __any(chg), any_l = __any(chg && lane < 32), any_r = __any(chg && lane >= 32);
-                if (lane == 0) {
-                    const unsigned long long word = ((unsigned long long) (((unsigned) epoch << 9) | (unsigned) (L + 1)) << 32) |
-                        (processed ? (0x800u | (any_o ? 0x100u : 0u) | (any_l ? 0x200u : 0u) | (any_r ? 0x400u : 0u) | (unsigned) t) : 0u);
-                    __hip_atomic_store(flagw + (L & 1) * LV_PMAX + slot, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                if (!(cur_full && cur_t == t && cur_L == L)) { ld_t = t; n_sync++; have_g = false; }
+                if (!mine) n_two++;
+            } else if (!mine && passed && L + 1 < nblk) {
+                LvMask M = touch_mask(L + 1);
+                M.lo |= A.lo;
+                int pt = my_tile(M, 0);
+                if (pt < 0 && M.first() >= 0) { pt = nearest_tile(M.first(), M.last()); if (pt < M.first() - 1 || pt > M.last() + 1 || pt >= ntiles) pt = -1; }
+                ld_t = pt; ld_L = L + 1;
+                cur_t = -1; cur_L = ld_L; cur_full = false;
             }
+            LTT(1);
+            if (ld_t >= 0) { set_tile(ld_t); issue_full(ld_L); cur_t = ld_t; cur_L = ld_L; cur_full = true; }
+#ifdef LQR_TIMING
+            if (t >= 0 && ld_t >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            LTT(4);
         }
+        // ---- the 32 rows of the tile, its last row to the granules
+        unsigned word = 0;
+        if (t >= 0) {
+            n_proc++;
+            if (L > 0 && row_above(L, t, A_prev, have_g, g)) s_fail = 1;
+#ifdef LQR_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            LTT(5);
+            if (!interior) {
+                // outside the image the energy AND the old value become +inf (see k_dp_tile_p)
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int k = 0; k < PX; k++) { q_e[r][k] = in[k] ? q_e[r][k] : INF; q_mo[r][k] = in[k] ? q_mo[r][k] : INF; }
+            }
+            batch_u(L * R);
+            LTT(6);
+            hold_L = L;
+            cur_full = false;                    // (the registers hold results now)
+            if (L + 1 < nblk && own_lane) {
+                gu64 *dst = gran + ((size_t) (L & 1) * ntiles + t) * OWN + PX * (lane - HL);
+                const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 9) | (unsigned) (L + 1)) << 32;
+#pragma unroll
+                for (int k = 0; k < PX; k++) __hip_atomic_store(dst + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const bool chg = own_lane && (acc_l0 | acc_l1) != 0;
+            const bool any_o = __any(chg), any_l = __any(chg && lane < 32), any_r = __any(chg && lane >= 32);
+            word = 0x800u | (any_o ? 0x100u : 0u) | (any_l ? 0x200u : 0u) | (any_r ? 0x400u : 0u) | (unsigned) t;
+        } else if (mine && passed) n_idle++;
+        // the slot's word for this wave's tile of the level (its granules were issued above; a reader checks their tags itself)
+        if (lane == 0 && (t >= 0 || mine) && *(volatile int *) &s_fail == 0) {
+            const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 9) | (unsigned) (L + 1)) << 32;
+            __hip_atomic_store(flagw + (size_t) (L & 1) * 2 * LV_PMAX + 2 * slot + (mine ? 0 : 1), tag | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        LTT(7);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const int fail = *(volatile int *) &s_fail;
-        if (fail == 1) return;                   // a time-out: results are invalid anyway
-        if (mine) {
-            if (fail == 2) return;               // (this wave received the collision itself: nothing of level L was computed)
-            // ---- level L is stored once every slot has finished it (the partner's barrier for level L + 1; the last level: ours)
-            bool may_store = true;
-            if (L + 1 < nblk) {
-                int spins = 0;
-                while (s_polled < L + 1 && *(volatile int *) &s_fail != 1 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
-                may_store = s_polled >= L + 1;
-            } else {
-                unsigned long long fw = 0;
-                may_store = wait_level(L + 1, fw) == 0;
-            }
-            if (may_store && processed) store_u(L * R);
-            // ---- prefetch for level L + 2 (this wave's next): the tile this slot is expected to have then
-            const int L2 = L + 2;
-            if (may_store && L2 < nblk && *(volatile int *) &s_fail == 0) {
-                int a = A.first(), b = A.last();
-                if (s_thi[L2] >= s_tlo[L2]) { const int f2 = touch_first(L2), l2 = touch_last(L2); a = a < 0 ? f2 : min(a, f2); b = b < 0 ? l2 : max(b, l2); }
-                if (s_thi[L + 1] >= s_tlo[L + 1]) { const int f1 = touch_first(L + 1), l1 = touch_last(L + 1); a = a < 0 ? f1 : min(a, f1); b = b < 0 ? l1 : max(b, l1); }
-                int pt = -1;
-                if (a >= 0) {
-                    pt = processed ? t : nearest_tile(a, b);
-                    if (pt < 0 || pt >= ntiles || pt < a - 1 || pt > b + 1) pt = -1;           // too far from everything that is going on
-                }
-                cur_t = -1; cur_L = L2; cur_full = false;
-                if (pt >= 0) { set_tile(pt); issue_full(L2); cur_t = pt; cur_full = true; }
-            }
-        } else if (fail == 2) {
-            // the partner received a collision at level L: this wave computed level L - 1, whose barrier has been passed -- store it
-            // (FLAG_OVF_ROW = 32 L: every row above must be final), then leave
-            return;
-        }
+        LTT(8);
+        if (*(volatile int *) &s_fail) return;    // 1: a time-out, results are invalid anyway; 2: the image stopped at this level (level L - 1 was stored above)
     }
-    if (lane == 0) { atomicAdd(&g_lv_stats[2], n_proc); atomicAdd(&g_lv_stats[3], n_idle); }
+#ifdef LQR_TIMING
+    if (blockIdx.y == 0 && lane == 0 && blockIdx.x < 16) { ltt[9] = __builtin_readcyclecounter() - ltstart; for (int i = 0; i < 10; i++) g_lv_time[blockIdx.x][q][i] = ltt[i]; }
+#endif
+    if (lane == 0) { atomicAdd(&g_lv_stats[2], n_proc); atomicAdd(&g_lv_stats[3], n_idle); if (n_two) atomicAdd(&g_lv_stats[4], n_two); }
     if (lane == 0 && n_sync) atomicAdd(&g_lv_stats[1], n_sync);
 }
 
+extern "C" void lqrhip_band_levels_debug(int v) { (void) hipMemcpyToSymbol(HIP_SYMBOL(g_lv_dbg), &v, sizeof v); }
 extern "C" int lqrhip_band_levels_stats(unsigned long long *out, int reset)
 {
     (void) hipDeviceSynchronize();

@@ -472,9 +472,9 @@ constexpr int BT_T_MAX = 12;              // workgroups per image: base tiles + 
 constexpr int BT_HDR = 16;                // 8-byte words of an image's header in the exchange area: [0] base tiles finished,
                                           // [1] requests made, [2 ..] the requests {epoch << 32 | side << 31 | start block << 16 | tile}
 constexpr int BT_NEVER = 1 << 30;
-// k_band_levels (k_levels.hip): slots per image at most, tiles per image at most (two 64-bit masks)
+// k_band_levels (k_levels.hip): slots per image at most, tiles per image at most (one 64-bit mask: rows up to 4096 px)
 constexpr int LV_PMAX = 16;
-constexpr int LV_MAX_TILES = 128;
+constexpr int LV_MAX_TILES = 64;
 
 // a job of the one-launch plane passes (inflate, flatten, transpose): one carver (root or attached) of a batch
 struct InflateDev {

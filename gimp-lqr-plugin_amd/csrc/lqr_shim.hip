@@ -1108,10 +1108,12 @@ static int band_levels_P(const LqrHipBatch *b, int w, int h)
     const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_levels) : g_dpp_max_wgs_levels;
     const int per_batch = limit / std::max(b->shared_n, 1);
     int P = std::min(LV_PMAX, per_batch / (int) std::max<size_t>(b->cs.size(), 1));
+    // automatic: 12 slots while the group's workgroups stay below ~480 (beyond that the sibling kernels are starved of registers,
+    // DESIGN.md 4.15 / 4.16), never fewer than 7 (6 and fewer put second tiles on a slot in 9 % of the tile-levels)
     const size_t group_images = b->cs.size() * (size_t) std::max(b->shared_n, 1);
-    const int want = g_band_levels > 0 ? g_band_levels : group_images > 40 ? 6 : group_images > 20 ? 8 : 12;
+    const int want = g_band_levels > 0 ? g_band_levels : std::max(7, std::min(12, (int) (480 / std::max<size_t>(group_images, 1))));
     P = std::min(P, want);
-    return P >= (g_band_levels > 0 ? 1 : 4) ? P : 0;
+    return P >= (g_band_levels > 0 ? 1 : 7) ? P : 0;
 }
 static int launch_band_levels(LqrHipBatch *b, const DpK &k, int w, int h, int lr, int P)
 {
@@ -1119,7 +1121,7 @@ static int launch_band_levels(LqrHipBatch *b, const DpK &k, int w, int h, int lr
     const size_t n = b->cs.size();
     int rc;
     const int ntiles = (w + 63) / 64;
-    const size_t need_elems = ((size_t) 2 * LV_PMAX + (size_t) 2 * ntiles * 64) * n;
+    const size_t need_elems = ((size_t) 4 * LV_PMAX + (size_t) 2 * ntiles * 64) * n;
     if (b->exch_elems < need_elems) {
         HIPCK(hipStreamSynchronize(b->stream));
         dfree(b->exch);
@@ -1254,8 +1256,11 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     // resident tile workgroups the carves of the sibling streams are starved of registers, so large groups
     // keep k_band_update_tw.
     {
-        // round 5: the band on P slots per image, tiles assigned level by level (k_band_levels, update mode 5)
-        const int PL = (fast_ok && g_update_mode == 5) ? band_levels_P(b, wnew, h) : 0;
+        // round 5: the band on P slots per image, tiles assigned level by level (k_band_levels): the default for groups of 8 to 40
+        // images (measured, Mseams*px/s at 4K, levels / k_band_tiles / k_band_update_tw: 8 images 137 / 134 / 127, 16: 234 / 235 / 193;
+        // 64: 508 / 488 / 508-540 -- large groups keep k_band_update_tw); update mode 5 forces it
+        const size_t group_images = (size_t) n * (size_t) std::max(b->shared_n, 1);
+        const int PL = (fast_ok && (g_update_mode == 5 || (g_update_mode < 0 && group_images >= 8 && group_images <= 40))) ? band_levels_P(b, wnew, h) : 0;
         if (PL > 0) {
             {
                 ProfScope ps("band_update", b->stream, 0);
@@ -1268,9 +1273,11 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
         }
     }
     {
-        const int T = (fast_ok && (g_update_mode < 0 || g_update_mode == 4)) ? band_tiles_T(b, h) : 0;
-        const size_t group_images = (size_t) n * (size_t) std::max(b->shared_n, 1);
-        if (T > 0 && (g_update_mode == 4 || (group_images >= 8 && group_images * (size_t) T <= 480))) {
+        // round 4's k_band_tiles (static tile sets that grow on demand through reserve tiles): on request only (update mode 4) -- the
+        // level-synchronous kernel above does the same job with half the workgroups and one spin instead of four protocols, and the
+        // one unexplained failure of round 4's suite was in a run whose cases include this kernel
+        const int T = (fast_ok && g_update_mode == 4) ? band_tiles_T(b, h) : 0;
+        if (T > 0) {
             {
                 ProfScope ps("band_update", b->stream, 0);
                 if ((rc = launch_band_tiles(b, k, wnew, h, leftright_next, T))) return rc;
