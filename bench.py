@@ -193,6 +193,7 @@ KERNEL_NAMES = {
     "carve": (["k_carve"], ["k_carve"]),
     "vpath": (["k_vpath1", "k_vpath"], ["k_vpath1", "k_vpath"]),
     "band_update": (["k_band_update_tw", "k_band_tiles", "k_band_update_mw", "k_band_update"], ["k_band_tiles", "k_band_update_tw", "k_band_update"]),
+    "band_levels": (["k_band_levels"], ["k_band_levels"]),
     "dp_update": (["k_dp_sweep"], ["k_dp_sweep"]),
     "dp_update_tiled": (["k_dp_tile_p"], ["k_dp_tile_p"]),
     "dp_sweep": (["k_dp_tile", "k_dp_sweep"], ["k_dp_tile_p", "k_dp_tile", "k_dp_sweep"]),
@@ -284,6 +285,9 @@ def main():
     lib.lqrhip_set_band_tiles_reserve(args.band_tiles_reserve)
     lib.lqrhip_set_band_levels.argtypes = [C.c_int]
     lib.lqrhip_set_band_levels(args.band_levels)
+    if os.environ.get("LQR_TW_TAIL"):
+        lib.lqrhip_set_tw_tail.argtypes = [C.c_int]
+        lib.lqrhip_set_tw_tail(int(os.environ["LQR_TW_TAIL"]))
     if os.environ.get("LQR_LV_DBG"):
         lib.lqrhip_band_levels_debug.argtypes = [C.c_int]
         lib.lqrhip_band_levels_debug(int(os.environ["LQR_LV_DBG"]))

@@ -31,7 +31,7 @@
 //     in place is safe (a slot's halo columns are its neighbours' own columns); inputs of later levels are rows nobody
 //     writes before those levels' own barriers.
 //   * no reserve tiles, no requests, no edge watches, no inactive forwarding: the only spin is the level barrier.
-// tags = epoch << 9 | (level + 1): nothing is cleared between launches.  Inputs are prefetched two levels ahead for the
+// tags = epoch << 10 | (level + 1): nothing is cleared between launches.  Inputs are prefetched two levels ahead for the
 // tile the slot is expected to have then (the same one, or the tile of its residue nearest to the seam); a wrong guess
 // costs a synchronous load, never a result.
 // Grid (P, images), all co-resident (bounded spins, DEVERR_TILE_TIMEOUT as in k_dp_tile_p).
@@ -64,17 +64,22 @@ struct LvMask {                       // a set of tiles (uniform over the wave);
     __device__ __forceinline__ int last() const { return lo ? 63 - __builtin_clzll(lo) : -1; }
 };
 
-template <bool LR, bool RIG>
+// DELTA = delta_x (1 .. 4): a change moves DELTA columns per row, so a level is HALO / DELTA rows (32, 16, 8, 8); RIGM = a rigidity
+// mask scales the rigidity term per pixel (one more 4-byte plane read).  The plain instantiations (1, false) use the 3-neighbour
+// row dp_row, the others dp_row_g, exactly as k_dp_tile_p's general instantiations do.
+template <bool LR, bool RIG, int DELTA, bool RIGM>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err)
 {
-    constexpr int PX = 2, HALO = 32, OWN = 64, HL = 16, R = 32, TILE = 128;
+    static_assert(DELTA >= 1 && DELTA <= 4 && (RIG || !RIGM), "delta_x 1 .. 4; a rigidity mask only matters with rigidity");
+    constexpr int PX = 2, HALO = 32, OWN = 64, HL = 16, R = lv_rows(DELTA, RIGM), TILE = 128;
+    static_assert(R * DELTA <= HALO, "a level's errors stay inside the halo");
     typedef LaneVec<2>::F FV;
     typedef LaneVec<2>::L LV;
     typedef GLOBAL_AS FV GFV;
     typedef GLOBAL_AS LV GLV;
     typedef GLOBAL_AS unsigned long long gu64;
-    __shared__ int s_tlo[BT_MAX_BLK], s_thi[BT_MAX_BLK];      // per level: columns the carve touched on its rows
+    __shared__ int s_tlo[LV_MAX_LEVELS], s_thi[LV_MAX_LEVELS];      // per level: columns the carve touched on its rows
     __shared__ int s_fail;                        // 1: a spin timed out (results invalid), 2: the image stopped (collision): leave at the next barrier
     __shared__ volatile int s_polled;             // last level whose barrier this workgroup has passed
     __shared__ unsigned long long s_A[2];         // the active set of a level (by parity), from the wave that received it to its partner
@@ -89,6 +94,9 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     gu64 *gran = ex_img + 4 * LV_PMAX;                       // [2 parities][ntiles][OWN]
     const float INF = __int_as_float(0x7f800000);
     const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
+    float rg[2 * DELTA + 1];
+#pragma unroll
+    for (int i = 0; i < 2 * DELTA + 1; i++) rg[i] = p.rigmap[i];
     const int dbg = __builtin_amdgcn_readfirstlane(g_lv_dbg);
     // which lanes of the barrier poll hold the words of the slot of tile `lane`, of tile `lane + 1`, of tile `lane - 1`
     const int ix_own = 2 * (lane % P), ix_right = 2 * ((lane + 1) % P), ix_left = 2 * ((lane + P - 1) % P);
@@ -99,13 +107,15 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     __syncthreads();
     for (int y = tid; y < h; y += 128) {
         const int v0 = c.seam_x[y], vm = c.seam_x[max(y - 1, 0)], vp = c.seam_x[min(y + 1, h - 1)];
-        const int t0 = max(min(min(v0, vm), vp) - 2, 0), t1 = min(max(max(v0, vm), vp) + 1, w - 1);
+        // pixels of row y whose inputs the carve changed: the energy next to the seam on rows y - 1 .. y + 1, and the pixels whose
+        // parent window (DELTA either way on row y - 1) straddles the seam there: [min - DELTA - 1, max + DELTA]
+        const int t0 = max(min(min(v0, vm), vp) - DELTA - 1, 0), t1 = min(max(max(v0, vm), vp) + DELTA, w - 1);
         atomicMin(&s_tlo[y / R], t0); atomicMax(&s_thi[y / R], t1);
     }
     __syncthreads();
     // tiles within reach of a level's touched columns (own_hi + HALO + 2 >= lo  and  own_lo - HALO - 2 <= hi), as one mask per
     // level, worked out once (the level loop reads one LDS word)
-    __shared__ unsigned long long s_tm[BT_MAX_BLK + 2];
+    __shared__ unsigned long long s_tm[LV_MAX_LEVELS + 2];
     for (int L = tid; L < nblk + 2; L += 128) {
         unsigned long long m = 0ull;
         if (L < nblk && s_thi[L] >= s_tlo[L]) {
@@ -168,7 +178,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     // the tile that owns this lane's columns when the wave works on tile t, and the lane's first column inside that tile
     auto owner_of = [&](int t) -> int { return lane < HL ? t - 1 : lane >= 64 - HL ? t + 1 : t; };
     const int owner_col = lane < HL ? HALO + PX * lane : lane >= 64 - HL ? PX * (lane - (64 - HL)) : PX * (lane - HL);
-    FV q_e[R], q_mo[R], q_ab;
+    FV q_e[R], q_mo[R], q_ab, q_rf[RIGM ? R : 1];
     LV q_lo[R];
     q_ab[0] = q_ab[1] = INF;
     auto issue_full = [&](int L) {              // inputs of level L for the tile set_tile() chose, and the row above them
@@ -180,6 +190,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
             q_e[r] = *(const GFV *) ((const gu8 *) c.en + ro4);
             q_mo[r] = *(const GFV *) ((const gu8 *) c.m + ro4);
             q_lo[r] = *(const GLV *) (c.least + ro);
+            if (RIGM) q_rf[RIGM ? r : 0] = *(const GFV *) ((const gu8 *) c.rig + ro4);
         }
         q_ab = *(const GFV *) ((const gu8 *) c.m + ((((unsigned) max(ybase - 1, 0) * (unsigned) stride) + lo_off) << 2));
     };
@@ -194,9 +205,24 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
             bool ch[PX];
 #pragma unroll
             for (int k = 0; k < PX; k++) { e[k] = q_e[r][k]; mo[k] = q_mo[r][k]; }
-            const float left = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1]), DPP_WAVE_SHR1, 0xf, 0xf, true));
-            const float right = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[0]), DPP_WAVE_SHL1, 0xf, 0xf, true));
-            dp_row<PX, LR, RIG, true, false>(mp, left, right, e, mo, (uint32_t) q_lo[r], in, rig_l, rig_r, mc, lnew, ch);
+            if constexpr (DELTA == 1 && !RIGM) {
+                const float left = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1]), DPP_WAVE_SHR1, 0xf, 0xf, true));
+                const float right = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mp[0]), DPP_WAVE_SHL1, 0xf, 0xf, true));
+                dp_row<PX, LR, RIG, true, false>(mp, left, right, e, mo, (uint32_t) q_lo[r], in, rig_l, rig_r, mc, lnew, ch);
+            } else {
+                float nl[DELTA], nr[DELTA], rf[PX];
+#pragma unroll
+                for (int i = 0; i < DELTA; i++) {       // pixel i % PX of the lane i / PX + 1 away: one wave shift per lane
+                    int a = __builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1 - i % PX]), DPP_WAVE_SHR1, 0xf, 0xf, true);
+                    int b2 = __builtin_amdgcn_mov_dpp(__float_as_int(mp[i % PX]), DPP_WAVE_SHL1, 0xf, 0xf, true);
+                    if (i >= PX) { a = __builtin_amdgcn_mov_dpp(a, DPP_WAVE_SHR1, 0xf, 0xf, true); b2 = __builtin_amdgcn_mov_dpp(b2, DPP_WAVE_SHL1, 0xf, 0xf, true); }
+                    nl[i] = __int_as_float(a);
+                    nr[i] = __int_as_float(b2);
+                }
+#pragma unroll
+                for (int k = 0; k < PX; k++) rf[k] = RIGM ? q_rf[RIGM ? r : 0][k] : 1.0f;
+                dp_row_g<PX, DELTA, LR, RIG, RIGM, true, false>(mp, nl, nr, e, mo, (uint32_t) q_lo[r], in, rg, rf, mc, lnew, ch);
+            }
             if (r == 0 && ybase == 0) {          // row 0: m = en, whatever stood there (update_mmap's first row)
 #pragma unroll
                 for (int k = 0; k < PX; k++) mc[k] = e[k];
@@ -229,7 +255,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     // that barrier, active set and halo cost ONE round trip through memory; prev = A_{L-1} says which tiles published.
     // Returns 0, or 1 on a time-out.  fw: this lane's word (lanes < 2 P); g: this lane's granules (valid if spec_t was right).
     auto wait_level = [&](int L, int spec_t, const LvMask &prev, unsigned long long &fw, unsigned long long (&g)[PX]) -> int {
-        const unsigned want = ((unsigned) epoch << 9) | (unsigned) L;
+        const unsigned want = ((unsigned) epoch << 10) | (unsigned) L;
         gu64 *fsrc = flagw + (size_t) ((L - 1) & 1) * 2 * LV_PMAX + (lane < 2 * P ? lane : 0);
         const bool need_g = spec_t >= 0 && prev.has(owner_of(spec_t)) && (in[0] || in[1]);
         gu64 *gsrc = gran + ((size_t) ((L - 1) & 1) * ntiles + (need_g ? owner_of(spec_t) : 0)) * OWN + (need_g ? owner_col : 0);
@@ -258,7 +284,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
         const bool from_gran = prev.has(u) && (in[0] || in[1]);
         if (!have_g) {
             gu64 *src = gran + ((size_t) ((L - 1) & 1) * ntiles + (from_gran ? u : 0)) * OWN + (from_gran ? owner_col : 0);
-            const unsigned want = ((unsigned) epoch << 9) | (unsigned) L;
+            const unsigned want = ((unsigned) epoch << 10) | (unsigned) L;
             int sp = 0;
             while (true) {
 #pragma unroll
@@ -343,7 +369,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
         }
         if (passed && *(volatile int *) &s_fail == 0) t = my_tile(A, mine ? 0 : 1);
         if (!mine && t < 0 && passed && lane == 0 && *(volatile int *) &s_fail == 0) {       // no second tile: said right away
-            const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 9) | (unsigned) (L + 1)) << 32;
+            const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 10) | (unsigned) (L + 1)) << 32;
             __hip_atomic_store(flagw + (size_t) (L & 1) * 2 * LV_PMAX + 2 * slot + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // ---- LOAD: the tile of this level if it is not what was prefetched (synchronous), else -- the other wave -- the prefetch for
@@ -390,7 +416,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
             cur_full = false;                    // (the registers hold results now)
             if (L + 1 < nblk && own_lane) {
                 gu64 *dst = gran + ((size_t) (L & 1) * ntiles + t) * OWN + PX * (lane - HL);
-                const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 9) | (unsigned) (L + 1)) << 32;
+                const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 10) | (unsigned) (L + 1)) << 32;
 #pragma unroll
                 for (int k = 0; k < PX; k++) __hip_atomic_store(dst + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -400,7 +426,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
         } else if (mine && passed) n_idle++;
         // the slot's word for this wave's tile of the level (its granules were issued above; a reader checks their tags itself)
         if (lane == 0 && (t >= 0 || mine) && *(volatile int *) &s_fail == 0) {
-            const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 9) | (unsigned) (L + 1)) << 32;
+            const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 10) | (unsigned) (L + 1)) << 32;
             __hip_atomic_store(flagw + (size_t) (L & 1) * 2 * LV_PMAX + 2 * slot + (mine ? 0 : 1), tag | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         LTT(7);
@@ -425,5 +451,9 @@ extern "C" int lqrhip_band_levels_stats(unsigned long long *out, int reset)
 }
 
 // ---- the instantiations the shim launches (lqr_kernels.h declares them)
-#define INST_LV(LRV, RIGV) template __global__ void k_band_levels<LRV, RIGV>(DevCarver *, DpK, int, int, int, unsigned long long *, int, int *);
-INST_LV(false, false) INST_LV(false, true) INST_LV(true, false) INST_LV(true, true)
+#define INST_LV(...) template __global__ void k_band_levels<__VA_ARGS__>(DevCarver *, DpK, int, int, int, unsigned long long *, int, int *);
+#define INST_LV_LR(LRV) INST_LV(LRV, false, 1, false) INST_LV(LRV, true, 1, false) INST_LV(LRV, true, 1, true) \
+    INST_LV(LRV, false, 2, false) INST_LV(LRV, true, 2, false) INST_LV(LRV, true, 2, true) \
+    INST_LV(LRV, false, 3, false) INST_LV(LRV, true, 3, false) INST_LV(LRV, true, 3, true) \
+    INST_LV(LRV, false, 4, false) INST_LV(LRV, true, 4, false) INST_LV(LRV, true, 4, true)
+INST_LV_LR(false) INST_LV_LR(true)

@@ -475,6 +475,8 @@ constexpr int BT_NEVER = 1 << 30;
 // k_band_levels (k_levels.hip): slots per image at most, tiles per image at most (one 64-bit mask: rows up to 4096 px)
 constexpr int LV_PMAX = 16;
 constexpr int LV_MAX_TILES = 64;
+constexpr int LV_MAX_LEVELS = 512;        // levels per image at most (10 bits of the tags; rows up to 4096 at delta_x >= 3)
+constexpr int lv_rows(int delta, bool rigm = false) { return delta == 1 ? (rigm ? 16 : 32) : delta == 2 ? 16 : 8; }      // rows per level: halo (32 columns) / delta_x (a rigidity mask: 16, for the registers)
 
 // a job of the one-launch plane passes (inflate, flatten, transpose): one carver (root or attached) of a batch
 struct InflateDev {

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h
 template <int PXT, bool UPDATE> __global__ __launch_bounds__(DP_THREADS) void k_dp_sweep(const DevCarver *cs, DpK p, int w, int h, int stride, int lr);
 __global__ __launch_bounds__(64) void k_band_update(const DevCarver *cs, DpK p, int w, int h, int stride, int lr);
 template <int PXL, int NW, int R, bool LR, bool RIG> __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs, DpK p, int w, int h, int stride);
-template <int NW, bool LR, bool RIG> __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs, DpK p, int w, int h, int stride, int *dev_err);
+template <int NW, bool LR, bool RIG> __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs, DpK p, int w, int h, int stride, int *dev_err, int tail);
 
 // k_tiles.hip
 template <bool LR, bool RIG> __global__ __launch_bounds__(64) void k_dp_tile(const DevCarver *cs, DpK p, int w, int h, int stride, int y0);
@@ -34,7 +34,7 @@ template <bool LR, bool RIG>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_band_tiles(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err, int t_base, int hset);
 
 // k_levels.hip
-template <bool LR, bool RIG>
+template <bool LR, bool RIG, int DELTA, bool RIGM>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err);
 
 // k_oneoff.hip

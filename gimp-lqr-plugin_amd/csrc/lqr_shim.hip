@@ -130,7 +130,12 @@ static int dpp_resident_workgroups(int dev)
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 128, 0) != hipSuccess) { (void) hipGetLastError(); n = 0; }
             per_cu = std::min(per_cu, n);
         };
-        ql(k_band_levels<false, false>); ql(k_band_levels<false, true>); ql(k_band_levels<true, false>); ql(k_band_levels<true, true>);
+#define QL(LRV) ql(k_band_levels<LRV, false, 1, false>); ql(k_band_levels<LRV, true, 1, false>); ql(k_band_levels<LRV, true, 1, true>); \
+    ql(k_band_levels<LRV, false, 2, false>); ql(k_band_levels<LRV, true, 2, false>); ql(k_band_levels<LRV, true, 2, true>); \
+    ql(k_band_levels<LRV, false, 3, false>); ql(k_band_levels<LRV, true, 3, false>); ql(k_band_levels<LRV, true, 3, true>); \
+    ql(k_band_levels<LRV, false, 4, false>); ql(k_band_levels<LRV, true, 4, false>); ql(k_band_levels<LRV, true, 4, true>)
+        QL(false); QL(true);
+#undef QL
         g_dpp_max_wgs_levels = std::max(0, per_cu - 1) * prop.multiProcessorCount;
     }
     return g_dpp_max_wgs_plain;
@@ -769,6 +774,9 @@ struct ProfScope {
 
 extern "C" void lqrhip_prof_enable(int on) { g_prof = on; }
 static int g_update_mode = -1;
+static int g_tw_tail = 1;                // k_band_update_tw finishes the rows its window could not hold itself (0: k_dp_sweep<UPDATE> in a launch of its own, as until round 4)
+extern "C" void lqrhip_set_tw_tail(int on) { g_tw_tail = on != 0; }
+static int g_band_levels = -1;           // k_band_levels: -1 automatic; 0 never; n: n slots per image (lqrhip_set_band_levels)
 // -1: by batch size (g_tiled_update_px); 0: band kernel (k_band_update_tw); 1: tiled full-width update whenever its
 // grid fits; 2: the per-row-barrier band kernel (k_band_update_mw); 3: the generic one-wave band kernel + sweep
 // (what delta_x > 2 runs on), whatever the parameters
@@ -900,7 +908,15 @@ extern "C" int lqrhip_general_batch_limit(int w)
 {
     if (lqrhip_init() < 0 || w < 1) return 0;
     const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_general) : g_dpp_max_wgs_general;
-    return limit / ((w + dpp_own(2) - 1) / dpp_own(2));
+    const int tiled = limit / ((w + dpp_own(2) - 1) / dpp_own(2));
+    // round 5: groups of 8 and more such carvers run on k_band_levels (7 or more slots per image, rows up to 4096 px), which takes
+    // far larger groups than the full-width tiled kernels; its full DPs (3 per resize) then go to k_dp_sweep, one workgroup per image
+    if (g_band_levels != 0 && g_update_mode < 0 && (w + 63) / 64 <= LV_MAX_TILES) {
+        const int lim_lv = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_levels) : g_dpp_max_wgs_levels;
+        const int lv = lim_lv / 7;
+        if (lv >= 8) return std::max(tiled, lv);
+    }
+    return tiled;
 }
 
 // E5 (UPDATE = false) or the full-width form of E9 (UPDATE = true) as one persistent launch
@@ -1100,11 +1116,10 @@ static int launch_band_tiles(LqrHipBatch *b, const DpK &k, int w, int h, int lr,
 // residency bound, at most LV_PMAX; lqrhip_set_band_levels pins it (tests, experiments).  The default for large groups is 6:
 // the active tiles of a 4K level are 4.5 on average, a window of 6 consecutive tiles never collides, and 64 x 6 workgroups hold
 // half the registers of round 4's 64 x 12.
-static int g_band_levels = -1;           // -1: automatic; 0: never; n: n slots per image
 extern "C" void lqrhip_set_band_levels(int slots) { g_band_levels = slots; }
-static int band_levels_P(const LqrHipBatch *b, int w, int h)
+static int band_levels_P(const LqrHipBatch *b, int w, int h, int delta)
 {
-    if (g_band_levels == 0 || (h + 31) / 32 > BT_MAX_BLK || (w + 63) / 64 > LV_MAX_TILES) return 0;
+    if (g_band_levels == 0 || delta < 1 || delta > 4 || (h + lv_rows(delta, true) - 1) / lv_rows(delta, true) > LV_MAX_LEVELS || (w + 63) / 64 > LV_MAX_TILES) return 0;
     const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_levels) : g_dpp_max_wgs_levels;
     const int per_batch = limit / std::max(b->shared_n, 1);
     int P = std::min(LV_PMAX, per_batch / (int) std::max<size_t>(b->cs.size(), 1));
@@ -1115,7 +1130,7 @@ static int band_levels_P(const LqrHipBatch *b, int w, int h)
     P = std::min(P, want);
     return P >= (g_band_levels > 0 ? 1 : 7) ? P : 0;
 }
-static int launch_band_levels(LqrHipBatch *b, const DpK &k, int w, int h, int lr, int P)
+static int launch_band_levels(LqrHipBatch *b, const DpK &k, int w, int h, int lr, int P, bool rigm)
 {
     LqrHipCarver *c0 = b->cs[0];
     const size_t n = b->cs.size();
@@ -1134,11 +1149,14 @@ static int launch_band_levels(LqrHipBatch *b, const DpK &k, int w, int h, int lr
         HIPCK(hipMemsetAsync(b->exch, 0, need_elems * sizeof(unsigned long long), b->stream));
         b->exch_ntiles = ntiles; b->exch_n = (int) n; b->exch_px = 103;
     }
-    const int epoch = 1 + ((b->tile_epoch++) % ((1 << 23) - 2));           // never 0; 23 bits above the 9 bits of level + 1
+    const int epoch = 1 + ((b->tile_epoch++) % ((1 << 22) - 2));           // never 0; 22 bits above the 10 bits of level + 1
     const dim3 grid(P, (unsigned) n);
-#define LAUNCH_LV(LRV, RIGV) hipLaunchKernelGGL((k_band_levels<LRV, RIGV>), grid, dim3(128), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
-    if (lr) { if (k.use_rig) LAUNCH_LV(true, true); else LAUNCH_LV(true, false); }
-    else { if (k.use_rig) LAUNCH_LV(false, true); else LAUNCH_LV(false, false); }
+#define LAUNCH_LV(LRV, RIGV, DV, RMV) hipLaunchKernelGGL((k_band_levels<LRV, RIGV, DV, RMV>), grid, dim3(128), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
+#define LAUNCH_LV_LR(RIGV, DV, RMV) do { if (lr) LAUNCH_LV(true, RIGV, DV, RMV); else LAUNCH_LV(false, RIGV, DV, RMV); } while (0)
+#define LAUNCH_LV_D(DV) do { if (!k.use_rig) LAUNCH_LV_LR(false, DV, false); else if (!rigm) LAUNCH_LV_LR(true, DV, false); else LAUNCH_LV_LR(true, DV, true); } while (0)
+    if (k.delta == 1) LAUNCH_LV_D(1); else if (k.delta == 2) LAUNCH_LV_D(2); else if (k.delta == 3) LAUNCH_LV_D(3); else LAUNCH_LV_D(4);
+#undef LAUNCH_LV_D
+#undef LAUNCH_LV_LR
 #undef LAUNCH_LV
     HIPCK(hipGetLastError());
     return 0;
@@ -1256,15 +1274,18 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     // resident tile workgroups the carves of the sibling streams are starved of registers, so large groups
     // keep k_band_update_tw.
     {
-        // round 5: the band on P slots per image, tiles assigned level by level (k_band_levels): the default for groups of 8 to 40
+        // round 5: the band on P slots per image, tiles assigned level by level (k_band_levels): the default for groups of 8 to 48
         // images (measured, Mseams*px/s at 4K, levels / k_band_tiles / k_band_update_tw: 8 images 137 / 134 / 127, 16: 234 / 235 / 193;
         // 64: 508 / 488 / 508-540 -- large groups keep k_band_update_tw); update mode 5 forces it
+        // round 5: also delta_x 2 .. 4 and rigidity masks (k_band_levels' general instantiations): a batch of such carvers used to be
+        // carved in groups of as many as the full-width tiled kernels hold (16 x 4K, delta_x 2: 68 k Mseams*px/s)
         const size_t group_images = (size_t) n * (size_t) std::max(b->shared_n, 1);
-        const int PL = (fast_ok && (g_update_mode == 5 || (g_update_mode < 0 && group_images >= 8 && group_images <= 40))) ? band_levels_P(b, wnew, h) : 0;
+        const bool lv_ok = p->delta_x >= 1 && p->delta_x <= 4 && g_update_mode != 3;
+        const int PL = (lv_ok && (g_update_mode == 5 || (g_update_mode < 0 && group_images >= 8 && (group_images <= 48 || !fast_ok)))) ? band_levels_P(b, wnew, h, p->delta_x) : 0;
         if (PL > 0) {
             {
-                ProfScope ps("band_update", b->stream, 0);
-                if ((rc = launch_band_levels(b, k, wnew, h, leftright_next, PL))) return rc;
+                ProfScope ps("band_levels", b->stream, 0);
+                if ((rc = launch_band_levels(b, k, wnew, h, leftright_next, PL, rigm))) return rc;
             }
             ProfScope ps("dp_update", b->stream, 0);
             if ((rc = launch_dp<true>(b, k, wnew, h, leftright_next))) return rc;
@@ -1300,10 +1321,17 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     const bool band_tw = fast_band && g_update_mode != 2 && wnew <= 4200 && (size_t) 2 * h * sizeof(int) <= 64 * 1024;
     if (band_tw) {
         ProfScope ps("band_update", b->stream, 0);
-#define LAUNCH_TW(LRV, RIGV) hipLaunchKernelGGL((k_band_update_tw<4, LRV, RIGV>), dim3(n), dim3(128 * 4), (size_t) 2 * h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, g_dev_err)
+        // dynamic LDS: the touch ranges of the band walk (2 h ints) and, after it, the two rows of the kernel's own tail sweep
+        const size_t tw_lds = std::max((size_t) 2 * h * sizeof(int), (size_t) 2 * ((wnew + 3) & ~3) * sizeof(float));
+#define LAUNCH_TW(LRV, RIGV) hipLaunchKernelGGL((k_band_update_tw<4, LRV, RIGV>), dim3(n), dim3(128 * 4), tw_lds, b->stream, b->d_desc, k, wnew, h, stride, g_dev_err, g_tw_tail)
         if (leftright_next) { if (p->use_rigidity) LAUNCH_TW(true, true); else LAUNCH_TW(true, false); }
         else { if (p->use_rigidity) LAUNCH_TW(false, true); else LAUNCH_TW(false, false); }
 #undef LAUNCH_TW
+        // (rows the window could not hold are finished by the kernel itself: no k_dp_sweep<UPDATE> launch behind it)
+        if (g_tw_tail) {
+            HIPCK(hipGetLastError());
+            return 0;
+        }
     } else if (fast_band) {
         ProfScope ps("band_update", b->stream, 0);
 #define LAUNCH_MW(NWV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_mw<2, NWV, 8, LRV, RIGV>), dim3(n), dim3(64 * NWV), (size_t) h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride)

@@ -42,7 +42,7 @@ def _kw(v, w, h, switch_freq):
 @pytest.mark.parametrize("kind,w,h,n_seams", [("photo", 700, 300, 40), ("noise", 1500, 150, 30), ("flat", 400, 220, 35), ("noise", 131, 517, 25)])
 def test_dp_planes_general_tiled(oracle, engine, variant, kind, w, h, n_seams):
     """en, m and the back pointers after the last incremental update, bit for bit, with the incremental updates on the
-    tiled kernel (auto) and on the generic band kernel + sweep (band): several tiles wide (64 own columns each), more
+    tiled kernel (auto), on the generic band kernel + sweep (band) and on k_band_levels (levels): several tiles wide (64 own columns each), more
     rows than one block (32 / delta_x rows), tie-heavy input included; switch_freq 0 keeps every update incremental"""
     v = VARIANTS[variant]
     img = {"photo": D.photo_like, "noise": D.noise, "flat": D.flat_blocks}[kind](w, h, w + h)
@@ -55,7 +55,7 @@ def test_dp_planes_general_tiled(oracle, engine, variant, kind, w, h, n_seams):
     oracle.lqrx_set_debug(0)
     c.destroy()
     try:
-        for mode in (-1, 0):
+        for mode in (-1, 0, 5):          # 5: k_band_levels' general instantiations (round 5)
             engine.lib.lqrhip_set_update_mode(mode)
             engine.lqrx_set_debug(1)
             c, _ = H.init_carver(engine, img, w - n_seams, h, **kw)

@@ -1,7 +1,10 @@
 """Round 5 (-m gpu).
 * A lock-step group of 32 or more delta_x = 2 / rigidity-mask carvers that fits the tiled kernels' residency bound is NOT split
   over sub-batch streams (shared batches never run the persistent kernels: ADVICE r4 -- such a group fell to the
-  one-wave-per-image kernels, ~30x slower, now that the library sets GPU_MAX_HW_QUEUES=8 itself).
+  one-wave-per-image kernels, ~30x slower, now that the library sets GPU_MAX_HW_QUEUES=8 itself); since k_band_levels has
+  general instantiations such a group runs on them (or on the full-width tiled kernels), never on k_band_update.
+* k_band_levels with delta_x 2 .. 4 and rigidity masks: lock-step batches of 9 images per variant against the oracle, and whole
+  resizes in both directions with the kernel forced (update mode 5) on single images.
 * lqrhip_moved_bytes: the bytes the carves had to move, as k_vpath* counts them, against a count made from the seam maps.
 """
 import ctypes
@@ -23,7 +26,7 @@ def prof_launches(lib, name):
 
 
 @pytest.mark.parametrize("variant", ["delta2", "rigmask"])
-def test_general_group_of_36_small_images_stays_on_the_tiled_kernels(oracle, engine, variant):
+def test_general_group_of_36_small_images_stays_off_the_one_wave_kernels(oracle, engine, variant):
     lib = engine.lib
     lib.lqrhip_sub_batches.argtypes = [ctypes.c_int]
     lib.lqrhip_set_sub_batches.argtypes = [ctypes.c_int]
@@ -45,7 +48,8 @@ def test_general_group_of_36_small_images_stays_on_the_tiled_kernels(oracle, eng
         lib.lqrhip_prof_reset(); lib.lqrhip_prof_enable(1)
         assert L.resize_batch(engine, cs, w - 21, h - 6) == L.LQR_OK
         lib.lqrhip_prof_enable(0)
-        assert prof_launches(lib, "dp_update_tiled") > 0 and prof_launches(lib, "band_update") == 0, "the group fell to the band kernels"
+        assert prof_launches(lib, "band_levels") + prof_launches(lib, "dp_update_tiled") > 0 and prof_launches(lib, "band_update") == 0, \
+            "the group fell to the one-wave band kernel"
         for c, im in zip(cs, imgs):
             ref = H.run_case(oracle, im, w - 21, h - 6, rigmask=rigm, **kw)
             assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"])
@@ -93,3 +97,56 @@ def test_moved_bytes_equal_the_shorter_side_of_every_seam(oracle, engine):
             cur_w -= 1
         return tot
     assert got.value in (total(order), total(order[::-1])), (got.value, total(order), total(order[::-1]))
+
+
+GENERAL = {"delta2": dict(delta_x=2), "delta3": dict(delta_x=3), "delta4-rigidity": dict(delta_x=4, rigidity=3.0),
+           "rigmask": dict(rigidity=5.0, rigmask=True), "delta2-rigmask": dict(delta_x=2, rigidity=2.0, rigmask=True)}
+
+
+@pytest.mark.parametrize("variant", sorted(GENERAL))
+def test_band_levels_general_batch_of_9(oracle, engine, variant):
+    """a group of 9 (>= 8: the engine's own choice is k_band_levels) with delta_x 2 .. 4 / a rigidity mask, every image against the oracle"""
+    lib = engine.lib
+    w, h, n = 700, 260, 9
+    v = dict(GENERAL[variant])
+    rigm = D.top_half_mask(w, h) if v.pop("rigmask", False) else None
+    imgs = [D.photo_like(w, h, 7100 + i) if i % 2 else D.noise(w, h, 7100 + i) for i in range(n)]
+    cs = []
+    for im in imgs:
+        c = L.Carver(engine, im, delta_x=v.get("delta_x", 1), rigidity=(3 * v.get("rigidity", 0.0) if rigm is not None else v.get("rigidity", 0.0)))
+        if rigm is not None:
+            assert c.rigmask_add(rigm) == L.LQR_OK
+        cs.append(c.configure())
+    lib.lqrhip_prof_reset(); lib.lqrhip_prof_enable(1)
+    try:
+        assert L.resize_batch(engine, cs, w - 50, h - 20) == L.LQR_OK
+    finally:
+        lib.lqrhip_prof_enable(0)
+    assert prof_launches(lib, "band_levels") > 0 and prof_launches(lib, "band_update") == 0
+    for c, im in zip(cs, imgs):
+        ref = H.run_case(oracle, im, w - 50, h - 20, rigmask=rigm, **v)
+        assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"])
+        assert np.array_equal(c.read_image(), ref["image"])
+    for c in cs:
+        c.destroy()
+
+
+@pytest.mark.parametrize("variant", sorted(GENERAL))
+@pytest.mark.parametrize("slots", [2, 5, 16])
+def test_band_levels_general_forced_on_single_images(oracle, engine, variant, slots):
+    """update mode 5 with few and many slots (few: two tiles per slot and level, three = the image stops and the sweep takes over)"""
+    lib = engine.lib
+    lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]
+    lib.lqrhip_set_band_levels.argtypes = [ctypes.c_int]
+    w, h = 900, 330
+    v = dict(GENERAL[variant])
+    rigm = D.ellipse_mask(w, h) if v.pop("rigmask", False) else None
+    img = D.photo_like(w, h, 88)
+    kw = dict(v, pres=D.ellipse_mask(w, h), output_seams=True)
+    lib.lqrhip_set_update_mode(5); lib.lqrhip_set_band_levels(slots)
+    try:
+        a = H.run_case(oracle, img, w - 70, h - 25, rigmask=rigm, **kw)
+        b = H.run_case(engine, img, w - 70, h - 25, rigmask=rigm, **kw)
+        H.assert_same(a, b, "levels general %s, %d slots" % (variant, slots))
+    finally:
+        lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_levels(-1)
