@@ -537,53 +537,8 @@ constexpr int TW_OWN = 256 - 2 * TW_R;       // own columns per slot
 // and that path is this kernel's bound.
 constexpr int TW_LANE_MARGIN = 2 * TW_R + 8;
 
-// The keep-rule over the FULL width from row y0 on, by the workgroup that walked the band down to there (delta_x = 1, no
-// rigidity mask): what k_dp_sweep<UPDATE> does in a launch of its own, as the tail of the band kernel -- the hand-over is rare
-// (the changes outgrew the 896-column window), and an (almost always empty) launch per seam round cost the chain 25 us plus a
-// dependency gap.  sm: 2 * ((w + 3) & ~3) floats of LDS (the touch ranges of the band walk are dead by now).  One barrier per row,
-// no register prefetch: a few hundred rows at ~1 us.
-template <int NT, bool LR, bool RIG>
-__device__ __forceinline__ void tail_sweep_update(const GCarver &c, const DpK &p, int w, int h, int stride, int y0, float *sm)
-{
-    const int tid = threadIdx.x;
-    const int wpad = (w + 3) & ~3;
-    float *prev = sm, *cur = sm + wpad;
-    const float INF = __int_as_float(0x7f800000);
-    const float rig_l = p.rigmap[0], rig_r = p.rigmap[2];
-    // the rows above y0 were stored by this workgroup: make them visible to its own loads
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (y0 == 0) {
-        for (int x = tid; x < w; x += NT) { const float e = c.en[x]; c.m[x] = e; prev[x] = e; }
-        y0 = 1;
-    } else {
-        for (int x = tid; x < w; x += NT) prev[x] = c.m[(size_t) (y0 - 1) * stride + x];
-    }
-    __syncthreads();
-    for (int y = y0; y < h; y++) {
-        for (int x = tid; x < w; x += NT) {
-            const size_t o = (size_t) y * stride + x;
-            float l = x > 0 ? prev[x - 1] : INF, cc = prev[x], rr = x + 1 < w ? prev[x + 1] : INF;
-            if (RIG) { l = __fadd_rn(l, rig_l); rr = __fadd_rn(rr, rig_r); }
-            const float best = fminf(fminf(l, cc), rr);
-            int bdx;
-            if (LR) { bdx = (cc == best) ? 0 : -1; bdx = (rr == best) ? 1 : bdx; }
-            else { bdx = (cc == best) ? 0 : 1; bdx = (l == best) ? -1 : bdx; }
-            float nm = __fadd_rn(c.en[o], best);
-            const float mo = c.m[o];
-            if ((int) c.least[o] == bdx && (double) fabsf(__fsub_rn(mo, nm)) < 1e-5) nm = mo;
-            else c.m[o] = nm;
-            c.least[o] = (int8_t) bdx;
-            cur[x] = nm;
-        }
-        __syncthreads();
-        float *t = prev; prev = cur; cur = t;
-    }
-}
-
 template <int NW, bool LR, bool RIG>
-__device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const DpK &p, int w, int h, int stride, int *dev_err, int tail)
+__device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const DpK &p, int w, int h, int stride, int *dev_err)
 {
     constexpr int R = TW_R, OWN = TW_OWN, WIN = NW * OWN, NT = 128 * NW;
     const GCarver c = gview(dc);
@@ -838,27 +793,20 @@ __device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const D
             __syncthreads();
         }
     }
-    // the rows the window could not hold: the full-width keep-rule from there, by this workgroup (every wave left the loop at the
-    // same `ovf`: the decision is uniform); nothing is left for k_dp_sweep<UPDATE>
-    if (ovf < h && tail) {
-        __syncthreads();
-        tail_sweep_update<NT, LR, RIG>(c, p, w, h, stride, ovf, (float *) s_tw);
-        ovf = h;
-    }
     if (tid == 0) c.flags[FLAG_OVF_ROW] = ovf;
 }
 
 template <int NW, bool LR, bool RIG>
-__global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs, DpK p, int w, int h, int stride, int *dev_err, int tail)
+__global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs, DpK p, int w, int h, int stride, int *dev_err)
 {
-    band_update_tw_body<NW, LR, RIG>(cs[blockIdx.x], p, w, h, stride, dev_err, tail);
+    band_update_tw_body<NW, LR, RIG>(cs[blockIdx.x], p, w, h, stride, dev_err);
 }
 
 
 // ---- the instantiations the shim launches (lqr_kernels.h declares them)
 #define INST_SWEEP(P) template __global__ void k_dp_sweep<P, false>(const DevCarver *, DpK, int, int, int, int); template __global__ void k_dp_sweep<P, true>(const DevCarver *, DpK, int, int, int, int);
 INST_SWEEP(1) INST_SWEEP(2) INST_SWEEP(4) INST_SWEEP(8) INST_SWEEP(16)
-#define INST_BAND(LRV, RIGV) template __global__ void k_band_update_tw<4, LRV, RIGV>(const DevCarver *, DpK, int, int, int, int *, int); \
+#define INST_BAND(LRV, RIGV) template __global__ void k_band_update_tw<4, LRV, RIGV>(const DevCarver *, DpK, int, int, int, int *); \
     template __global__ void k_band_update_mw<2, 8, 8, LRV, RIGV>(const DevCarver *, DpK, int, int, int); \
     template __global__ void k_band_update_mw<2, 16, 8, LRV, RIGV>(const DevCarver *, DpK, int, int, int);
 INST_BAND(false, false) INST_BAND(false, true) INST_BAND(true, false) INST_BAND(true, true)

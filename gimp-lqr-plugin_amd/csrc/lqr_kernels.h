@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h
 template <int PXT, bool UPDATE> __global__ __launch_bounds__(DP_THREADS) void k_dp_sweep(const DevCarver *cs, DpK p, int w, int h, int stride, int lr);
 __global__ __launch_bounds__(64) void k_band_update(const DevCarver *cs, DpK p, int w, int h, int stride, int lr);
 template <int PXL, int NW, int R, bool LR, bool RIG> __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs, DpK p, int w, int h, int stride);
-template <int NW, bool LR, bool RIG> __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs, DpK p, int w, int h, int stride, int *dev_err, int tail);
+template <int NW, bool LR, bool RIG> __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs, DpK p, int w, int h, int stride, int *dev_err);
 
 // k_tiles.hip
 template <bool LR, bool RIG> __global__ __launch_bounds__(64) void k_dp_tile(const DevCarver *cs, DpK p, int w, int h, int stride, int y0);

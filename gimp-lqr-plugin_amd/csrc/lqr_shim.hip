@@ -774,8 +774,6 @@ struct ProfScope {
 
 extern "C" void lqrhip_prof_enable(int on) { g_prof = on; }
 static int g_update_mode = -1;
-static int g_tw_tail = 1;                // k_band_update_tw finishes the rows its window could not hold itself (0: k_dp_sweep<UPDATE> in a launch of its own, as until round 4)
-extern "C" void lqrhip_set_tw_tail(int on) { g_tw_tail = on != 0; }
 static int g_band_levels = -1;           // k_band_levels: -1 automatic; 0 never; n: n slots per image (lqrhip_set_band_levels)
 // -1: by batch size (g_tiled_update_px); 0: band kernel (k_band_update_tw); 1: tiled full-width update whenever its
 // grid fits; 2: the per-row-barrier band kernel (k_band_update_mw); 3: the generic one-wave band kernel + sweep
@@ -1321,17 +1319,13 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     const bool band_tw = fast_band && g_update_mode != 2 && wnew <= 4200 && (size_t) 2 * h * sizeof(int) <= 64 * 1024;
     if (band_tw) {
         ProfScope ps("band_update", b->stream, 0);
-        // dynamic LDS: the touch ranges of the band walk (2 h ints) and, after it, the two rows of the kernel's own tail sweep
-        const size_t tw_lds = std::max((size_t) 2 * h * sizeof(int), (size_t) 2 * ((wnew + 3) & ~3) * sizeof(float));
-#define LAUNCH_TW(LRV, RIGV) hipLaunchKernelGGL((k_band_update_tw<4, LRV, RIGV>), dim3(n), dim3(128 * 4), tw_lds, b->stream, b->d_desc, k, wnew, h, stride, g_dev_err, g_tw_tail)
+#define LAUNCH_TW(LRV, RIGV) hipLaunchKernelGGL((k_band_update_tw<4, LRV, RIGV>), dim3(n), dim3(128 * 4), (size_t) 2 * h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride, g_dev_err)
         if (leftright_next) { if (p->use_rigidity) LAUNCH_TW(true, true); else LAUNCH_TW(true, false); }
         else { if (p->use_rigidity) LAUNCH_TW(false, true); else LAUNCH_TW(false, false); }
 #undef LAUNCH_TW
-        // (rows the window could not hold are finished by the kernel itself: no k_dp_sweep<UPDATE> launch behind it)
-        if (g_tw_tail) {
-            HIPCK(hipGetLastError());
-            return 0;
-        }
+        // (round 5: the kernel finishing the rows its window cannot hold itself, without the (almost always empty) k_dp_sweep<UPDATE>
+        // launch behind it, was built and measured on one box: 527.5 / 523.5 k against 531 / 528 k -- the launch's 22 us reappear in
+        // the kernels around it (k_vpath1 74 -> 92 us, k_carve 149 -> 162), the step is not the sum of a chain's kernels; removed)
     } else if (fast_band) {
         ProfScope ps("band_update", b->stream, 0);
 #define LAUNCH_MW(NWV, LRV, RIGV) hipLaunchKernelGGL((k_band_update_mw<2, NWV, 8, LRV, RIGV>), dim3(n), dim3(64 * NWV), (size_t) h * sizeof(int), b->stream, b->d_desc, k, wnew, h, stride)
