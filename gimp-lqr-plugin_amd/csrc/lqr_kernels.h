@@ -17,6 +17,9 @@ __global__ __launch_bounds__(256) void k_frozen_catchup(const DevCarver *cs, int
 __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, int w, int h, int stride, int lr, int delta, int log_index, int moved_unit);
 template <int DELTA> __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, int w, int h, int stride, int lr, int log_index, int moved_unit);
 
+__global__ __launch_bounds__(VPATH_THREADS) void k_vpath2(const DevCarver *cs, int w, int h, int stride, int lr, int log_index, int moved_unit, int *dev_err);
+extern "C" size_t lqrhip_vpath2_lds_bytes(void);
+
 // k_carve.hip
 __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h, int stride, int delta, int move_dp);
 

@@ -774,6 +774,8 @@ struct ProfScope {
 
 extern "C" void lqrhip_prof_enable(int on) { g_prof = on; }
 static int g_update_mode = -1;
+static int g_vpath2 = 1;                 // delta_x = 1 backtrack: 1 k_vpath2 (three waves, round 5), 0 k_vpath1<1> (one wave)
+extern "C" void lqrhip_set_vpath2(int on) { g_vpath2 = on != 0; }
 static int g_band_levels = -1;           // k_band_levels: -1 automatic; 0 never; n: n slots per image (lqrhip_set_band_levels)
 // -1: by batch size (g_tiled_update_px); 0: band kernel (k_band_update_tw); 1: tiled full-width update whenever its
 // grid fits; 2: the per-row-barrier band kernel (k_band_update_mw); 3: the generic one-wave band kernel + sweep
@@ -1215,7 +1217,15 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     const int moved_unit = 2 * (4 + (move_dp ? 5 : 0) + (has_rigmask ? 4 : 0));
     {
         ProfScope ps("vpath", b->stream, 0);
-        if (p->delta_x == 1)
+        if (p->delta_x == 1 && g_vpath2) {
+            // round 5: the chase on a wave of its own (loader / chaser / helper waves, LDS ring filled by LDS-DMA)
+            static bool attr_set = false;
+            if (!attr_set) {
+                HIPCK(hipFuncSetAttribute((const void *) k_vpath2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lqrhip_vpath2_lds_bytes()));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_vpath2, dim3(n), dim3(VPATH_THREADS), lqrhip_vpath2_lds_bytes(), b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit, g_dev_err);
+        } else if (p->delta_x == 1)
             hipLaunchKernelGGL(k_vpath1<1>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit);
         else if (p->delta_x == 2)
             hipLaunchKernelGGL(k_vpath1<2>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit);
