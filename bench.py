@@ -285,9 +285,6 @@ def main():
     lib.lqrhip_set_band_tiles_reserve(args.band_tiles_reserve)
     lib.lqrhip_set_band_levels.argtypes = [C.c_int]
     lib.lqrhip_set_band_levels(args.band_levels)
-    if os.environ.get("LQR_VPATH2"):
-        lib.lqrhip_set_vpath2.argtypes = [C.c_int]
-        lib.lqrhip_set_vpath2(int(os.environ["LQR_VPATH2"]))
     if os.environ.get("LQR_LV_DBG"):
         lib.lqrhip_band_levels_debug.argtypes = [C.c_int]
         lib.lqrhip_band_levels_debug(int(os.environ["LQR_LV_DBG"]))

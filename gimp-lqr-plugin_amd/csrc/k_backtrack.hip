@@ -284,146 +284,6 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, i
 }
 
 
-// ---------------------------------------------------------------------------
-// k_vpath2 (round 5, delta_x == 1): k_vpath1 with the chase taken off everything that is not the chase.  In k_vpath1 ONE wave does
-// it all: per 28-row chunk ~2 050 cycles of which the serial chase is 630; the rest is issuing the loads of the chunk three ahead,
-// moving the landed rows from registers to LDS, and -- after the chase -- the odd rows, the seam stores and the side sum.  Here the
-// four waves that found the argmin split up:
-//   * wave 1, the LOADER, streams the back-pointer rows straight into an LDS ring (global_load_lds_dwordx4: 1 KiB per instruction,
-//     two rows of a 512-column window, no registers), up to 6 chunks ahead of the chase and 4 chunks of loads in flight (vmcnt
-//     holds 63).  The window is centred on the column the chase has reached when the loads are issued; it drifts 28 columns per
-//     chunk at most, so the 64 columns a chunk spreads out are inside (6 x 28 + 28 + 32 < 240);
-//   * wave 0, the CHASER, per chunk: 28 LDS byte reads (one column per lane around its exact start column), 14 pair compositions
-//     (ds_bpermute), the 14-step chase, and the path (one register) to LDS;
-//   * wave 2, the HELPER, fills in the odd rows, stores seam and seam log, sums the columns and finally publishes the side.
-// They meet through LDS counters only (chunks landed / chased / helped); LDS operations of a wave execute in order, so a counter
-// written after the data is seen after it.  Same results as k_vpath / k_vpath1 by construction (the same byte plane, the same walk).
-// ---------------------------------------------------------------------------
-constexpr int VP2_R = 28, VP2_WIN = 512, VP2_RING = 8, VP2_FLIGHT = 4, VP2_LEAD = 6;
-constexpr int VP2_SLOT = VP2_R * VP2_WIN;           // bytes of a ring slot
-static_assert(VP2_LEAD * VP2_R + VP2_R + 32 <= VP2_WIN / 2 - 16 && VP2_LEAD + 2 <= VP2_RING && (VP2_R / 2) * (VP2_FLIGHT) <= 63, "window margin, ring size, vmcnt");
-typedef __attribute__((address_space(1))) const void vp_gv;
-typedef __attribute__((address_space(3))) void vp_lv;
-extern "C" size_t lqrhip_vpath2_lds_bytes(void) { return (size_t) VP2_RING * VP2_SLOT; }
-
-__global__ __launch_bounds__(VPATH_THREADS) void k_vpath2(const DevCarver *cs, int w, int h, int stride, int lr, int log_index, int moved_unit, int *dev_err)
-{
-    const GCarver c = gview(cs[blockIdx.x]);
-    const int org = c.flags[FLAG_ORG];           // read before the helper publishes the next one
-    extern __shared__ __attribute__((aligned(16))) int8_t s_ring[];      // [VP2_RING][VP2_R rows][VP2_WIN columns]
-    __shared__ float s_val[VPATH_THREADS / 64];
-    __shared__ int s_idx[VPATH_THREADS / 64];
-    __shared__ volatile int s_landed, s_chased, s_helped;      // chunks whose rows are in the ring / chased / written out
-    __shared__ volatile int s_xlatest, s_xfinal;               // the column the chase has reached (start of chunk s_chased); at row 0
-    __shared__ volatile int s_base[VP2_RING], s_xstart[VP2_RING];      // per slot: first column of the window; the chunk's exact start column
-    __shared__ int s_path[2][64];                              // chaser -> helper, by chunk parity
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) { s_landed = 0; s_chased = 0; s_helped = 0; s_xfinal = 0; }
-
-    // ---- argmin over the last row: leftmost (lr=0) / rightmost (lr=1) of equals (all four waves; row_argmin has the barriers)
-    const int xmin = row_argmin(c.m + (size_t) (h - 1) * stride, w, lr, s_val, s_idx);
-    const int x_first = __builtin_amdgcn_readfirstlane(max(xmin, 0));
-    if (tid == 0) s_xlatest = x_first;
-    __syncthreads();
-    constexpr int R = VP2_R;
-    const int nchunk = (h - 1 + R - 1) / R;                     // rows h - 1 .. 1 in chunks of R from the bottom
-    auto nap = [&](int &sp) { __builtin_amdgcn_s_sleep(1); return ++sp < (1 << 22); };
-    if (wave == 1) {
-        // ---- LOADER
-        for (int j = 0; j < nchunk; j++) {
-            int sp = 0;
-            while ((min(s_chased, s_helped) < j - VP2_RING + 1 || s_chased < j - VP2_LEAD) && nap(sp)) { }
-            if (sp >= (1 << 22)) { if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); return; }
-            const int cx = s_xlatest;
-            const int base = (cx - VP2_WIN / 2) & ~15;          // multiple of 16: a lane's 16 columns never straddle column 0
-            const int slot = j % VP2_RING;
-            if (lane == 0) s_base[slot] = base;
-            const int y_top = h - 1 - j * R;
-            // lanes 0 .. 31: row y_top - 2 q, lanes 32 .. 63: the row above it; 16 columns per lane; nothing is predicated (columns
-            // outside the plane are clamped into it -- the path never goes there -- and rows above row 1 re-read row 1)
-            const int voff = min(max(base + 16 * (lane & 31), 0), stride - 16);
-            const int rsub = (lane >> 5) * stride;
-#pragma unroll
-            for (int q = 0; q < R / 2; q++) {
-                const int row = max((y_top - 2 * q) * stride - rsub, stride);
-                __builtin_amdgcn_global_load_lds((vp_gv *) (c.least + (unsigned) (row + voff)), (vp_lv *) (s_ring + slot * VP2_SLOT + q * 1024), 16, 0, 0);
-            }
-            if (j >= VP2_FLIGHT - 1) {                           // chunk j - (FLIGHT - 1) has landed when at most (FLIGHT - 1) chunks' loads are out
-                __builtin_amdgcn_s_waitcnt((((R / 2) * (VP2_FLIGHT - 1)) & 15) | (7 << 4) | (15 << 8) | ((((R / 2) * (VP2_FLIGHT - 1)) >> 4) << 14));
-                if (lane == 0) s_landed = j - VP2_FLIGHT + 2;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) s_landed = nchunk;
-    } else if (wave == 0) {
-        // ---- CHASER
-        int x = x_first;
-        for (int k = 0; k < nchunk; k++) {
-            int sp = 0;
-            while ((s_landed < k + 1 || s_helped < k - 1) && nap(sp)) { }
-            if (sp >= (1 << 22)) { if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); return; }
-            const int slot = k % VP2_RING;
-            const int relbase = x - 32 - s_base[slot];           // window column of lane 0's column
-            if (relbase < 0 || relbase > VP2_WIN - 64) { if (lane == 0) dev_fail(dev_err, DEVERR_BAND_PREDICTION); return; }      // (cannot happen: VP2_LEAD)
-            const int8_t *win = s_ring + slot * VP2_SLOT + relbase + lane;
-            int e[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) e[r] = win[r * VP2_WIN];
-            int e2[R / 2];
-#pragma unroll
-            for (int i = 0; i < R / 2; i++) e2[i] = e[2 * i] + __builtin_amdgcn_ds_bpermute((lane + e[2 * i]) << 2, e[2 * i + 1]);
-            int o = 32, path = 0;
-            vp1_chase<R / 2>(e2, o, path, std::make_integer_sequence<int, R / 2>{});          // lane i <- window offset at row y_top - 2 i
-            const int y_top = h - 1 - k * R;
-            const int nrows = min(R, y_top);
-            s_path[k & 1][lane] = path;
-            if (lane == 0) s_xstart[slot] = x;
-            int xn;
-            if (nrows == R) xn = x + o - 32;
-            else {
-                // the last chunk may hold fewer real rows than R (the rest re-read row 1): the column after `nrows` steps
-                const int l = nrows >> 1;
-                const int pl = __builtin_amdgcn_readlane(path, l);
-                xn = pl + x - 32;
-                if (nrows & 1) xn += (s_ring + slot * VP2_SLOT)[(2 * l) * VP2_WIN + relbase + pl];
-            }
-            x = __builtin_amdgcn_readfirstlane(xn);
-            if (lane == 0) { if (k + 1 == nchunk) s_xfinal = x; s_xlatest = x; s_chased = k + 1; }
-        }
-        if (nchunk == 0 && lane == 0) s_xfinal = x;
-    } else if (wave == 2) {
-        // ---- HELPER
-        gi32 *seam = c.seam_x;
-        gi32 *logp = c.seam_log + (size_t) log_index * h;
-        int acc = 0;
-        for (int k = 0; k < nchunk; k++) {
-            int sp = 0;
-            while (s_chased < k + 1 && nap(sp)) { }
-            if (sp >= (1 << 22)) { if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); return; }
-            const int slot = k % VP2_RING;
-            const int xs = s_xstart[slot], relbase = xs - 32 - s_base[slot];
-            const int path = lane < R / 2 ? s_path[k & 1][lane] : 32;
-            // the odd rows: lane i looks its even row's displacement up at the column it stands on
-            const int odd = path + (s_ring + slot * VP2_SLOT)[min(lane, R / 2 - 1) * 2 * VP2_WIN + relbase + path];
-            const int y_top = h - 1 - k * R;
-            const int pe = path + xs - 32, po = odd + xs - 32;     // columns at rows y_top - 2 i and y_top - 2 i - 1
-            const int nrows = min(R, y_top);
-            if (2 * lane < nrows) { seam[y_top - 2 * lane] = pe; logp[y_top - 2 * lane] = pe; acc += pe; }
-            if (2 * lane + 1 < nrows) { seam[y_top - 2 * lane - 1] = po; logp[y_top - 2 * lane - 1] = po; acc += po; }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the ring slot and s_path were read
-            if (lane == 0) s_helped = k + 1;
-        }
-        {
-            int sp = 0;
-            while (nchunk > 0 && s_chased < nchunk && nap(sp)) { }
-        }
-        const int x = s_xfinal;
-        if (lane == 0) { seam[0] = x; logp[0] = x; acc += x; }
-        publish_side(c, org, acc, w, h, lane, moved_unit);
-    }
-}
-
 // ---- the instantiations the shim launches (lqr_kernels.h declares them)
 template __global__ void k_vpath1<1>(const DevCarver *, int, int, int, int, int, int);
 template __global__ void k_vpath1<2>(const DevCarver *, int, int, int, int, int, int);

@@ -34,7 +34,7 @@
 // tags = epoch << 10 | (level + 1): nothing is cleared between launches.  Inputs are prefetched two levels ahead for the
 // tile the slot is expected to have then (the same one, or the tile of its residue nearest to the seam); a wrong guess
 // costs a synchronous load, never a result.
-// Grid (P, images), all co-resident (bounded spins, DEVERR_TILE_TIMEOUT as in k_dp_tile_p).
+// Grid: 8 * ceil(images / 8) * P workgroups (see the mapping at the top of the kernel), all co-resident (bounded spins, DEVERR_TILE_TIMEOUT as in k_dp_tile_p).
 // ---------------------------------------------------------------------------
 // [0] images stopped by three active tiles on one slot, [1] synchronous (mispredicted or second-tile) loads, [2] tile-levels
 // processed, [3] slot-levels idle, [4] levels in which a slot had two tiles
@@ -69,7 +69,7 @@ struct LvMask {                       // a set of tiles (uniform over the wave);
 // row dp_row, the others dp_row_g, exactly as k_dp_tile_p's general instantiations do.
 template <bool LR, bool RIG, int DELTA, bool RIGM>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err)
+void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err, int P, int n_img)
 {
     static_assert(DELTA >= 1 && DELTA <= 4 && (RIG || !RIGM), "delta_x 1 .. 4; a rigidity mask only matters with rigidity");
     constexpr int PX = 2, HALO = 32, OWN = 64, HL = 16, R = lv_rows(DELTA, RIGM), TILE = 128;
@@ -85,11 +85,16 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     __shared__ unsigned long long s_A[2];         // the active set of a level (by parity), from the wave that received it to its partner
         const int tid = threadIdx.x, lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P = (int) gridDim.x, slot = (int) blockIdx.x;
+    // A one-dimensional grid of 8 * ceil(n_img / 8) * P workgroups.  Workgroup b is observed to run on XCD b mod 8 (no promise: speed
+    // only, the protocol is placement-independent): the P slots of an image are the workgroups b = xcd + 8 (P g + slot), image = 8 g +
+    // xcd -- all on one XCD, whose L2 then serves the level hand-overs' reads a little sooner (handoff-1to1: cross-XCD +0.1 - 0.3 us)
+    const int b_xcd = (int) blockIdx.x & 7, b_k = (int) blockIdx.x >> 3;
+    const int slot = b_k % P, image = (b_k / P) * 8 + b_xcd;
+    if (image >= n_img) return;
     const int nblk = (h + R - 1) / R;
     const int ntiles = (w + OWN - 1) / OWN;
-    const GCarver c = gview(cs[blockIdx.y]);
-    gu64 *ex_img = (gu64 *) exch + (size_t) blockIdx.y * ((size_t) 4 * LV_PMAX + (size_t) 2 * ntiles * OWN);
+    const GCarver c = gview(cs[image]);
+    gu64 *ex_img = (gu64 *) exch + (size_t) image * ((size_t) 4 * LV_PMAX + (size_t) 2 * ntiles * OWN);
     gu64 *flagw = ex_img;                                    // [2 parities][LV_PMAX slots][2 tiles]
     gu64 *gran = ex_img + 4 * LV_PMAX;                       // [2 parities][ntiles][OWN]
     const float INF = __int_as_float(0x7f800000);
@@ -435,7 +440,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
         if (*(volatile int *) &s_fail) return;    // 1: a time-out, results are invalid anyway; 2: the image stopped at this level (level L - 1 was stored above)
     }
 #ifdef LQR_TIMING
-    if (blockIdx.y == 0 && lane == 0 && blockIdx.x < 16) { ltt[9] = __builtin_readcyclecounter() - ltstart; for (int i = 0; i < 10; i++) g_lv_time[blockIdx.x][q][i] = ltt[i]; }
+    if (image == 0 && lane == 0 && slot < 16) { ltt[9] = __builtin_readcyclecounter() - ltstart; for (int i = 0; i < 10; i++) g_lv_time[slot][q][i] = ltt[i]; }
 #endif
     if (lane == 0) { atomicAdd(&g_lv_stats[2], n_proc); atomicAdd(&g_lv_stats[3], n_idle); if (n_two) atomicAdd(&g_lv_stats[4], n_two); }
     if (lane == 0 && n_sync) atomicAdd(&g_lv_stats[1], n_sync);
@@ -451,7 +456,7 @@ extern "C" int lqrhip_band_levels_stats(unsigned long long *out, int reset)
 }
 
 // ---- the instantiations the shim launches (lqr_kernels.h declares them)
-#define INST_LV(...) template __global__ void k_band_levels<__VA_ARGS__>(DevCarver *, DpK, int, int, int, unsigned long long *, int, int *);
+#define INST_LV(...) template __global__ void k_band_levels<__VA_ARGS__>(DevCarver *, DpK, int, int, int, unsigned long long *, int, int *, int, int);
 #define INST_LV_LR(LRV) INST_LV(LRV, false, 1, false) INST_LV(LRV, true, 1, false) INST_LV(LRV, true, 1, true) \
     INST_LV(LRV, false, 2, false) INST_LV(LRV, true, 2, false) INST_LV(LRV, true, 2, true) \
     INST_LV(LRV, false, 3, false) INST_LV(LRV, true, 3, false) INST_LV(LRV, true, 3, true) \

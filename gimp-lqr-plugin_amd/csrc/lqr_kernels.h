@@ -17,9 +17,6 @@ __global__ __launch_bounds__(256) void k_frozen_catchup(const DevCarver *cs, int
 __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, int w, int h, int stride, int lr, int delta, int log_index, int moved_unit);
 template <int DELTA> __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, int w, int h, int stride, int lr, int log_index, int moved_unit);
 
-__global__ __launch_bounds__(VPATH_THREADS) void k_vpath2(const DevCarver *cs, int w, int h, int stride, int lr, int log_index, int moved_unit, int *dev_err);
-extern "C" size_t lqrhip_vpath2_lds_bytes(void);
-
 // k_carve.hip
 __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h, int stride, int delta, int move_dp);
 
@@ -38,7 +35,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // k_levels.hip
 template <bool LR, bool RIG, int DELTA, bool RIGM>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err);
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err, int P, int n_img);
 
 // k_oneoff.hip
 __global__ __launch_bounds__(256) void k_vs_commit(const DevCarver *cs, int w0, int h0, int wc0, int n_seams, int first_level, int finish);

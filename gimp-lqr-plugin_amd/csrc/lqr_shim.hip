@@ -774,8 +774,6 @@ struct ProfScope {
 
 extern "C" void lqrhip_prof_enable(int on) { g_prof = on; }
 static int g_update_mode = -1;
-static int g_vpath2 = 1;                 // delta_x = 1 backtrack: 1 k_vpath2 (three waves, round 5), 0 k_vpath1<1> (one wave)
-extern "C" void lqrhip_set_vpath2(int on) { g_vpath2 = on != 0; }
 static int g_band_levels = -1;           // k_band_levels: -1 automatic; 0 never; n: n slots per image (lqrhip_set_band_levels)
 // -1: by batch size (g_tiled_update_px); 0: band kernel (k_band_update_tw); 1: tiled full-width update whenever its
 // grid fits; 2: the per-row-barrier band kernel (k_band_update_mw); 3: the generic one-wave band kernel + sweep
@@ -1150,8 +1148,8 @@ static int launch_band_levels(LqrHipBatch *b, const DpK &k, int w, int h, int lr
         b->exch_ntiles = ntiles; b->exch_n = (int) n; b->exch_px = 103;
     }
     const int epoch = 1 + ((b->tile_epoch++) % ((1 << 22) - 2));           // never 0; 22 bits above the 10 bits of level + 1
-    const dim3 grid(P, (unsigned) n);
-#define LAUNCH_LV(LRV, RIGV, DV, RMV) hipLaunchKernelGGL((k_band_levels<LRV, RIGV, DV, RMV>), grid, dim3(128), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
+    const dim3 grid((unsigned) (8 * ((n + 7) / 8) * P));          // the slots of an image on one XCD (k_levels.hip)
+#define LAUNCH_LV(LRV, RIGV, DV, RMV) hipLaunchKernelGGL((k_band_levels<LRV, RIGV, DV, RMV>), grid, dim3(128), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err, P, (int) n)
 #define LAUNCH_LV_LR(RIGV, DV, RMV) do { if (lr) LAUNCH_LV(true, RIGV, DV, RMV); else LAUNCH_LV(false, RIGV, DV, RMV); } while (0)
 #define LAUNCH_LV_D(DV) do { if (!k.use_rig) LAUNCH_LV_LR(false, DV, false); else if (!rigm) LAUNCH_LV_LR(true, DV, false); else LAUNCH_LV_LR(true, DV, true); } while (0)
     if (k.delta == 1) LAUNCH_LV_D(1); else if (k.delta == 2) LAUNCH_LV_D(2); else if (k.delta == 3) LAUNCH_LV_D(3); else LAUNCH_LV_D(4);
@@ -1217,15 +1215,7 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     const int moved_unit = 2 * (4 + (move_dp ? 5 : 0) + (has_rigmask ? 4 : 0));
     {
         ProfScope ps("vpath", b->stream, 0);
-        if (p->delta_x == 1 && g_vpath2) {
-            // round 5: the chase on a wave of its own (loader / chaser / helper waves, LDS ring filled by LDS-DMA)
-            static bool attr_set = false;
-            if (!attr_set) {
-                HIPCK(hipFuncSetAttribute((const void *) k_vpath2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lqrhip_vpath2_lds_bytes()));
-                attr_set = true;
-            }
-            hipLaunchKernelGGL(k_vpath2, dim3(n), dim3(VPATH_THREADS), lqrhip_vpath2_lds_bytes(), b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit, g_dev_err);
-        } else if (p->delta_x == 1)
+        if (p->delta_x == 1)
             hipLaunchKernelGGL(k_vpath1<1>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit);
         else if (p->delta_x == 2)
             hipLaunchKernelGGL(k_vpath1<2>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit);

@@ -190,8 +190,6 @@ int lqrhip_prof_get_union(const char *kernel, double *ms_union);
  * many pixels lie on the side the carve will move, and sums pixels x bytes per pixel (en; m and back pointer unless a full DP
  * follows; the rigidity mask) over images and seams.  The roofline's numerator next to SURVEY 8(d)'s half-row figure. */
 int lqrhip_moved_bytes(unsigned long long *bytes, int reset);
-/* Test / A-B hook: the delta_x = 1 backtrack: 1 (default) k_vpath2 (loader, chaser and helper waves), 0 k_vpath1<1> (one wave) */
-void lqrhip_set_vpath2(int on);
 /* Test hook: slots (workgroups) per image of k_band_levels (-1 automatic, 0 never, n exactly n). */
 void lqrhip_set_band_levels(int slots);
 /* k_band_levels' events since the last reset: [0] images stopped by two active tiles on one slot (the full-width sweep took over),

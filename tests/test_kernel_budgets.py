@@ -31,7 +31,6 @@ BUDGETS = [
     (r"^k_dp_tile_p<2, .*, [1234], (true|false)>$", 272, 0, 0, "general instantiations (delta_x 2..4, rigidity mask): at least one workgroup per SIMD pair, no scratch"),
     (r"^k_vpath1<1>$", 192, 0, 0, "one wave chases, 2 waves per SIMD of the 4-wave workgroup"),
     (r"^k_vpath1<[234]>$", 128, 0, 0, "shorter chunks"),
-    (r"^k_vpath2$", 96, 0, 0, "loader / chaser / helper waves; its LDS ring (112 KB) is what bounds residency, not registers"),
     (r"^k_emap_update<\d, 12>$", 64, 0, 0, "delta_x <= 2: 8 waves per SIMD"),
     (r"^k_dp_tile<", 96, 0, 0, "one wave per tile, 5 per SIMD"),
 ]

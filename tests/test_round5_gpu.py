@@ -153,16 +153,9 @@ def test_band_levels_general_forced_on_single_images(oracle, engine, variant, sl
 
 
 @pytest.mark.parametrize("w,h", [(300, 160), (1400, 700), (40, 9), (2500, 31), (700, 57), (3000, 29)])
-def test_both_backtrack_kernels(oracle, engine, w, h):
-    """delta_x = 1: k_vpath2 (loader / chaser / helper waves, the default) and k_vpath1<1> (one wave) give the oracle's seams --
-    heights around the 28-row chunk (29 = one full chunk, 31, 57 = 2 chunks, 9 = a partial one), rows wider than the 512-column window"""
-    lib = engine.lib
-    lib.lqrhip_set_vpath2.argtypes = [ctypes.c_int]
+def test_backtrack_chunk_boundaries(oracle, engine, w, h):
+    """delta_x = 1 (k_vpath1<1>, 28-row chunks): heights around the chunk size (29 = one full chunk, 31, 57 = two, 9 = a partial one)
+    and rows wider than its 256-column window, against the oracle"""
     img = D.photo_like(w, h, w + 3 * h)
     ref = H.run_case(oracle, img, w - min(30, w // 3), h)
-    try:
-        for on in (1, 0):
-            lib.lqrhip_set_vpath2(on)
-            H.assert_same(ref, H.run_case(engine, img, w - min(30, w // 3), h), "backtrack kernel %d, %dx%d" % (on, w, h))
-    finally:
-        lib.lqrhip_set_vpath2(1)
+    H.assert_same(ref, H.run_case(engine, img, w - min(30, w // 3), h), "backtrack %dx%d" % (w, h))
