@@ -884,12 +884,12 @@ static int launch_dp_tiled(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
 // chain is then ~33 instructions per wave instead of ~58; measured per 4K seam round, 2 vs 4 px per lane:
 // 1 image 0.40 / 0.50 ms, 4: 0.45 / 0.55, 8: 0.58 / 0.62, 12: 0.76 / 0.77), else 4, 0 = not at all.
 // `general`: delta_x = 2 and / or a rigidity mask (with rigidity): those instantiations exist for 2 px per lane only
-static int dp_persistent_px(const LqrHipBatch *b, int w, bool general = false, int delta = 1)
+static int dp_persistent_px(const LqrHipBatch *b, int w, bool general = false, int delta = 1, int count = -1)
 {
     if (b->shared) return 0;
     const int bound = general ? g_dpp_max_wgs_general : g_dpp_max_wgs;
     const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, bound) : bound;
-    const size_t n = b->cs.size();
+    const size_t n = count < 0 ? b->cs.size() : (size_t) count;
     const int hh = b->cs[0]->wk_h;                            // the block index is DPP_BLK_BITS bits of the granule tag
     const int maxblk = (1 << DPP_BLK_BITS) - 1;
     if ((general || g_dpp_px_override != 4) && hh <= maxblk * dpp_rb(2, delta) && (size_t) ((w + dpp_own(2) - 1) / dpp_own(2)) * n <= (size_t) limit) return 2;
@@ -918,17 +918,19 @@ extern "C" int lqrhip_general_batch_limit(int w)
 }
 
 // E5 (UPDATE = false) or the full-width form of E9 (UPDATE = true) as one persistent launch
+// (first, count): a range of the batch's images (E5 only: a general batch too large for one persistent grid is swept group after group)
 template <bool UPDATE>
-static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
+static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int lr, int first = 0, int count = -1)
 {
     LqrHipCarver *c0 = b->cs[0];
-    const size_t n = b->cs.size();
+    const size_t n = count < 0 ? b->cs.size() : (size_t) count;
+    if (UPDATE && count >= 0) return LQRHIP_EARG;
     bool rigm = false;
     for (auto *c : b->cs) rigm |= (c->rig != nullptr);
     rigm = rigm && k.use_rig;                                  // without rigidity the mask multiplies nothing
     const bool general = k.delta != 1 || rigm;
     if (k.delta < 1 || k.delta > 4) return LQRHIP_EARG;
-    const int px = dp_persistent_px(b, w, general, k.delta);
+    const int px = dp_persistent_px(b, w, general, k.delta, count);
     if (!px) return LQRHIP_EARG;
     const int ntiles = (w + dpp_own(px) - 1) / dpp_own(px);
     int rc;
@@ -969,13 +971,13 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
     }
     const int epoch = 1 + ((b->tile_epoch++) % ((1 << (31 - DPP_BLK_BITS)) - 2));          // never 0; above the block index in the 32-bit tag
     const dim3 grid(ntiles, (unsigned) n);
-#define LAUNCH_TILE(PXV, LRV, RIGV) hipLaunchKernelGGL((k_dp_tile_p<PXV, LRV, RIGV, UPDATE>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
+#define LAUNCH_TILE(PXV, LRV, RIGV) hipLaunchKernelGGL((k_dp_tile_p<PXV, LRV, RIGV, UPDATE>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc + first, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
 #define LAUNCH_TILE_PX(PXV)                                                                 \
     do {                                                                                    \
         if (lr) { if (k.use_rig) LAUNCH_TILE(PXV, true, true); else LAUNCH_TILE(PXV, true, false); }     \
         else { if (k.use_rig) LAUNCH_TILE(PXV, false, true); else LAUNCH_TILE(PXV, false, false); }      \
     } while (0)
-#define LAUNCH_TILE_G(LRV, RIGV, DV, RMV) hipLaunchKernelGGL((k_dp_tile_p<2, LRV, RIGV, UPDATE, DV, RMV>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
+#define LAUNCH_TILE_G(LRV, RIGV, DV, RMV) hipLaunchKernelGGL((k_dp_tile_p<2, LRV, RIGV, UPDATE, DV, RMV>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc + first, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
 #define LAUNCH_TILE_G_LR(RIGV, DV, RMV) do { if (lr) LAUNCH_TILE_G(true, RIGV, DV, RMV); else LAUNCH_TILE_G(false, RIGV, DV, RMV); } while (0)
     if (general) {
 #define LAUNCH_TILE_G_D(DV) do { if (!k.use_rig) LAUNCH_TILE_G_LR(false, DV, false); else if (!rigm) LAUNCH_TILE_G_LR(true, DV, false); else LAUNCH_TILE_G_LR(true, DV, true); } while (0)
@@ -1006,6 +1008,20 @@ static int launch_dp(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
         rigm = rigm && k.use_rig;
         if (k.delta == 1 && !rigm) return dp_persistent_ok(b, w) ? launch_dp_persistent<false>(b, k, w, h, lr) : launch_dp_tiled(b, k, w, h, lr);
         if (k.delta >= 1 && k.delta <= 4 && dp_persistent_px(b, w, true, k.delta)) return launch_dp_persistent<false>(b, k, w, h, lr);
+        // round 5: a general batch too large for one persistent grid (it runs its incremental updates on k_band_levels): the full DP
+        // group after group of as many images as fit, instead of one 1024-thread workgroup per image (k_dp_sweep: 4 - 8 ms per sweep
+        // of 16 x 4K against 2 x 0.5)
+        if (k.delta >= 1 && k.delta <= 4 && !b->shared) {
+            const int total = (int) b->cs.size();
+            int per = total;
+            while (per > 1 && !dp_persistent_px(b, w, true, k.delta, per)) per = (per + 1) / 2;
+            if (dp_persistent_px(b, w, true, k.delta, per)) {
+                int rc;
+                for (int first = 0; first < total; first += per)
+                    if ((rc = launch_dp_persistent<false>(b, k, w, h, lr, first, std::min(per, total - first)))) return rc;
+                return 0;
+            }
+        }
     }
     int pxt = (w + DP_THREADS - 1) / DP_THREADS;
     size_t lds = (size_t) 2 * ((w + 3) & ~3) * sizeof(float);
