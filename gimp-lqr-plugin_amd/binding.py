@@ -19,7 +19,8 @@ except Exception:      # the engine does not need torch
     torch = None
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ENGINE_LIB = os.path.join(HERE, "liblqr-hip.so")
+# (LQR_HIP_LIB: another build of the same library, for A/B runs of bench.py and the tests)
+ENGINE_LIB = os.environ.get("LQR_HIP_LIB") or os.path.join(HERE, "liblqr-hip.so")
 
 LQR_ERROR, LQR_OK, LQR_NOMEM, LQR_USRCANCEL = 0, 1, 2, 3
 LQR_RES_ORDER_HOR, LQR_RES_ORDER_VERT = 0, 1

@@ -799,6 +799,12 @@ __device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const D
 template <int NW, bool LR, bool RIG>
 __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs, DpK p, int w, int h, int stride, int *dev_err)
 {
+    // Claim the whole register file of the SIMDs this workgroup sits on (2 waves x 256 VGPRs): no wave of a sibling stream's kernel is
+    // placed on this CU while the band is walked.  Measured at 64 x 4K on one box, alternating builds: 500.0 / 501.1 k against 489.8 /
+    // 493.6 k Mseams*px/s (+1.8 %) -- NOT through this kernel's own time (630 us either way: what stretches it from 466 us alone is the
+    // loaded memory system, not its CU's neighbours) but through the kernels that no longer land beside it (k_emap_update 50 -> 32 us,
+    // k_dp_tile 2.1 -> 1.5 ms per sweep).
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
     band_update_tw_body<NW, LR, RIG>(cs[blockIdx.x], p, w, h, stride, dev_err);
 }
 

@@ -1,0 +1,9 @@
+#!/bin/bash
+mkdir -p gpurun_out/job16; O=gpurun_out/job16
+P='import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d["value"]), d["ms_per_step"], {k: round(v["ms"]/v["launches"]*1000) for k,v in d["kernels_ms"].items()})'
+run() { echo -n "lib=${LQR_HIP_LIB##*/} $* : "; timeout 600 python bench.py --steps 6 --warmup 2 --no-configs --no-cpu-baseline --no-phases --kernel-times "$@" 2>>$O/bench.err | python3 -c "$P"; }
+for i in 1 2; do
+unset LQR_HIP_LIB; run --images-per-gpu 64
+export LQR_HIP_LIB=$PWD/gimp-lqr-plugin_amd/liblqr-hip-x.so; run --images-per-gpu 64
+done
