@@ -537,6 +537,15 @@ constexpr int TW_OWN = 256 - 2 * TW_R;       // own columns per slot
 // and that path is this kernel's bound.
 constexpr int TW_LANE_MARGIN = 2 * TW_R + 8;
 
+#ifdef LQR_TIMING
+// per wave of image 0's workgroup: cycles [0] waiting for the prefetched batch (landed), [1] the batch (rows, hand-over, or idling), [2] barrier,
+// [3] between barrier and issue, [4] issue, [5] whole kernel
+__device__ unsigned long long g_tw_time[8][8];
+#define TWT(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); twt[i] += t__ - twprev; twprev = t__; } while (0)
+extern "C" int lqrhip_band_tw_timing(unsigned long long *out) { (void) hipDeviceSynchronize(); return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tw_time), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1; }
+#else
+#define TWT(i) do { } while (0)
+#endif
 template <int NW, bool LR, bool RIG>
 __device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const DpK &p, int w, int h, int stride, int *dev_err)
 {
@@ -612,6 +621,11 @@ __device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const D
         for (int r = 0; r < R; r++) asm volatile("" ::"v"(q_e[r]), "v"(q_mo[r]), "v"(q_lo[r]));
     };
 
+#ifdef LQR_TIMING
+    unsigned long long twt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long twprev = __builtin_readcyclecounter();
+    const unsigned long long twstart = twprev;
+#endif
     int y = 1, ovf = h, kpar = 0;
     bool loads_full = true;                  // does this wave's staged batch hold all rows (or only the hand-over row)?
     bool lane_staged = true;                 // ... for this lane (a slot stages only the lanes near the changes)
@@ -679,6 +693,7 @@ __device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const D
             // this wave's batch landed an iteration ago; saying so here keeps the compiler from counting
             // vmcnt down through the rows, which would make the later rows wait for the earlier rows' stores
             landed();
+            TWT(0);
             // GUARD: the image ends inside the batch (last batch of a sweep only); MASK: the slot reaches over
             // the image's left or right border
             auto rows = [&](auto guard, auto mask) {
@@ -753,9 +768,12 @@ __device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const D
             }
         } else {
             landed();
+            TWT(0);
         }
         // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. the prefetch
+        TWT(1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        TWT(2);
         {
             int a = 1 << 30, b = -1;
 #pragma unroll
@@ -785,7 +803,9 @@ __device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const D
             // already contain the R columns of the slot test)
             const int xl = B + OWN * slot - R + 4 * lane;
             lane_staged = issue_full && (lane_all || (xl + 3 >= plo_l && xl <= phi_l));
+            TWT(3);
             issue(y_issue, lane_staged);
+            TWT(4);
             loads_full = issue_full;
         }
         if (just_rebased) {
@@ -794,6 +814,9 @@ __device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const D
         }
     }
     if (tid == 0) c.flags[FLAG_OVF_ROW] = ovf;
+#ifdef LQR_TIMING
+    if (blockIdx.x == 0 && lane == 0) { twt[5] = __builtin_readcyclecounter() - twstart; for (int i = 0; i < 8; i++) g_tw_time[wv][i] = twt[i]; }
+#endif
 }
 
 template <int NW, bool LR, bool RIG>
