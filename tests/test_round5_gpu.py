@@ -152,45 +152,10 @@ def test_band_levels_general_forced_on_single_images(oracle, engine, variant, sl
         lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_levels(-1)
 
 
-@pytest.mark.parametrize("w,h", [(300, 160), (1400, 700), (40, 9), (2500, 31), (700, 57), (3000, 29)])
+@pytest.mark.parametrize("w,h", [(300, 160), (1400, 700), (40, 9), (2500, 31), (700, 57), (3000, 29), (64, 1), (900, 2), (3840, 300)])
 def test_backtrack_chunk_boundaries(oracle, engine, w, h):
-    """delta_x = 1 (k_vpath1<1>, 28-row chunks): heights around the chunk size (29 = one full chunk, 31, 57 = two, 9 = a partial one)
-    and rows wider than its 256-column window, against the oracle"""
+    """delta_x = 1 (k_vpath1<1>, 28-row chunks): heights around the chunk size (29 = one full chunk, 31, 57 = two, 9 = a partial one,
+    1 and 2 = none / one row) and rows wider than its 256-column window, against the oracle"""
     img = D.photo_like(w, h, w + 3 * h)
-    ref = H.run_case(oracle, img, w - min(30, w // 3), h)
-    H.assert_same(ref, H.run_case(engine, img, w - min(30, w // 3), h), "backtrack %dx%d" % (w, h))
-
-
-@pytest.mark.parametrize("variant", ["delta2", "rigmask"])
-def test_general_full_dp_group_after_group(oracle, engine, variant):
-    """a general batch whose tiles do not fit one persistent grid (forced: room for 3 images' tiles) runs its full DPs on the tiled
-    kernel group after group (3 + 3 + 3) and its incremental updates on k_band_levels (3 slots here: mostly the sweep takes over)"""
-    lib = engine.lib
-    for f in ("lqrhip_set_dp_persistent_limit", "lqrhip_set_update_mode", "lqrhip_set_band_levels"):
-        getattr(lib, f).argtypes = [ctypes.c_int]
-    w, h, n = 520, 150, 9
-    v = dict(GENERAL[variant])
-    rigm = D.top_half_mask(w, h) if v.pop("rigmask", False) else None
-    imgs = [D.photo_like(w, h, 8100 + i) for i in range(n)]
-    tiles = (w + 63) // 64
-    lib.lqrhip_set_dp_persistent_limit(3 * tiles); lib.lqrhip_set_update_mode(5); lib.lqrhip_set_band_levels(3)
-    try:
-        cs = []
-        for im in imgs:
-            c = L.Carver(engine, im, delta_x=v.get("delta_x", 1), rigidity=(3 * v.get("rigidity", 0.0) if rigm is not None else v.get("rigidity", 0.0)))
-            if rigm is not None:
-                assert c.rigmask_add(rigm) == L.LQR_OK
-            cs.append(c.configure())
-        lib.lqrhip_prof_reset(); lib.lqrhip_prof_enable(1)
-        assert L.resize_batch(engine, cs, w - 33, h - 9) == L.LQR_OK
-        lib.lqrhip_prof_enable(0)
-        assert prof_launches(lib, "band_levels") > 0
-        for c, im in zip(cs, imgs):
-            ref = H.run_case(oracle, im, w - 33, h - 9, rigmask=rigm, **v)
-            assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"])
-            assert np.array_equal(c.read_image(), ref["image"])
-        for c in cs:
-            c.destroy()
-    finally:
-        lib.lqrhip_prof_enable(0)
-        lib.lqrhip_set_dp_persistent_limit(-1); lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_levels(-1)
+    nw = w - min(30, w // 3)
+    H.assert_same(H.run_case(oracle, img, nw, h), H.run_case(engine, img, nw, h), "backtrack %dx%d" % (w, h))
