@@ -66,7 +66,19 @@ while budget.more(n):
         for c in cs:
             c.destroy()
     except Exception as ex:
-        fails.record(n, what, ex)
+        # is it a state of the process or a passing event?  the same batch once more
+        again = "not rerun"
+        try:
+            cs2 = [H.init_carver(e, im, w + dw, h + dh, **kw, **mk)[0] for im in imgs]
+            ok2 = L.resize_batch(e, cs2, w + dw, h + dh) == L.LQR_OK
+            for im, c in zip(imgs, cs2):
+                ref = H.run_case(o, im, w + dw, h + dh, **kw, **mk)
+                ok2 = ok2 and np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"]) and np.array_equal(c.read_image(), ref["image"])
+                c.destroy()
+            again = "rerun of the same batch: " + ("ok" if ok2 else "differs again")
+        except Exception as ex2:
+            again = "rerun raised %s" % str(ex2)[:100]
+        fails.record(n, what + " [" + again + "]", ex)
     n += 1
 lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_sub_batches(0)
 FC.summary("batch fuzz", n, budget, fails, seed)

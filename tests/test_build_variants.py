@@ -51,7 +51,20 @@ def test_parity_without_the_scheduler_option(plain_build, oracle, mode):
     try:
         for what, make, nw, nh, kw in CASES:
             img = make()
-            H.assert_same(H.run_case(oracle, img, nw, nh, **kw), H.run_case(plain_build, img, nw, nh, **kw), "%s, update mode %d" % (what, mode))
+            ref = H.run_case(oracle, img, nw, nh, **kw)
+            try:
+                H.assert_same(ref, H.run_case(plain_build, img, nw, nh, **kw), "%s, update mode %d" % (what, mode))
+            except AssertionError as ex:
+                # (round 5: this test failed ONCE in a full-suite run and never again -- DESIGN.md 8.  Should it happen again: is the
+                # mismatch a state of the process, or a passing event?  The same case three more times, and the engine's last error.)
+                again = []
+                for _ in range(3):
+                    try:
+                        H.assert_same(ref, H.run_case(plain_build, img, nw, nh, **kw), "again")
+                        again.append("ok")
+                    except AssertionError as ex2:
+                        again.append(str(ex2)[:120])
+                raise AssertionError("%s\n  the same case three more times: %s\n  last error: %r" % (ex, again, plain_build.lib.lqrhip_last_error()))
     finally:
         plain_build.lib.lqrhip_set_update_mode(-1)
 
