@@ -651,7 +651,7 @@ extern "C" int lqrhip_mask_add(LqrHipCarver *c, const unsigned char *mask, int c
 // number of streams; the default is automatic (lqrhip_sub_batches below).  DESIGN.md 4.11.
 static int g_sub_batches = 0;           // 0: automatic (below)
 extern "C" void lqrhip_set_sub_batches(int n) { g_sub_batches = n > 0 ? n : 0; }
-// Streams a lock-step group of n carvers is split over.  Automatic: 4 for groups of 32 and more WHEN the process has the
+// Streams a lock-step group of n carvers is split over.  Automatic: 4 for groups of 49 and more, 2 for 32 to 48 (round 5) WHEN the process has the
 // hardware queues for them -- the HIP runtime's GPU_MAX_HW_QUEUES (default 4, read when HIP initialises, shared with every
 // other stream of the process) must be 8 or more; with fewer, streams share queues and the split is 30 % slower than
 // one stream, so it is not made.
@@ -660,7 +660,9 @@ extern "C" int lqrhip_sub_batches(int n)
     int nb = g_sub_batches;
     if (nb == 0) {
         const char *q = getenv("GPU_MAX_HW_QUEUES");
-        nb = (n >= 32 && q && atoi(q) >= 8) ? 4 : 1;
+        // 4 streams for the groups that run k_band_update_tw (49 images and more), 2 for the groups of 32 to 48 that run k_band_levels
+        // (round 5, one box, Mseams*px/s with 2 / 4 streams: 32 images 360 / 352 k, 48 images 432 / 404 k)
+        nb = (q && atoi(q) >= 8) ? (n >= 49 ? 4 : n >= 32 ? 2 : 1) : 1;
     }
     return n >= 2 * nb ? nb : 1;
 }
@@ -1247,6 +1249,8 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
         // algorithmic bytes of one carve launch: read + write of one 4-byte
         // plane over the half of each row right of the seam = 8 B * w*h/2 per image
         ProfScope ps("carve", b->stream, 4.0 * (double) w * h * n);
+        // (a grid of a half, a quarter, an eighth of the rows, the kernel striding over the rest, measured at 64 x 4K in round 5: 508 / 504 / 490 k
+        // against 488 - 501 k: inside the run-to-run spread; not adopted)
         hipLaunchKernelGGL(k_carve, dim3((h + 3) / 4, n), dim3(256), 0, b->stream, b->d_desc, w, h, stride, p->delta_x, move_dp);
     }
     if (wnew <= 1) {            // liblqr's finish_vsmap case: nothing left to update

@@ -99,7 +99,7 @@ def test_general_tiled_batch(oracle, engine):
 
 
 def test_sub_batch_streams_are_the_default_for_large_groups(oracle, engine):
-    """lqrhip_sub_batches: 4 streams for 32 carvers and more when the process says it has the hardware queues
+    """lqrhip_sub_batches: 4 streams for 49 carvers and more, 2 for 32 to 48 (round 5) when the process says it has the hardware queues
     (GPU_MAX_HW_QUEUES >= 8), else one; then a 34-image group through that default path, image by image
     against the oracle.  (The variable only steers the engine's choice here: HIP read it, or its absence, long ago.  It is
     changed in the C environment -- where the library set it when it was loaded, tests/test_queue_env.py -- not in
@@ -117,8 +117,8 @@ def test_sub_batch_streams_are_the_default_for_large_groups(oracle, engine):
         libc.setenv(b"GPU_MAX_HW_QUEUES", b"4", 1)
         assert lib.lqrhip_sub_batches(64) == 1
         libc.setenv(b"GPU_MAX_HW_QUEUES", b"8", 1)
-        assert [lib.lqrhip_sub_batches(n) for n in (1, 31, 32, 64)] == [1, 1, 4, 4]
-        # the 34-image group on 4 streams, as the bench runs it
+        assert [lib.lqrhip_sub_batches(n) for n in (1, 31, 32, 48, 49, 64)] == [1, 1, 2, 2, 4, 4]
+        # a forced count, then the 34-image group on the engine's own choice (2 streams, k_band_levels)
         lib.lqrhip_set_sub_batches(2)
         assert [lib.lqrhip_sub_batches(n) for n in (3, 4, 64)] == [1, 2, 2]
         lib.lqrhip_set_sub_batches(0)
