@@ -31,6 +31,12 @@
 //     in place is safe (a slot's halo columns are its neighbours' own columns); inputs of later levels are rows nobody
 //     writes before those levels' own barriers.
 //   * no reserve tiles, no requests, no edge watches, no inactive forwarding: the only spin is the level barrier.
+//   * every word and granule is published TWICE: the write-through copy above (visible from every XCD: the protocol rests on it
+//     alone) and a "near" copy at + near_off written with a plain store, which stays in the writer's L2.  An image's slots are
+//     observed to sit on ONE XCD (the grid mapping below), whose L2 then hands the near copy over without the trip to memory
+//     and back; the poll reads the near copy three times out of four and the write-through copy the fourth, so a placement
+//     that puts the slots on different XCDs only polls slower.  A stale near line can never be taken for a fresh one: tags.
+//     (+3 % at 8 and 16 images, +4 % at 48: DESIGN.md 4.16; lqrhip_band_levels_debug(4) turns the near copy off.)
 // tags = epoch << 10 | (level + 1): nothing is cleared between launches.  Inputs are prefetched two levels ahead for the
 // tile the slot is expected to have then (the same one, or the tile of its residue nearest to the seam); a wrong guess
 // costs a synchronous load, never a result.
@@ -48,7 +54,7 @@ extern "C" int lqrhip_band_levels_timing(unsigned long long *out) { (void) hipDe
 #else
 #define LTT(i) do { } while (0)
 #endif
-__device__ int g_lv_dbg;               // experiment switches (lqrhip_band_levels_debug): 1 no speculative granule fetch, 2 sleep longer in the poll
+__device__ int g_lv_dbg;               // experiment switches (lqrhip_band_levels_debug): 1 no speculative granule fetch, 2 sleep longer in the poll, 4 no near copy, 8 an image's slots on different XCDs
 
 // a value every lane holds (read from LDS), as a scalar
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v)
@@ -88,13 +94,17 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     // A one-dimensional grid of 8 * ceil(n_img / 8) * P workgroups.  Workgroup b is observed to run on XCD b mod 8 (no promise: speed
     // only, the protocol is placement-independent): the P slots of an image are the workgroups b = xcd + 8 (P g + slot), image = 8 g +
     // xcd -- all on one XCD, whose L2 then serves the level hand-overs' reads a little sooner (handoff-1to1: cross-XCD +0.1 - 0.3 us)
+    const int dbg = __builtin_amdgcn_readfirstlane(g_lv_dbg);
     const int b_xcd = (int) blockIdx.x & 7, b_k = (int) blockIdx.x >> 3;
-    const int slot = b_k % P, image = (b_k / P) * 8 + b_xcd;
+    // (debug switch 8: consecutive workgroups = the slots of one image, i.e. on DIFFERENT XCDs -- the placement the near copies do
+    // not serve; the tests run it to show that nothing but speed depends on where the slots sit)
+    const int slot = (dbg & 8) ? (int) blockIdx.x % P : b_k % P, image = (dbg & 8) ? (int) blockIdx.x / P : (b_k / P) * 8 + b_xcd;
     if (image >= n_img) return;
     const int nblk = (h + R - 1) / R;
     const int ntiles = (w + OWN - 1) / OWN;
     const GCarver c = gview(cs[image]);
-    gu64 *ex_img = (gu64 *) exch + (size_t) image * ((size_t) 4 * LV_PMAX + (size_t) 2 * ntiles * OWN);
+    const size_t near_off = (size_t) 4 * LV_PMAX + (size_t) 2 * ntiles * OWN;      // the near copies (see the header)
+    gu64 *ex_img = (gu64 *) exch + (size_t) image * 2 * near_off;
     gu64 *flagw = ex_img;                                    // [2 parities][LV_PMAX slots][2 tiles]
     gu64 *gran = ex_img + 4 * LV_PMAX;                       // [2 parities][ntiles][OWN]
     const float INF = __int_as_float(0x7f800000);
@@ -102,7 +112,6 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     float rg[2 * DELTA + 1];
 #pragma unroll
     for (int i = 0; i < 2 * DELTA + 1; i++) rg[i] = p.rigmap[i];
-    const int dbg = __builtin_amdgcn_readfirstlane(g_lv_dbg);
     // which lanes of the barrier poll hold the words of the slot of tile `lane`, of tile `lane + 1`, of tile `lane - 1`
     const int ix_own = 2 * (lane % P), ix_right = 2 * ((lane + 1) % P), ix_left = 2 * ((lane + P - 1) % P);
 
@@ -266,10 +275,11 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
         gu64 *gsrc = gran + ((size_t) ((L - 1) & 1) * ntiles + (need_g ? owner_of(spec_t) : 0)) * OWN + (need_g ? owner_col : 0);
         int sp = 0;
         while (true) {
-            fw = __hip_atomic_load(fsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const size_t off = (!(dbg & 4) && (sp & 3) != 3) ? near_off : 0;
+            fw = __hip_atomic_load(fsrc + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (spec_t >= 0) {
 #pragma unroll
-                for (int k = 0; k < PX; k++) g[k] = __hip_atomic_load(gsrc + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int k = 0; k < PX; k++) g[k] = __hip_atomic_load(gsrc + off + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             const bool okf = __all(lane >= 2 * P || (unsigned) (fw >> 32) == want);
             bool okg = true;
@@ -292,8 +302,9 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
             const unsigned want = ((unsigned) epoch << 10) | (unsigned) L;
             int sp = 0;
             while (true) {
+                const size_t off = (!(dbg & 4) && (sp & 3) != 3) ? near_off : 0;
 #pragma unroll
-                for (int k = 0; k < PX; k++) g[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int k = 0; k < PX; k++) g[k] = __hip_atomic_load(src + off + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 bool ok = true;
 #pragma unroll
                 for (int k = 0; k < PX; k++) ok &= (unsigned) (g[k] >> 32) == want;
@@ -375,7 +386,9 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
         if (passed && *(volatile int *) &s_fail == 0) t = my_tile(A, mine ? 0 : 1);
         if (!mine && t < 0 && passed && lane == 0 && *(volatile int *) &s_fail == 0) {       // no second tile: said right away
             const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 10) | (unsigned) (L + 1)) << 32;
-            __hip_atomic_store(flagw + (size_t) (L & 1) * 2 * LV_PMAX + 2 * slot + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gu64 *fdst = flagw + (size_t) (L & 1) * 2 * LV_PMAX + 2 * slot + 1;
+            if (!(dbg & 4)) __hip_atomic_store(fdst + near_off, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(fdst, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // ---- LOAD: the tile of this level if it is not what was prefetched (synchronous), else -- the other wave -- the prefetch for
         // its next level: the tile this slot is expected to have then
@@ -423,7 +436,10 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
                 gu64 *dst = gran + ((size_t) (L & 1) * ntiles + t) * OWN + PX * (lane - HL);
                 const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 10) | (unsigned) (L + 1)) << 32;
 #pragma unroll
-                for (int k = 0; k < PX; k++) __hip_atomic_store(dst + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int k = 0; k < PX; k++) {
+                    if (!(dbg & 4)) __hip_atomic_store(dst + near_off + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(dst + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             const bool chg = own_lane && (acc_l0 | acc_l1) != 0;
             const bool any_o = __any(chg), any_l = __any(chg && lane < 32), any_r = __any(chg && lane >= 32);
@@ -432,7 +448,9 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
         // the slot's word for this wave's tile of the level (its granules were issued above; a reader checks their tags itself)
         if (lane == 0 && (t >= 0 || mine) && *(volatile int *) &s_fail == 0) {
             const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 10) | (unsigned) (L + 1)) << 32;
-            __hip_atomic_store(flagw + (size_t) (L & 1) * 2 * LV_PMAX + 2 * slot + (mine ? 0 : 1), tag | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gu64 *fdst = flagw + (size_t) (L & 1) * 2 * LV_PMAX + 2 * slot + (mine ? 0 : 1);
+            if (!(dbg & 4)) __hip_atomic_store(fdst + near_off, tag | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(fdst, tag | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         LTT(7);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

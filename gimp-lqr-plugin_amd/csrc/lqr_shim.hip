@@ -1152,7 +1152,7 @@ static int launch_band_levels(LqrHipBatch *b, const DpK &k, int w, int h, int lr
     const size_t n = b->cs.size();
     int rc;
     const int ntiles = (w + 63) / 64;
-    const size_t need_elems = ((size_t) 4 * LV_PMAX + (size_t) 2 * ntiles * 64) * n;
+    const size_t need_elems = 2 * ((size_t) 4 * LV_PMAX + (size_t) 2 * ntiles * 64) * n;    // (two copies of each word: k_levels.hip, near_off)
     if (b->exch_elems < need_elems) {
         HIPCK(hipStreamSynchronize(b->stream));
         dfree(b->exch);

@@ -10,6 +10,8 @@ for f in ("lqrhip_set_update_mode", "lqrhip_set_band_levels", "lqrhip_set_sub_ba
 lib.lqrhip_band_levels_stats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 def stats():
     st = (C.c_ulonglong * 8)(); lib.lqrhip_band_levels_stats(st, 1); return [int(x) for x in st[:4]]
+if os.environ.get("LQR_LV_DBG"):
+    lib.lqrhip_band_levels_debug.argtypes = [C.c_int]; lib.lqrhip_band_levels_debug(int(os.environ["LQR_LV_DBG"]))
 bad = 0
 cases = [("photo 300x160", D.photo_like(300, 160, 73), 260, 160, {}),
          ("noise 1200x200", D.noise(1200, 200, 5), 1150, 200, dict(switch_freq=0)),

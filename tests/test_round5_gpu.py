@@ -5,6 +5,8 @@
   general instantiations such a group runs on them (or on the full-width tiled kernels), never on k_band_update.
 * k_band_levels with delta_x 2 .. 4 and rigidity masks: lock-step batches of 9 images per variant against the oracle, and whole
   resizes in both directions with the kernel forced (update mode 5) on single images.
+* k_band_levels' two copies of every hand-over word: with the near (L2-resident) copy off, and with an image's slots placed on
+  different XCDs (where the near copy is never seen and every fourth poll, of the write-through copy, carries the protocol).
 * lqrhip_moved_bytes: the bytes the carves had to move, as k_vpath* counts them, against a count made from the seam maps.
 """
 import ctypes
@@ -150,6 +152,40 @@ def test_band_levels_general_forced_on_single_images(oracle, engine, variant, sl
         H.assert_same(a, b, "levels general %s, %d slots" % (variant, slots))
     finally:
         lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_levels(-1)
+
+
+@pytest.mark.parametrize("dbg", [4, 8, 12])
+def test_band_levels_handover_copies_and_slot_placement(oracle, engine, dbg):
+    """4: no near copy; 8: the slots of an image on different XCDs (near copies written, never seen); 12: both -- a lock-step
+    group of 9 and a forced single image against the oracle.  Nothing but speed may depend on where the slots sit."""
+    lib = engine.lib
+    lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]
+    lib.lqrhip_set_band_levels.argtypes = [ctypes.c_int]
+    lib.lqrhip_band_levels_debug.argtypes = [ctypes.c_int]
+    w, h, n = 1100, 300, 9
+    imgs = [D.photo_like(w, h, 9100 + i) if i % 2 else D.noise(w, h, 9100 + i) for i in range(n)]
+    lib.lqrhip_band_levels_debug(dbg)
+    try:
+        cs = [L.Carver(engine, im).configure() for im in imgs]
+        lib.lqrhip_prof_reset(); lib.lqrhip_prof_enable(1)
+        try:
+            assert L.resize_batch(engine, cs, w - 60, h - 20) == L.LQR_OK
+        finally:
+            lib.lqrhip_prof_enable(0)
+        assert prof_launches(lib, "band_levels") > 0
+        for c, im in zip(cs, imgs):
+            ref = H.run_case(oracle, im, w - 60, h - 20)
+            assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"])
+            assert np.array_equal(c.read_image(), ref["image"])
+        for c in cs:
+            c.destroy()
+        lib.lqrhip_set_update_mode(5); lib.lqrhip_set_band_levels(5)
+        img = D.photo_like(1400, 420, 31)
+        a = H.run_case(oracle, img, 1330, 400, output_seams=True)
+        b = H.run_case(engine, img, 1330, 400, output_seams=True)
+        H.assert_same(a, b, "levels, debug %d" % dbg)
+    finally:
+        lib.lqrhip_band_levels_debug(0); lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_levels(-1)
 
 
 @pytest.mark.parametrize("w,h", [(300, 160), (1400, 700), (40, 9), (2500, 31), (700, 57), (3000, 29), (64, 1), (900, 2), (3840, 300)])
