@@ -288,6 +288,9 @@ def main():
     if os.environ.get("LQR_LV_DBG"):
         lib.lqrhip_band_levels_debug.argtypes = [C.c_int]
         lib.lqrhip_band_levels_debug(int(os.environ["LQR_LV_DBG"]))
+    if os.environ.get("LQR_DPP_DBG"):
+        lib.lqrhip_dp_tile_debug.argtypes = [C.c_int]
+        lib.lqrhip_dp_tile_debug(int(os.environ["LQR_DPP_DBG"]))
     if args.dp_px:
         lib.lqrhip_set_dp_persistent_px.argtypes = [C.c_int]
         lib.lqrhip_set_dp_persistent_px(args.dp_px)

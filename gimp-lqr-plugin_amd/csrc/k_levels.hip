@@ -49,7 +49,7 @@ __device__ unsigned long long g_lv_stats[8];
 // per slot of image 0 and wave: cycles in [0] barrier poll (wait_level), [1] active set + tile choice, [2] waiting for the partner's poll,
 // [3] stores, [4] loads (issue; synchronous ones include the wait), [5] row above, [6] the 32 rows, [7] publish, [8] LDS barrier, [9] whole kernel
 __device__ unsigned long long g_lv_time[16][2][10];
-#define LTT(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); ltt[i] += t__ - ltprev; ltprev = t__; } while (0)
+#define LTT(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t__ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); ltt[i] += t__ - ltprev; ltprev = t__; } while (0)
 extern "C" int lqrhip_band_levels_timing(unsigned long long *out) { (void) hipDeviceSynchronize(); return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lv_time), sizeof(unsigned long long) * 320) == hipSuccess ? 0 : -1; }
 #else
 #define LTT(i) do { } while (0)
@@ -87,7 +87,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     typedef GLOBAL_AS unsigned long long gu64;
     __shared__ int s_tlo[LV_MAX_LEVELS], s_thi[LV_MAX_LEVELS];      // per level: columns the carve touched on its rows
     __shared__ int s_fail;                        // 1: a spin timed out (results invalid), 2: the image stopped (collision): leave at the next barrier
-    __shared__ volatile int s_polled;             // last level whose barrier this workgroup has passed
+    __shared__ int s_polled;                      // last level whose barrier this workgroup has passed
     __shared__ unsigned long long s_A[2];         // the active set of a level (by parity), from the wave that received it to its partner
         const int tid = threadIdx.x, lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,7 +117,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
 
     // ---- carve-touched columns per level (as k_band_tiles / k_band_update_tw)
     for (int i = tid; i < nblk; i += 128) { s_tlo[i] = 1 << 30; s_thi[i] = -1; }
-    if (tid == 0) { s_fail = 0; s_polled = -1; }
+    if (tid == 0) { s_fail = 0; s_polled = -1; }        // (flags: through LDS_FLAG once the waves run apart)
     __syncthreads();
     for (int y = tid; y < h; y += 128) {
         const int v0 = c.seam_x[y], vm = c.seam_x[max(y - 1, 0)], vp = c.seam_x[min(y + 1, h - 1)];
@@ -345,7 +345,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
                 const int spec_t = (hold_L < 0 && cur_full && cur_L == L && L < nblk && !(dbg & 1)) ? cur_t : -1;
                 const int wl_rc = wait_level(L, spec_t, A_prev, fw, g);
                 LTT(0);
-                if (wl_rc) { s_fail = 1; passed = false; }
+                if (wl_rc) { LDS_FLAG(s_fail) = 1; passed = false; }
                 else if (L < nblk) {
                     // tile `lane` is active in level L iff its own slot's words say "own pixels changed", or the tile to its right says
                     // "left 32 changed", or the tile to its left "right 32 changed" (six words, fetched across the lanes; one ballot)
@@ -364,11 +364,11 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
                     have_g = spec_t >= 0;
                 }
             }
-            if (lane == 0) { s_A[L & 1] = A.lo; if (passed) s_polled = L; }        // level L - 1 may be stored now (not after a time-out)
+            if (lane == 0) { s_A[L & 1] = A.lo; if (passed) LDS_FLAG(s_polled) = L; }        // level L - 1 may be stored now (not after a time-out)
         } else {
             int spins = 0;
-            while (s_polled < L && *(volatile int *) &s_fail != 1 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
-            passed = s_polled >= L;
+            while (LDS_FLAG(s_polled) < L && LDS_FLAG(s_fail) != 1 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
+            passed = LDS_FLAG(s_polled) >= L;
             if (passed) A.lo = uni64(s_A[L & 1]);
             LTT(2);
         }
@@ -380,11 +380,11 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
         if (mine && passed && any_collision(A)) {
             // three active tiles on one slot: the image stops here (every slot decides the same); rows from 32 L on are the sweep's
             if (slot == 0 && lane == 0) { __hip_atomic_fetch_min(c.flags + FLAG_OVF_ROW, L * R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicAdd(&g_lv_stats[0], 1ull); }
-            s_fail = 2;
+            LDS_FLAG(s_fail) = 2;
             passed = false;
         }
-        if (passed && *(volatile int *) &s_fail == 0) t = my_tile(A, mine ? 0 : 1);
-        if (!mine && t < 0 && passed && lane == 0 && *(volatile int *) &s_fail == 0) {       // no second tile: said right away
+        if (passed && LDS_FLAG(s_fail) == 0) t = my_tile(A, mine ? 0 : 1);
+        if (!mine && t < 0 && passed && lane == 0 && LDS_FLAG(s_fail) == 0) {       // no second tile: said right away
             const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 10) | (unsigned) (L + 1)) << 32;
             gu64 *fdst = flagw + (size_t) (L & 1) * 2 * LV_PMAX + 2 * slot + 1;
             if (!(dbg & 4)) __hip_atomic_store(fdst + near_off, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -416,7 +416,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
         unsigned word = 0;
         if (t >= 0) {
             n_proc++;
-            if (L > 0 && row_above(L, t, A_prev, have_g, g)) s_fail = 1;
+            if (L > 0 && row_above(L, t, A_prev, have_g, g)) LDS_FLAG(s_fail) = 1;
 #ifdef LQR_TIMING
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -446,7 +446,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
             word = 0x800u | (any_o ? 0x100u : 0u) | (any_l ? 0x200u : 0u) | (any_r ? 0x400u : 0u) | (unsigned) t;
         } else if (mine && passed) n_idle++;
         // the slot's word for this wave's tile of the level (its granules were issued above; a reader checks their tags itself)
-        if (lane == 0 && (t >= 0 || mine) && *(volatile int *) &s_fail == 0) {
+        if (lane == 0 && (t >= 0 || mine) && LDS_FLAG(s_fail) == 0) {
             const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 10) | (unsigned) (L + 1)) << 32;
             gu64 *fdst = flagw + (size_t) (L & 1) * 2 * LV_PMAX + 2 * slot + (mine ? 0 : 1);
             if (!(dbg & 4)) __hip_atomic_store(fdst + near_off, tag | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -455,7 +455,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
         LTT(7);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         LTT(8);
-        if (*(volatile int *) &s_fail) return;    // 1: a time-out, results are invalid anyway; 2: the image stopped at this level (level L - 1 was stored above)
+        if (LDS_FLAG(s_fail)) return;    // 1: a time-out, results are invalid anyway; 2: the image stopped at this level (level L - 1 was stored above)
     }
 #ifdef LQR_TIMING
     if (image == 0 && lane == 0 && slot < 16) { ltt[9] = __builtin_readcyclecounter() - ltstart; for (int i = 0; i < 10; i++) g_lv_time[slot][q][i] = ltt[i]; }

@@ -122,6 +122,7 @@ __device__ unsigned long long g_tile_dbg[2 * 16];
 #else
 #define TT(i) do { } while (0)
 #endif
+__device__ int g_dpp_dbg;          // experiment switches (lqrhip_dp_tile_debug): 1 no near copies, 2 tile = workgroup index (neighbours on different XCDs) and no near copies
 template <int PX, bool LR, bool RIG, bool UPDATE, int DELTA, bool RIGM>
 __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err)
 {
@@ -133,17 +134,28 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
     constexpr int HALO = dpp_halo(PX), OWN = dpp_own(PX), EX_TILE = dpp_ex_tile(PX), TILE = 64 * PX, HL = 16;      // HL: halo lanes per side
     __shared__ FV s_mp[64];                      // the row above the next batch, handed from wave to wave
     __shared__ int s_fail;                       // a neighbour never showed up: both waves leave at the next barrier
-    __shared__ volatile int s_polled;            // last block whose halo wave 0 has received
+    __shared__ int s_polled;                     // last block whose halo wave 0 has received (LDS_FLAG: lqr_common.h)
     if (threadIdx.x == 0) { s_fail = 0; s_polled = 0; }
     __syncthreads();
     const GCarver c = gview(cs[blockIdx.y]);
     gf32 *m_out = UPDATE ? c.m2 : c.m;
     gi8 *least_out = UPDATE ? c.least2 : c.least;
-    const int ntiles = gridDim.x, tile = blockIdx.x;
+    // Workgroup b is observed to run on XCD b mod 8 (no promise: speed only).  The tiles are numbered so that the workgroups of one
+    // XCD hold CONSECUTIVE tiles (class b & 7 holds tiles [cls a + min(cls, r), ...), ntiles = 8 a + r): all but seven of the
+    // neighbour pairs then sit on one XCD, whose L2 serves their hand-over through the near copies below.  (debug switch 2: tile = b)
+    const int dbg = __builtin_amdgcn_readfirstlane(g_dpp_dbg);
+    const int ntiles = gridDim.x;
+    const int cls = (int) blockIdx.x & 7, cls_k = (int) blockIdx.x >> 3, cls_n = (ntiles >> 3) + (cls < (ntiles & 7) ? 1 : 0);
+    const int tile = (dbg & 2) ? (int) blockIdx.x : cls * (ntiles >> 3) + min(cls, ntiles & 7) + cls_k;
     // exchange area of this image: per tile EX_TILE granules ({m bits, tag}, 8 bytes, one store each), then one
-    // word that counts finished tiles
+    // word that counts finished tiles; then the same again: the NEAR copies of the granules (plain stores: they stay in the writer's
+    // L2, where a neighbour on the same XCD finds them without the trip to memory and back -- see k_levels.hip).  A lane whose
+    // neighbour is of its own class polls the near copy three times out of four, the write-through copy the fourth; the others
+    // poll the write-through copy only.  The protocol rests on the write-through copies alone.
     typedef GLOBAL_AS unsigned long long gu64;
-    gu64 *ex_img = (gu64 *) exch + (size_t) blockIdx.y * ((size_t) ntiles * EX_TILE + 8);
+    const size_t near_off = (size_t) ntiles * EX_TILE + 8;
+    gu64 *ex_img = (gu64 *) exch + (size_t) blockIdx.y * 2 * near_off;
+    const bool near_l = !(dbg & 3) && cls_k > 0, near_r = !(dbg & 3) && cls_k + 1 < cls_n;      // the left / right neighbour is on this XCD
     gi32 *done_ctr = (gi32 *) (ex_img + (size_t) ntiles * EX_TILE);
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -349,9 +361,11 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     unsigned long long g[PX];
                     int spins = 0;
                     bool failed = false;
+                    const bool lane_near = need && (lane < 32 ? near_l : near_r);
                     while (true) {
+                        gu64 *s2 = src + ((lane_near && (spins & 3) != 3) ? near_off : 0);
 #pragma unroll
-                        for (int k = 0; k < PX; k++) g[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int k = 0; k < PX; k++) g[k] = __hip_atomic_load(s2 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         bool ok = true;
 #pragma unroll
                         for (int k = 0; k < PX; k++) ok &= ((unsigned) (g[k] >> 32) == want);
@@ -361,12 +375,12 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                         if ((spins & 1023) == 0 && dev_failed(dev_err)) { failed = true; break; }
                         if (spins > (1 << 22)) { if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); failed = true; break; }
                     }
-                    if (failed) s_fail = 1;
+                    if (failed) LDS_FLAG(s_fail) = 1;
                     if (need) {
 #pragma unroll
                         for (int k = 0; k < PX; k++) mp[k] = in[k] ? __uint_as_float((unsigned) g[k]) : INF;
                     }
-                    if (lane == 0) s_polled = j;          // the partner's prefetch may start (see the issue site)
+                    if (lane == 0) LDS_FLAG(s_polled) = j;          // the partner's prefetch may start (see the issue site)
                 }
                 TT(1);
 #ifdef LQR_TIMING
@@ -405,7 +419,10 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                         gu64 *dst = ex_img + (size_t) tile * EX_TILE + (size_t) ((j & 1) * 2 + side) * HALO + PX * (lane - (side ? 32 : HL));
                         const unsigned long long tag = (unsigned long long) (((unsigned) epoch << DPP_BLK_BITS) | (unsigned) (j + 1)) << 32;
 #pragma unroll
-                        for (int k = 0; k < PX; k++) __hip_atomic_store(dst + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int k = 0; k < PX; k++) {
+                            if (side ? near_r : near_l) __hip_atomic_store(dst + near_off + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_store(dst + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
                 }
             }
@@ -422,7 +439,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                 // the poll double the wait (measured on the band variant of this kernel: 4200 -> 2200 cycles per block).
                 if (bb == NBB - 1 && j + 1 < nblk) {
                     int spins = 0;
-                    while (s_polled < j + 1 && !*(volatile int *) &s_fail && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
+                    while (LDS_FLAG(s_polled) < j + 1 && !LDS_FLAG(s_fail) && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
                 }
                 TT(6);
                 if constexpr (UPDATE) store_u(yb);        // the batch this wave has just computed, before its registers are reloaded
@@ -518,9 +535,9 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
     typedef GLOBAL_AS unsigned long long gu64;
     __shared__ FV s_mp[64];                       // the row above the next block, handed from wave to wave
     __shared__ int s_fail;                        // leave at the next barrier: a neighbour timed out, or the image was aborted
-    __shared__ volatile int s_polled;             // last block whose hand-over this workgroup has received
+    __shared__ int s_polled;                      // last block whose hand-over this workgroup has received (flags: LDS_FLAG, lqr_common.h)
     __shared__ int s_own_chg;                     // an own pixel changed on the last row of the block just finished
-    __shared__ volatile int s_nbr_live;           // the hand-over last received says a neighbour was active or changed at its edge
+    __shared__ int s_nbr_live;                    // the hand-over last received says a neighbour was active or changed at its edge
     __shared__ int s_from[2];                     // first block with a left / right neighbour
     __shared__ int s_asked[2];                    // a reserve tile was asked for on that side (or there is none left)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -752,8 +769,8 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
             int rcv = 0;
             if (j > 0) {
                 rcv = receive(j, true);
-                if (rcv & 4) s_fail = 1;
-                if (lane == 0) { s_nbr_live = (rcv & 9) != 0; s_polled = j; }
+                if (rcv & 4) LDS_FLAG(s_fail) = 1;
+                if (lane == 0) { LDS_FLAG(s_nbr_live) = (rcv & 9) != 0; LDS_FLAG(s_polled) = j; }
             }
             BTT(0);
             abort = (rcv & 2) != 0;
@@ -788,7 +805,7 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
                 // nobody beyond the outermost own column during this block: it must not have changed before the block's last
                 // row, and if it changed ON the last row somebody must be there from the next block on
                 const bool last_l = __any(acc_l0 != 0 && lane == HL), last_r = __any(acc_l1 != 0 && lane == 63 - HL);
-                const int fl = *(volatile int *) &s_from[0], fr = *(volatile int *) &s_from[1];
+                const int fl = LDS_FLAG(s_from[0]), fr = LDS_FLAG(s_from[1]);
                 if ((alone_l && (__any(acc_e0 != 0 && lane == HL) || (last_l && j + 1 < nblk && fl > j + 1))) ||
                     (alone_r && (__any(acc_e1 != 0 && lane == 63 - HL) || (last_r && j + 1 < nblk && fr > j + 1)))) {
                     // this block stays unstored, rows from y0 on are the full-width sweep's
@@ -823,8 +840,8 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
         if (mine) {
             if (j + 1 < nblk) {
                 int spins = 0;
-                while (s_polled < j + 1 && !*(volatile int *) &s_fail && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
-                if (*(volatile int *) &s_fail) continue;          // the partner saw an abort or a time-out: it is at the barrier
+                while (LDS_FLAG(s_polled) < j + 1 && !LDS_FLAG(s_fail) && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
+                if (LDS_FLAG(s_fail)) continue;          // the partner saw an abort or a time-out: it is at the barrier
             } else if (act) {
                 if (receive(nblk, false) & 6) continue;            // (aborted neighbours: their rows are the sweep's anyway)
             }
@@ -835,7 +852,7 @@ __device__ __forceinline__ void band_tile_run(const GCarver &c, const DpK &p, in
             if (j2 < nblk) {
                 // (the partner has just received the hand-over for block j + 1: what it says about the neighbours' block j is one
                 // block fresher than this wave's own knowledge)
-                staged = act || nbr_act || s_nbr_live != 0 || (fnext & 8u);      // an active neighbour's band may arrive within two blocks
+                staged = act || nbr_act || LDS_FLAG(s_nbr_live) != 0 || (fnext & 8u);      // an active neighbour's band may arrive within two blocks
                 if (staged) issue_full(j2 * R); else issue_last(j2 * R);
             }
             BTT(6);
@@ -946,6 +963,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #ifdef LQR_TIMING
 extern "C" int lqrhip_band_tiles_timing(unsigned long long *out) { (void) hipDeviceSynchronize(); return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bt_time), sizeof(unsigned long long) * 320) == hipSuccess ? 0 : -1; }
 #endif
+extern "C" void lqrhip_dp_tile_debug(int v) { (void) hipMemcpyToSymbol(HIP_SYMBOL(g_dpp_dbg), &v, sizeof v); }
 extern "C" int lqrhip_band_tiles_stats(unsigned long long *out, int reset)
 {
     (void) hipDeviceSynchronize();

@@ -97,6 +97,17 @@ struct DevCarver {
 // emits flat_load/flat_store (slower issue, and every access also ties up lgkmcnt, which
 // defeats software prefetching).  Kernels therefore work on a view whose members are typed
 // as address-space-1 (global) pointers, so that they become global_load/global_store.
+// A flag in LDS that one wave of a workgroup writes while the other reads it.  NOT `volatile int` / `*(volatile int *) &x`: inside a
+// lambda (and after inlining) a __shared__ variable is reached through a GENERIC pointer, and the compiler leaves volatile accesses
+// through generic pointers as FLAT instructions, each followed by s_waitcnt vmcnt(0): every read of such a flag drained the
+// wave's outstanding prefetch loads AND waited for the acknowledgement of its write-through hand-over stores (found in round 5
+// in k_band_levels' publish path and k_dp_tile_p's hold-back spin).  With the address space spelt out it is ds_read / ds_write.
+typedef __attribute__((address_space(3))) volatile int lds_vint;
+#ifdef LDS_FLAG_GENERIC            // (the old form, for A/B measurements: make EXTRA=-DLDS_FLAG_GENERIC)
+#define LDS_FLAG(x) (*(volatile int *) &(x))
+#else
+#define LDS_FLAG(x) (*(lds_vint *) &(x))
+#endif
 #define GLOBAL_AS __attribute__((address_space(1)))
 typedef GLOBAL_AS uint8_t gu8;
 typedef GLOBAL_AS uint32_t gu32;

@@ -936,7 +936,7 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
     if (!px) return LQRHIP_EARG;
     const int ntiles = (w + dpp_own(px) - 1) / dpp_own(px);
     int rc;
-    const size_t need_elems = ((size_t) ntiles * dpp_ex_tile(px) + 8) * n;
+    const size_t need_elems = 2 * ((size_t) ntiles * dpp_ex_tile(px) + 8) * n;      // (granules + finished-tile counter, and the near copies: k_tiles.hip)
     if (b->exch_elems < need_elems) {
         HIPCK(hipStreamSynchronize(b->stream));
         dfree(b->exch);
