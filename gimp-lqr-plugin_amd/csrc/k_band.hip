@@ -550,7 +550,8 @@ template <int NW, bool LR, bool RIG>
 __device__ __forceinline__ void band_update_tw_body(const DevCarver &dc, const DpK &p, int w, int h, int stride, int *dev_err)
 {
     constexpr int R = TW_R, OWN = TW_OWN, WIN = NW * OWN, NT = 128 * NW;
-    const GCarver c = gview(dc);
+    GCarver c = gview(dc);
+    c.en = uni_ptr(c.en); c.m = uni_ptr(c.m); c.least = uni_ptr(c.least);       // (scalar bases for the row loop: lqr_common.h)
     extern __shared__ int s_tw[];                          // [2h]: per row, per batch-starting-at-row touch ranges
     int *s_touch = s_tw, *s_touchR = s_tw + h;
     // m of the last finished row over [B-R, B+WIN+R), double-buffered by batch parity: a slot reads its halo

@@ -146,10 +146,9 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     };
     // tiles of this slot's residue (t mod P == slot), and of residue 0: no integer division inside the level loop (a lone wave pays
     // ~40 instructions x 4-5 cycles for each: five of them were 2 000 cycles per level)
-    unsigned long long res_mine = 0ull, res_zero = 0ull;
+    unsigned long long res_mine = 0ull;
     for (int t = slot; t < LV_MAX_TILES; t += P) res_mine |= 1ull << t;
-    for (int t = 0; t < LV_MAX_TILES; t += P) res_zero |= 1ull << t;
-    res_mine = uni64(res_mine); res_zero = uni64(res_zero);
+    res_mine = uni64(res_mine);
     // the which-th (0, 1) tile of this slot's residue in a set, -1: none
     auto my_tile = [&](const LvMask &A, int which) -> int {
         unsigned long long m = A.lo & res_mine;
@@ -160,6 +159,8 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     auto any_collision = [&](const LvMask &A) -> bool {
         const int a = A.first(), b = A.last();
         if (a < 0 || b - a < 2 * P) return false;            // a window of 2 P consecutive tiles: at most two per residue
+        unsigned long long res_zero = 0ull;                  // (worked out here: the wide window is rare, and two scalar registers held
+        for (int t = 0; t < LV_MAX_TILES; t += P) res_zero |= 1ull << t;      //  across the row loop cost it its free compare registers)
         for (int r = 0; r < P; r++)
             if (__popcll(A.lo & (res_zero << r)) > 2) return true;
         return false;
@@ -321,7 +322,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     // them makes the register allocator keep two sets: 330 spilled VGPRs).  Wave q receives the barrier of the levels of its
     // parity and takes the slot's FIRST tile there; in the other levels it stores what it holds, takes the slot's SECOND tile if
     // there is one, else prefetches its own next level.  Iteration nblk only closes the last level.
-    unsigned long long n_proc = 0, n_idle = 0, n_sync = 0, n_two = 0;
+    unsigned n_proc = 0, n_idle = 0, n_sync = 0, n_two = 0;             // (32 bits: scalar registers are what the row loop is short of)
     int hold_L = -1;                            // the level whose (unstored) results sit in this wave's registers
 #ifdef LQR_TIMING
     unsigned long long ltt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -460,8 +461,8 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
 #ifdef LQR_TIMING
     if (image == 0 && lane == 0 && slot < 16) { ltt[9] = __builtin_readcyclecounter() - ltstart; for (int i = 0; i < 10; i++) g_lv_time[slot][q][i] = ltt[i]; }
 #endif
-    if (lane == 0) { atomicAdd(&g_lv_stats[2], n_proc); atomicAdd(&g_lv_stats[3], n_idle); if (n_two) atomicAdd(&g_lv_stats[4], n_two); }
-    if (lane == 0 && n_sync) atomicAdd(&g_lv_stats[1], n_sync);
+    if (lane == 0) { atomicAdd(&g_lv_stats[2], (unsigned long long) n_proc); atomicAdd(&g_lv_stats[3], (unsigned long long) n_idle); if (n_two) atomicAdd(&g_lv_stats[4], (unsigned long long) n_two); }
+    if (lane == 0 && n_sync) atomicAdd(&g_lv_stats[1], (unsigned long long) n_sync);
 }
 
 extern "C" void lqrhip_band_levels_debug(int v) { (void) hipMemcpyToSymbol(HIP_SYMBOL(g_lv_dbg), &v, sizeof v); }

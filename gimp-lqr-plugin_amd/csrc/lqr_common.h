@@ -155,6 +155,17 @@ __device__ __forceinline__ GCarver gview(const DevCarver &d)
     return g;
 }
 
+// A pointer every lane holds, moved to scalar registers ONCE.  The device descriptors are read with vector loads (other kernels
+// write them, so the compiler may not use the scalar cache), which leaves the plane pointers in VGPRs: uniform, but every use as
+// the scalar base of a load or store then costs v_readfirstlane x 2 and a hazard nop -- inside k_band_update_tw's row loop 7 of
+// 71 instructions per row.
+template <class T> __device__ __forceinline__ T *uni_ptr(T *p)
+{
+    const unsigned long long v = (unsigned long long) p;
+    const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) v), hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (v >> 32));
+    return (T *) (((unsigned long long) hi << 32) | lo);
+}
+
 struct DpK {
     int delta;
     int use_rig;

@@ -1139,10 +1139,10 @@ static int band_levels_P(const LqrHipBatch *b, int w, int h, int delta)
     const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_levels) : g_dpp_max_wgs_levels;
     const int per_batch = limit / std::max(b->shared_n, 1);
     int P = std::min(LV_PMAX, per_batch / (int) std::max<size_t>(b->cs.size(), 1));
-    // automatic: 12 slots while the group's workgroups stay below ~480 (beyond that the sibling kernels are starved of registers,
-    // DESIGN.md 4.15 / 4.16), never fewer than 7 (6 and fewer put second tiles on a slot in 9 % of the tile-levels)
+    // automatic: 12 slots while the group's workgroups stay below ~384 (beyond that the sibling kernels are starved of registers,
+    // 48 images with 10 slots 452 k, with 8 slots 479 k), never fewer than 7 (6 and fewer put second tiles on a slot in 9 % of the tile-levels)
     const size_t group_images = b->cs.size() * (size_t) std::max(b->shared_n, 1);
-    const int want = g_band_levels > 0 ? g_band_levels : std::max(7, std::min(12, (int) (480 / std::max<size_t>(group_images, 1))));
+    const int want = g_band_levels > 0 ? g_band_levels : std::max(7, std::min(12, (int) (384 / std::max<size_t>(group_images, 1))));
     P = std::min(P, want);
     return P >= (g_band_levels > 0 ? 1 : 7) ? P : 0;
 }

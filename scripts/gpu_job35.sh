@@ -1,0 +1,12 @@
+#!/bin/bash
+# which of the level loop's LDS flag reads matter: the tree against variant a (no s_fail reads between the barriers) and b (only the one before the word store removed)
+mkdir -p gpurun_out/job35; O=gpurun_out/job35
+P='import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d["value"]), d["ms_per_step"], {k: round(v["ms"]/v["launches"]*1000) for k,v in d["kernels_ms"].items()})'
+D=$PWD/gimp-lqr-plugin_amd
+run() { echo -n "lib=$V $* : "; timeout 600 python bench.py --steps 3 --warmup 1 --no-configs --no-cpu-baseline --no-phases --kernel-times "$@" 2>>$O/bench.err | python3 -c "$P"; }
+for n in 8 16; do for r in 1 2; do
+  V=tree run --images-per-gpu $n
+  V=a LQR_HIP_LIB=$D/liblqr-hip-va.so run --images-per-gpu $n
+  V=b LQR_HIP_LIB=$D/liblqr-hip-vb.so run --images-per-gpu $n
+done; done
