@@ -16,7 +16,7 @@ KEYS = ("vgpr_count", "agpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spil
 
 
 def tools_available():
-    return all(os.path.exists(os.path.join(LLVM_BIN, t)) for t in ("clang-offload-bundler", "llvm-readelf")) and shutil.which("objcopy") and shutil.which("c++filt")
+    return all(os.path.exists(os.path.join(LLVM_BIN, t)) for t in ("clang-offload-bundler", "llvm-readelf", "llvm-objdump")) and shutil.which("objcopy") and shutil.which("c++filt")
 
 
 def kernels(so_path):
@@ -51,6 +51,44 @@ def kernels(so_path):
             n = re.sub(r"^void ", "", n)
             n = re.sub(r"\(.*", "", n)
             out[n] = d
+    return out
+
+
+def instruction_counts(so_path, mnemonics=("s_nop", "v_readfirstlane_b32", "flat_load_dword", "flat_store_dword")):
+    """{demangled kernel name: {mnemonic: count}} from the disassembly of every gfx950 code object in the library"""
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", so_path, fat])
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+        counts = {}
+        for i, a in enumerate(starts):
+            b = starts[i + 1] if i + 1 < len(starts) else len(blob)
+            piece, co = os.path.join(td, "b%d.bin" % i), os.path.join(td, "b%d.co" % i)
+            open(piece, "wb").write(blob[a:b])
+            subprocess.check_call([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o",
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + piece, "--output=" + co])
+            if os.path.getsize(co) == 0:
+                continue
+            dis = subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+            cur = None
+            for line in dis.split("\n"):
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                if m:
+                    cur = counts.setdefault(m.group(1), dict.fromkeys(mnemonics, 0))
+                    continue
+                if cur is None:
+                    continue
+                t = line.split()
+                if t and t[0] in cur:
+                    cur[t[0]] += 1
+        mangled = sorted(counts)
+        names = subprocess.run(["c++filt"], input="\n".join(mangled), capture_output=True, text=True, check=True).stdout.split("\n")
+        for mn, n in zip(mangled, names):
+            n = re.sub(r"^void ", "", n)
+            n = re.sub(r"\(.*", "", n)
+            out[n] = counts[mn]
     return out
 
 

@@ -10,6 +10,7 @@ Checked red on a deliberately fattened build: `make -C gimp-lqr-plugin_amd EXTRA
 (the carve's group size: 104 VGPRs) and `LQR_BUDGET_LIB=/tmp/fat/lib.so pytest tests/test_kernel_budgets.py` -> k_carve
 over budget; test_checker_is_red_on_a_fattened_kernel does the same on doctored metadata in every run."""
 import copy
+import functools
 import os
 import re
 
@@ -24,6 +25,7 @@ LIB = os.environ.get("LQR_BUDGET_LIB") or os.path.join(ROOT, "gimp-lqr-plugin_am
 BUDGETS = [
     (r"^k_carve$", 96, 0, 0, "5 waves per SIMD: the carve's 0.4 of the HBM roof next to the chain kernels (DESIGN 4.9, 4.14)"),
     (r"^k_band_update_tw<4, ", 256, 0, 0, "8 waves per workgroup = 2 per SIMD; it claims all 256 registers on purpose (no sibling kernel's wave beside it); no scratch in the row loop"),
+    (r"^k_band_levels<", 256, 0, 0, "2 waves per SIMD (amdgpu_waves_per_eu(2, 2)): the residency bound the slot count is taken from; one site each for loads, rows and stores or 330 VGPRs spill (DESIGN 4.16)"),
     (r"^k_band_tiles<", 256, 32, 8, "2 waves per SIMD (amdgpu_waves_per_eu(2, 2)): the residency bound of 768 workgroups; the few spills sit outside the row loop"),
     (r"^k_dp_tile_p<[24], (true|false), (true|false), false, 1, false>$", 128, 0, 0, "E5, plain: 4 waves per SIMD"),
     (r"^k_dp_tile_p<2, (true|false), (true|false), true, 1, false>$", 232, 0, 0, "E9 full width, 32-row block staged in registers: 2 waves per SIMD"),
@@ -84,3 +86,58 @@ def test_checker_is_red_on_a_fattened_kernel(meta):
     bad = violations(fat)
     assert len(bad) >= 3 and any(b.startswith("k_carve:") for b in bad) and any("k_band_tiles<false, false>" in b for b in bad) \
         and any("k_band_update_tw<4, true, false>" in b for b in bad), bad
+
+
+# ---- what the disassembly must (not) contain: findings of round 5 that a compile can silently undo
+# (regular expression on the demangled name, mnemonic, max count, why)
+ISA_LIMITS = [
+    (r"^k_band_levels<(true|false), false, 1, false>$", "s_nop", 40,
+     "the 32-row loop with its compares in free SGPR pairs (13 hazard nops in the kernel); when the scalar registers run out the "
+     "register allocator serialises every compare through VCC: 4 nops per row, 141 in the kernel, 261 -> 284 us at 8 images "
+     "(DESIGN.md 4.16: any edit of the kernel can flip it; measured with seven variants)"),
+    (r"^k_band_update_tw<4, ", "v_readfirstlane_b32", 40,
+     "plane pointers in scalar registers (uni_ptr): from the descriptor's vector loads they arrive in VGPRs and every row paid "
+     "4 v_readfirstlane + hazard nops (202 in the kernel)"),
+    (r"^k_band_update_tw<4, ", "s_nop", 40, "as above (106 before)"),
+    (r"^k_dp_tile_p<2, (true|false), false, true, 1, false>$", "s_nop", 40, "the 32-row block loop, as k_band_levels (10 now)"),
+    (r"^k_(band|dp_tile|dp_sweep|vpath|carve|emap)", "flat_load_dword", 0,
+     "an LDS flag read through a generic pointer (volatile cast of a __shared__ variable inside a lambda): FLAT + s_waitcnt "
+     "vmcnt(0) drains the wave's prefetch and waits for its write-through stores -- use LDS_FLAG (lqr_common.h)"),
+    (r"^k_(band|dp_tile|dp_sweep|vpath|carve|emap)", "flat_store_dword", 0, "as above (the one-off kernels of k_oneoff.hip take generic pointers and may)"),
+]
+
+
+@functools.lru_cache(maxsize=None)
+def isa_counts():
+    return KM.instruction_counts(LIB)
+
+
+def isa_violations(counts):
+    bad = []
+    seen = set()
+    for name, d in sorted(counts.items()):
+        for pat, mn, limit, why in ISA_LIMITS:
+            if re.search(pat, name):
+                seen.add((pat, mn))
+                if d.get(mn, 0) > limit:
+                    bad.append("%s: %d x %s, limit %d: %s" % (name, d[mn], mn, limit, why))
+    for pat, mn, *_ in ISA_LIMITS:
+        if (pat, mn) not in seen:
+            bad.append("no kernel matches ISA pattern %s (renamed? the limit must follow it)" % pat)
+    return bad
+
+
+def test_row_loops_keep_their_schedule_and_no_flag_goes_through_flat(meta):
+    counts = isa_counts()
+    assert len(counts) > 100, "expected the whole kernel set, found %d kernels" % len(counts)
+    bad = isa_violations(counts)
+    assert not bad, "\n".join(bad)
+
+
+def test_isa_checker_is_red_on_doctored_counts(meta):
+    fat = copy.deepcopy(isa_counts())
+    fat["k_band_levels<false, false, 1, false>"]["s_nop"] = 141
+    fat["k_dp_tile_p<2, true, false, true, 1, false>"]["flat_load_dword"] = 3
+    fat["k_band_update_tw<4, false, false>"]["v_readfirstlane_b32"] = 202
+    bad = isa_violations(fat)
+    assert len(bad) == 3 and "k_band_levels" in bad[0] and "k_band_update_tw" in bad[1] and "flat_load_dword" in bad[2], bad
