@@ -48,8 +48,9 @@ Also on the JSON line:
                 extra untimed step with all of them timed: launches, average duration, share of the kernel time,
                 algorithmic and PMC bytes, fraction of the roof.  end_to_end = the whole step against the roof:
                 value x (4 B carve + 9 B x full DPs per phase / seams per phase) / 8 TB/s.
-  configs       after the headline: config 4's literal per-GPU shard (batch4k_8img: 8 x 4K) and BASELINE configs 2, 3 and 5
-                (fhd, single4k, config5: one carver, the plug-in's own call shape), 3 steps each, with their own
+  configs       after the headline: config 4's literal per-GPU shard (batch4k_8img: 8 x 4K), BASELINE configs 2, 3 and 5
+                (fhd, single4k, config5: one carver, the plug-in's own call shape) and 96 x 4K (batch4k_96img: what the same
+                four streams carry when the group is larger), 3 steps each, with their own
                 roofline.kernels, phases and cpu_baseline (--no-configs skips).  summary = every workload's value, last on the line.
   cpu_baseline  the CPU oracle (oracle/, a port of liblqr pinned against the genuine liblqr 0.4.1, oracle/REF_CHECK.md)
                 timed on this host: one image on one core, and one image per core on all cores for the batch workload
@@ -644,7 +645,9 @@ def main():
     if args.workload == "batch4k" and world == 1 and not args.no_configs and args.seams is None and not args.strong:
         result["configs"] = {}
         keep = ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernels_ms", "phases", "cpu_baseline", "parity_vs_oracle", "hbm_used_gb")
-        legs = [("batch4k_8img", "batch4k", 8), ("fhd", "fhd", None), ("single4k", "single4k", None), ("config5", "config5", None)]
+        # (batch4k_96img: the headline's 64 images are four chains of 16 in flight and the chain's latency, not the chip, bounds
+        # them -- half as many images again run through the same four streams in a fifth more time: DESIGN.md 4.11 / 9)
+        legs = [("batch4k_8img", "batch4k", 8), ("fhd", "fhd", None), ("single4k", "single4k", None), ("config5", "config5", None), ("batch4k_96img", "batch4k", 96)]
         for name, wl, images in legs:
             if images and images == args.images_per_gpu:
                 continue
