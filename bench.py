@@ -450,7 +450,7 @@ def main():
                         "note": "frac = min(alg_bytes, moved_bytes) per launch / avg_launch_us / peak for k_carve, the HBM-bound kernel: alg = SURVEY 8(d)'s "
                                 "8 B x W*H/2 per image, moved = 18 B x the pixels on the side of the seam the carve really moves (k_vpath*'s count; "
                                 "8 B on seams a full DP follows); traffic_ratio = PMC traffic / moved; frac_alg = the alg-only figure of earlier "
-                                "rounds; launches of the sub-batch streams overlap, frac_while_active divides by the union of their intervals; "
+                                "rounds; launches of the sub-batch streams overlap, frac_while_active divides by the union of their intervals, `alone` is the same kernel on one stream with nothing beside it; "
                                 "`kernels` lists every kernel of the step, `end_to_end` is the whole step against the roof",
                         "end_to_end": {"bytes_per_seam_px": round(b_alg, 4), "achieved": round(value * b_alg * 1e-3 / max(world, 1), 1),
                                        "unit": "GB/s per GPU", "frac": round(value * b_alg * 1e-3 / max(world, 1) / 8000.0, 4)}}
@@ -468,6 +468,19 @@ def main():
             timed(carvers, ptrs, 1, 0, 1)
             kern = {k: prof(k) for k in KERNEL_NAMES}
         tot_ms = sum(v[0] for v in kern.values()) or 1.0
+        # ---- the same kernel with the device to itself: ONE more untimed step on ONE stream (every image of the group in one
+        # launch, no sibling stream's kernels beside it).  In the timed region the launches of the sub-batch streams overlap each
+        # other and the other streams' band kernels, and avg_launch_us is a contended figure; this is the kernel's own.
+        if roofline is not None and headline and streams > 1 and not args.no_kernel_breakdown and not args.kernel_times:
+            lib.lqrhip_set_sub_batches(1)
+            timed(carvers, ptrs, 1, 0, 2)
+            lib.lqrhip_set_sub_batches(args.sub_batches)
+            a_ms, a_n, a_bytes = prof("carve")
+            if a_n:
+                a_num = min(a_bytes / a_n, timed.moved_bytes / a_n) if timed.moved_bytes else a_bytes / a_n
+                roofline["alone"] = {"streams": 1, "launches": a_n, "avg_launch_us": round(a_ms * 1e3 / a_n, 2), "bytes_per_launch": round(a_num),
+                                     "achieved": round(a_num / (a_ms * 1e-3 / a_n) / 1e9, 1), "frac": round(a_num / (a_ms * 1e-3 / a_n) / 8e12, 4),
+                                     "note": "k_carve over the whole group in one launch per seam, one stream, nothing beside it (an extra untimed step)"}
         if roofline is not None:
             roofline["kernels"] = []
             for k, (ms, n, by) in sorted(kern.items(), key=lambda kv: -kv[1][0]):

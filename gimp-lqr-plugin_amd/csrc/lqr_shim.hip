@@ -1292,16 +1292,17 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     // resident tile workgroups the carves of the sibling streams are starved of registers, so large groups
     // keep k_band_update_tw.
     {
-        // round 5: the band on P slots per image, tiles assigned level by level (k_band_levels): the default for groups of 8 to 48
+        // round 5: the band on P slots per image, tiles assigned level by level (k_band_levels): the default for groups of 8 to 64
         // images (measured, Mseams*px/s at 4K, levels / k_band_update_tw: 8 images 148 / 127, 16: 256 / 180, 48: 479 / 404).  64 images
-        // on four streams with 7 slots, alternating on three boxes: 516 / 495-516, 497 / 488, 520 / 504 -- but its 448 workgroups
-        // stretch the sibling streams' carves (k_carve 167 -> 203 us per launch, 0.39 -> 0.32 of the HBM roof per launch) for that
-        // 2 %, and 96 images run 585 / 622: groups above 48 keep k_band_update_tw; update mode 5 forces the level kernel
+        // on four streams with 7 slots: alternating 3-step runs on three boxes 516 / 495-516, 497 / 488, 520 / 504; the driver's
+        // 20-step command on two boxes of equal speed (every other figure within 1 %) 567.2 / 538.9 k.  Its 448 workgroups stretch
+        // the sibling streams' carves (k_carve 172 -> 203 us per launch) while the whole step's share of the HBM roof rises (0.279
+        // -> 0.293).  96 images run 585 / 622: groups above 64 keep k_band_update_tw; update mode 0 / 5 force either
         // round 5: also delta_x 2 .. 4 and rigidity masks (k_band_levels' general instantiations): a batch of such carvers used to be
         // carved in groups of as many as the full-width tiled kernels hold (16 x 4K, delta_x 2: 68 k Mseams*px/s)
         const size_t group_images = (size_t) n * (size_t) std::max(b->shared_n, 1);
         const bool lv_ok = p->delta_x >= 1 && p->delta_x <= 4 && g_update_mode != 3;
-        const int PL = (lv_ok && (g_update_mode == 5 || (g_update_mode < 0 && group_images >= 8 && (group_images <= 48 || !fast_ok)))) ? band_levels_P(b, wnew, h, p->delta_x) : 0;
+        const int PL = (lv_ok && (g_update_mode == 5 || (g_update_mode < 0 && group_images >= 8 && (group_images <= 64 || !fast_ok)))) ? band_levels_P(b, wnew, h, p->delta_x) : 0;
         if (PL > 0) {
             {
                 ProfScope ps("band_levels", b->stream, 0);
