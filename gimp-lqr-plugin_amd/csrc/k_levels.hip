@@ -102,7 +102,8 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     if (image >= n_img) return;
     const int nblk = (h + R - 1) / R;
     const int ntiles = (w + OWN - 1) / OWN;
-    const GCarver c = gview(cs[image]);
+    GCarver c = gview(cs[image]);
+    if constexpr (RIG && DELTA == 1 && !RIGM) { c.en = uni_ptr(c.en); c.m = uni_ptr(c.m); c.least = uni_ptr(c.least); }      // (see LEAN below)
     const size_t near_off = (size_t) 4 * LV_PMAX + (size_t) 2 * ntiles * OWN;      // the near copies (see the header)
     gu64 *ex_img = (gu64 *) exch + (size_t) image * 2 * near_off;
     gu64 *flagw = ex_img;                                    // [2 parities][LV_PMAX slots][2 tiles]
@@ -180,15 +181,32 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     bool cur_full = false;
     int x0 = 0;
     unsigned lo_off = 0;
+    // The per-lane predicates of the staged tile (inside the image? an own column? a tile that reaches over the border?).  As booleans
+    // each is a pair of scalar registers held across the whole level loop, and scalar registers are what the row loop runs out of:
+    // its compares then go through VCC one after the other (4 hazard nops per row, -8 %).  The rigidity
+    // instantiations (LEAN) therefore work them out from x0 where they are needed -- one unsigned compare each, on a copy the
+    // compiler cannot see through -- and get the fast row schedule (296 -> 275 us at 16 images); the plain instantiations have the
+    // fast schedule WITH the booleans and lose 4 % without them (255 -> 267 us at 8 images: 38 more s_waitcnt in the rows), so
+    // they keep them.  tests/test_kernel_budgets.py watches both.
+    constexpr bool LEAN = RIG && DELTA == 1 && !RIGM;       // (measured: delta_x 2 with rigidity 440 -> 456 us WITH it, so only here)
     bool in[PX] = {false, false}, own = false, interior = false;
     const bool own_lane = lane >= HL && lane < 64 - HL;
+    auto X0 = [&]() -> int { int v = x0; asm volatile("" : "+v"(v)); return v; };
+    auto in_k = [&](int k) -> bool { if constexpr (LEAN) return (unsigned) (X0() + k) < (unsigned) w; else return in[k]; };
+    auto is_own = [&]() -> bool { if constexpr (LEAN) return own_lane && X0() < w; else return own; };
+    auto is_interior = [&]() -> bool {
+        if constexpr (LEAN) { const int t0 = __builtin_amdgcn_readfirstlane(X0()); return t0 >= 0 && t0 + TILE <= w; }
+        else return interior;
+    };
     auto set_tile = [&](int t) {
         x0 = t * OWN - HALO + PX * lane;
         lo_off = (unsigned) min(max(x0, 0), stride - PX);
+        if constexpr (!LEAN) {
 #pragma unroll
-        for (int k = 0; k < PX; k++) in[k] = x0 + k >= 0 && x0 + k < w;
-        own = own_lane && x0 < w;
-        interior = (x0 - PX * lane >= 0) && (x0 - PX * lane + TILE <= w);
+            for (int k = 0; k < PX; k++) in[k] = x0 + k >= 0 && x0 + k < w;
+            own = own_lane && x0 < w;
+            interior = (x0 - PX * lane >= 0) && (x0 - PX * lane + TILE <= w);
+        }
     };
     // the tile that owns this lane's columns when the wave works on tile t, and the lane's first column inside that tile
     auto owner_of = [&](int t) -> int { return lane < HL ? t - 1 : lane >= 64 - HL ? t + 1 : t; };
@@ -254,8 +272,9 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
         }
     };
     auto store_u = [&](int ybase) {
-        const unsigned inc = own ? (unsigned) stride : 0u, inc4 = inc * 4u;
-        unsigned so = own ? (unsigned) ybase * (unsigned) stride + (unsigned) x0 : (unsigned) h * (unsigned) stride + (unsigned) (PX * lane), so4 = so * 4u;
+        const bool own_ = is_own();
+        const unsigned inc = own_ ? (unsigned) stride : 0u, inc4 = inc * 4u;
+        unsigned so = own_ ? (unsigned) ybase * (unsigned) stride + (unsigned) x0 : (unsigned) h * (unsigned) stride + (unsigned) (PX * lane), so4 = so * 4u;
         const int nr = min(R, h - ybase);
 #pragma unroll
         for (int r = 0; r < R; r++, so += inc, so4 += inc4) {
@@ -272,7 +291,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     auto wait_level = [&](int L, int spec_t, const LvMask &prev, unsigned long long &fw, unsigned long long (&g)[PX]) -> int {
         const unsigned want = ((unsigned) epoch << 10) | (unsigned) L;
         gu64 *fsrc = flagw + (size_t) ((L - 1) & 1) * 2 * LV_PMAX + (lane < 2 * P ? lane : 0);
-        const bool need_g = spec_t >= 0 && prev.has(owner_of(spec_t)) && (in[0] || in[1]);
+        const bool need_g = spec_t >= 0 && prev.has(owner_of(spec_t)) && (in_k(0) || in_k(1));
         gu64 *gsrc = gran + ((size_t) ((L - 1) & 1) * ntiles + (need_g ? owner_of(spec_t) : 0)) * OWN + (need_g ? owner_col : 0);
         int sp = 0;
         while (true) {
@@ -297,7 +316,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     // in level L - 1, else from memory (q_ab: nothing changed there).  have_g: g holds this tile's granules already.
     auto row_above = [&](int L, int t, const LvMask &prev, bool have_g, unsigned long long (&g)[PX]) -> int {
         const int u = owner_of(t);
-        const bool from_gran = prev.has(u) && (in[0] || in[1]);
+        const bool from_gran = prev.has(u) && (in_k(0) || in_k(1));
         if (!have_g) {
             gu64 *src = gran + ((size_t) ((L - 1) & 1) * ntiles + (from_gran ? u : 0)) * OWN + (from_gran ? owner_col : 0);
             const unsigned want = ((unsigned) epoch << 10) | (unsigned) L;
@@ -315,7 +334,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
             }
         }
 #pragma unroll
-        for (int k = 0; k < PX; k++) mp[k] = !in[k] ? INF : from_gran ? __uint_as_float((unsigned) g[k]) : q_ab[k];
+        for (int k = 0; k < PX; k++) mp[k] = !in_k(k) ? INF : from_gran ? __uint_as_float((unsigned) g[k]) : q_ab[k];
         return 0;
     };
     // ---- the level loop.  ONE site each for the loads, the 32 rows and the stores of the staging registers (a second site of any of
@@ -422,12 +441,13 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
             LTT(5);
-            if (!interior) {
+            if (!is_interior()) {
                 // outside the image the energy AND the old value become +inf (see k_dp_tile_p)
+                const bool ik[PX] = {in_k(0), in_k(1)};
 #pragma unroll
                 for (int r = 0; r < R; r++)
 #pragma unroll
-                    for (int k = 0; k < PX; k++) { q_e[r][k] = in[k] ? q_e[r][k] : INF; q_mo[r][k] = in[k] ? q_mo[r][k] : INF; }
+                    for (int k = 0; k < PX; k++) { q_e[r][k] = ik[k] ? q_e[r][k] : INF; q_mo[r][k] = ik[k] ? q_mo[r][k] : INF; }
             }
             batch_u(L * R);
             LTT(6);

@@ -9,7 +9,7 @@ import lqr_ctypes as L
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 W, H = 3840, 2160
-eng = L.Api(os.path.join(os.path.dirname(L.ENGINE_LIB), "liblqr-hip-timing.so"), ""); lib = eng.lib
+eng = L.Api(os.path.join(os.path.dirname(L.ENGINE_LIB), os.environ.get("LQR_TIMING_LIB", "liblqr-hip-timing.so")), ""); lib = eng.lib
 for f in ("lqrhip_set_update_mode", "lqrhip_set_sub_batches", "lqrhip_set_band_levels"): getattr(lib, f).argtypes = [C.c_int]
 lib.lqrhip_set_update_mode(5); lib.lqrhip_set_sub_batches(1); lib.lqrhip_set_band_levels(P)
 rng = np.random.default_rng(5)

@@ -95,6 +95,9 @@ ISA_LIMITS = [
      "the 32-row loop with its compares in free SGPR pairs (13 hazard nops in the kernel); when the scalar registers run out the "
      "register allocator serialises every compare through VCC: 4 nops per row, 141 in the kernel, 261 -> 284 us at 8 images "
      "(DESIGN.md 4.16: any edit of the kernel can flip it; measured with seven variants)"),
+    (r"^k_band_levels<(true|false), true, 1, false>$", "s_nop", 80,
+     "the rigidity instantiations get the same row schedule by NOT holding the per-lane predicates as scalar-register pairs (LEAN in "
+     "k_levels.hip): 50 nops, of which 32 are single wait states between the prefetch loads; 138 with the VCC-serialised rows"),
     (r"^k_band_update_tw<4, ", "v_readfirstlane_b32", 40,
      "plane pointers in scalar registers (uni_ptr): from the descriptor's vector loads they arrive in VGPRs and every row paid "
      "4 v_readfirstlane + hazard nops (202 in the kernel)"),
