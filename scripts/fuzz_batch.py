@@ -27,6 +27,8 @@ lib = e.lib
 for f in ("lqrhip_set_update_mode", "lqrhip_set_sub_batches"):
     getattr(lib, f).argtypes = [ctypes.c_int]
 fails = FC.Failures(lib)
+if os.environ.get("LQR_LV_DBG"):        # k_band_levels' experiment switches (4 no near copy, 8 an image's slots on different XCDs)
+    lib.lqrhip_band_levels_debug.argtypes = [ctypes.c_int]; lib.lqrhip_band_levels_debug(int(os.environ["LQR_LV_DBG"]))
 n = 0
 while budget.more(n):
     kind = int(rng.integers(0, 3))

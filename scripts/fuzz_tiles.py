@@ -21,6 +21,8 @@ lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]; lib.lqrhip_set_band_tiles.
 lib.lqrhip_set_band_levels.argtypes = [ctypes.c_int]
 levels = bool(os.environ.get("FUZZ_LEVELS"))
 fails = FC.Failures(lib)
+if os.environ.get("LQR_LV_DBG"):        # k_band_levels' experiment switches (4 no near copy, 8 an image's slots on different XCDs)
+    lib.lqrhip_band_levels_debug.argtypes = [ctypes.c_int]; lib.lqrhip_band_levels_debug(int(os.environ["LQR_LV_DBG"]))
 n = 0
 try:
     while budget.more(n):
