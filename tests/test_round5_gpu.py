@@ -7,6 +7,8 @@
   resizes in both directions with the kernel forced (update mode 5) on single images.
 * k_band_levels' two copies of every hand-over word: with the near (L2-resident) copy off, and with an image's slots placed on
   different XCDs (where the near copy is never seen and every fourth poll, of the write-through copy, carries the protocol).
+* k_dp_tile_p's tile numbering (the workgroups of one XCD hold consecutive tiles) and near copies: round 4's numbering and "no near
+  copies" (lqrhip_dp_tile_debug 2 / 1) give the same results on a single image and on a group of 4.
 * lqrhip_moved_bytes: the bytes the carves had to move, as k_vpath* counts them, against a count made from the seam maps.
 """
 import ctypes
@@ -152,6 +154,37 @@ def test_band_levels_general_forced_on_single_images(oracle, engine, variant, sl
         H.assert_same(a, b, "levels general %s, %d slots" % (variant, slots))
     finally:
         lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_levels(-1)
+
+
+@pytest.mark.parametrize("dbg", [1, 2])
+def test_dp_tile_p_tile_numbering_and_near_copies(oracle, engine, dbg):
+    """1: no near copies; 2: tile = workgroup index (neighbours on different XCDs, no near copies) -- a single image in both directions
+    (the plug-in's own call shape: k_dp_tile_p<UPDATE> per seam, E5 at the side switches) and a lock-step group of 4"""
+    lib = engine.lib
+    lib.lqrhip_dp_tile_debug.argtypes = [ctypes.c_int]
+    lib.lqrhip_dp_tile_debug(dbg)
+    try:
+        img = D.photo_like(1500, 400, 77)
+        a = H.run_case(oracle, img, 1440, 380, output_seams=True)
+        b = H.run_case(engine, img, 1440, 380, output_seams=True)
+        H.assert_same(a, b, "k_dp_tile_p, debug %d" % dbg)
+        w, h, n = 1000, 260, 4
+        imgs = [D.photo_like(w, h, 9300 + i) if i % 2 else D.noise(w, h, 9300 + i) for i in range(n)]
+        cs = [L.Carver(engine, im).configure() for im in imgs]
+        lib.lqrhip_prof_reset(); lib.lqrhip_prof_enable(1)
+        try:
+            assert L.resize_batch(engine, cs, w - 50, h) == L.LQR_OK
+        finally:
+            lib.lqrhip_prof_enable(0)
+        assert prof_launches(lib, "dp_update_tiled") > 0
+        for c, im in zip(cs, imgs):
+            ref = H.run_case(oracle, im, w - 50, h)
+            assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"])
+            assert np.array_equal(c.read_image(), ref["image"])
+        for c in cs:
+            c.destroy()
+    finally:
+        lib.lqrhip_dp_tile_debug(0)
 
 
 @pytest.mark.parametrize("dbg", [4, 8, 12])
