@@ -1308,8 +1308,10 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
                 ProfScope ps("band_levels", b->stream, 0);
                 if ((rc = launch_band_levels(b, k, wnew, h, leftright_next, PL, rigm))) return rc;
             }
+#ifndef LQR_EXP_NO_SWEEP        // (experiment builds only: what the almost always empty launch costs; results are wrong when an image stopped)
             ProfScope ps("dp_update", b->stream, 0);
             if ((rc = launch_dp<true>(b, k, wnew, h, leftright_next))) return rc;
+#endif
             HIPCK(hipGetLastError());
             return 0;
         }
