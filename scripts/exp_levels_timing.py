@@ -11,7 +11,7 @@ P = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 W, H = 3840, 2160
 eng = L.Api(os.path.join(os.path.dirname(L.ENGINE_LIB), os.environ.get("LQR_TIMING_LIB", "liblqr-hip-timing.so")), ""); lib = eng.lib
 for f in ("lqrhip_set_update_mode", "lqrhip_set_sub_batches", "lqrhip_set_band_levels"): getattr(lib, f).argtypes = [C.c_int]
-lib.lqrhip_set_update_mode(5); lib.lqrhip_set_sub_batches(1); lib.lqrhip_set_band_levels(P)
+lib.lqrhip_set_update_mode(5); lib.lqrhip_set_sub_batches(int(os.environ.get("LQR_EXP_STREAMS", "1"))); lib.lqrhip_set_band_levels(P)
 rng = np.random.default_rng(5)
 imgs = [rng.integers(0, 256, (H, W, 4), dtype=np.uint8) for _ in range(n)]
 for im in imgs: im[..., 3] = 255
