@@ -403,8 +403,12 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
             LDS_FLAG(s_fail) = 2;
             passed = false;
         }
-        if (passed && LDS_FLAG(s_fail) == 0) t = my_tile(A, mine ? 0 : 1);
-        if (!mine && t < 0 && passed && lane == 0 && LDS_FLAG(s_fail) == 0) {       // no second tile: said right away
+        // (no look at s_fail here: a partner that stops the image or times out in this iteration is not waited for -- what this wave
+        // then computes or publishes for level L is never stored nor read, every slot takes the same decision and leaves at the
+        // barrier below; an LDS read is ~130 cycles of a level's ~8 700.  The read in front of the word store STAYS: without it
+        // the compiler's schedule of the row loop flips to the slow one)
+        if (passed) t = my_tile(A, mine ? 0 : 1);
+        if (!mine && t < 0 && passed && lane == 0) {       // no second tile: said right away
             const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 10) | (unsigned) (L + 1)) << 32;
             gu64 *fdst = flagw + (size_t) (L & 1) * 2 * LV_PMAX + 2 * slot + 1;
             if (!(dbg & 4)) __hip_atomic_store(fdst + near_off, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
