@@ -371,14 +371,18 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
                     // "left 32 changed", or the tile to its left "right 32 changed" (six words, fetched across the lanes; one ballot)
                     const int wl = (int) (unsigned) fw;
                     bool act = false;
+                    unsigned wo[2], wr[2], wlf[2];          // (all six fetches issued before the first is waited for: one LDS latency instead of two)
 #pragma unroll
                     for (int i = 0; i < 2; i++) {
-                        const unsigned wo = (unsigned) __builtin_amdgcn_ds_bpermute((ix_own + i) << 2, wl);
-                        const unsigned wr = (unsigned) __builtin_amdgcn_ds_bpermute((ix_right + i) << 2, wl);
-                        const unsigned wlf = (unsigned) __builtin_amdgcn_ds_bpermute((ix_left + i) << 2, wl);
-                        act |= (wo & 0x900u) == 0x900u && (int) (wo & 0xffu) == lane;
-                        act |= (wr & 0xa00u) == 0xa00u && (int) (wr & 0xffu) == lane + 1;
-                        act |= (wlf & 0xc00u) == 0xc00u && (int) (wlf & 0xffu) == lane - 1;
+                        wo[i] = (unsigned) __builtin_amdgcn_ds_bpermute((ix_own + i) << 2, wl);
+                        wr[i] = (unsigned) __builtin_amdgcn_ds_bpermute((ix_right + i) << 2, wl);
+                        wlf[i] = (unsigned) __builtin_amdgcn_ds_bpermute((ix_left + i) << 2, wl);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        act |= (wo[i] & 0x900u) == 0x900u && (int) (wo[i] & 0xffu) == lane;
+                        act |= (wr[i] & 0xa00u) == 0xa00u && (int) (wr[i] & 0xffu) == lane + 1;
+                        act |= (wlf[i] & 0xc00u) == 0xc00u && (int) (wlf[i] & 0xffu) == lane - 1;
                     }
                     A.lo |= __ballot(act && lane < ntiles);
                     have_g = spec_t >= 0;
