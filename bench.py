@@ -96,10 +96,7 @@ def parse():
                     help="HIP streams the batch is split over (chain kernels of one sub-batch under the carve of another); "
                          "0 = the engine's choice: 4 for 32 images and more, given GPU_MAX_HW_QUEUES >= 8 (set above)")
     ap.add_argument("--update-mode", type=int, default=-1,
-                    help="update_mmap kernel: -1 the engine's choice, 0 band (k_band_update_tw), 1 tiled full width, 2 band-mw, 4 k_band_tiles, 5 k_band_levels")
-    ap.add_argument("--band-tiles", type=int, default=-1,
-                    help="tiles per image of the multi-CU band update k_band_tiles: -1 the engine's choice, 0 never (k_band_update_tw), n at most n")
-    ap.add_argument("--band-tiles-reserve", type=int, default=-1, help="how many of those are reserve tiles (-1: a third)")
+                    help="update_mmap kernel: -1 the engine's choice, 0 band (k_band_update_tw), 1 tiled full width, 2 band-mw, 3 generic, 5 k_band_levels")
     ap.add_argument("--band-levels", type=int, default=-1,
                     help="slots per image of k_band_levels (update mode 5): -1 the engine's choice, 0 never, n exactly n")
     ap.add_argument("--dp-px", type=int, default=0, help="pin the persistent tiled sweep's pixels per lane (2 or 4; 0: by batch size)")
@@ -193,7 +190,7 @@ def config5_masks(w, h, rigmask):
 KERNEL_NAMES = {
     "carve": (["k_carve"], ["k_carve"]),
     "vpath": (["k_vpath1", "k_vpath"], ["k_vpath1", "k_vpath"]),
-    "band_update": (["k_band_update_tw", "k_band_tiles", "k_band_update_mw", "k_band_update"], ["k_band_tiles", "k_band_update_tw", "k_band_update"]),
+    "band_update": (["k_band_update_tw", "k_band_update_mw", "k_band_update"], ["k_band_update_tw", "k_band_update"]),
     "band_levels": (["k_band_levels"], ["k_band_levels"]),
     "dp_update": (["k_dp_sweep"], ["k_dp_sweep"]),
     "dp_update_tiled": (["k_dp_tile_p"], ["k_dp_tile_p"]),
@@ -280,10 +277,6 @@ def main():
     lib.lqrhip_sub_batches.argtypes = [C.c_int]
     lib.lqrhip_set_update_mode.argtypes = [C.c_int]
     lib.lqrhip_set_update_mode(args.update_mode)
-    lib.lqrhip_set_band_tiles.argtypes = [C.c_int]
-    lib.lqrhip_set_band_tiles(args.band_tiles)
-    lib.lqrhip_set_band_tiles_reserve.argtypes = [C.c_int]
-    lib.lqrhip_set_band_tiles_reserve(args.band_tiles_reserve)
     lib.lqrhip_set_band_levels.argtypes = [C.c_int]
     lib.lqrhip_set_band_levels(args.band_levels)
     if os.environ.get("LQR_LV_DBG"):
@@ -645,10 +638,11 @@ def main():
         return result
 
     result = measure(args.workload, args.steps, args.warmup, True)
-    if hasattr(lib, "lqrhip_band_tiles_stats"):
+    if hasattr(lib, "lqrhip_fault_stats"):        # a bench line made with a redone session says so
         st = (C.c_ulonglong * 8)()
-        if lib.lqrhip_band_tiles_stats(st, 1) == 0 and any(st[i] for i in range(4)):
-            result["band_tiles_stats"] = {"uncovered_images": st[0], "aborted_images": st[1], "reserve_tiles_woken": st[2], "requests_without_reserve": st[3]}
+        if lib.lqrhip_fault_stats(st, 0) == 0 and any(st[i] for i in range(7)):
+            result["fault_stats"] = {"spin_timeouts": st[0], "failed_predictions": st[1], "seam_log_check_failures": st[2], "level_check_failures": st[3],
+                                     "sessions_rolled_back": st[4], "sessions_redone_without_spin_kernels": st[6]}
     if hasattr(lib, "lqrhip_band_levels_stats"):
         st = (C.c_ulonglong * 8)()
         if lib.lqrhip_band_levels_stats(st, 1) == 0 and any(st[i] for i in range(4)):

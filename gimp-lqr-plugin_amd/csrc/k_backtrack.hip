@@ -85,6 +85,7 @@ __device__ __forceinline__ void publish_side(const GCarver &c, int org, int acc,
 }
 extern "C" int lqrhip_moved_bytes(unsigned long long *out, int reset)
 {
+    if (lqrhip_init() < 0) return -1;          // the symbol of the device the library selected (LOCAL_RANK), not device 0's
     (void) hipDeviceSynchronize();
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_moved_bytes), sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) { unsigned long long z = 0; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_moved_bytes), &z, sizeof z); }

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h
     const GCarver c = gview_phys(cs[blockIdx.y]);
     const int org = c.flags[FLAG_ORG_PREV], side = c.flags[FLAG_SIDE];      // published by k_vpath* for this seam
     const int lane = threadIdx.x & 63;
-    if (blockIdx.x == 0 && threadIdx.x == 0) c.flags[FLAG_OVF_ROW] = h;       // k_band_tiles lowers it with atomic mins; the other band kernels overwrite it
+    if (blockIdx.x == 0 && threadIdx.x == 0) c.flags[FLAG_OVF_ROW] = h;       // the band kernels lower / overwrite it when they hand rows over to k_dp_sweep<UPDATE>
     for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < h; y += gridDim.x * 4) carve_row(c, org, side, y, w, stride, delta, move_dp, lane);
 }
 

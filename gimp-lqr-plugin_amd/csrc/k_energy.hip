@@ -27,6 +27,40 @@ __global__ void k_wk_init(const DevCarver *cs, int w, int h, int stride, int ch)
     if (c.rig) c.rig[o] = r;
 }
 
+// The same from a carver that is NOT flat (round 6: a session redone after a fault, or working planes lost on a multi-size
+// image): the carved frame is the pixels of the base layout that have no level yet (vs == 0), in order -- what k_vs_commit
+// ranks.  One block per row, ballot-rank compaction; the tail of the row is zero-filled as k_wk_init does.
+__global__ __launch_bounds__(256) void k_wk_init_visible(const DevCarver *cs, int w0, int h, int stride, int ch)
+{
+    __shared__ int s_wave[4];
+    const GCarver c = gview_phys(cs[blockIdx.y]);
+    const int y = blockIdx.x, tid = threadIdx.x;
+    if (y == 0 && tid == 0) { c.flags[FLAG_ORG] = 0; c.flags[FLAG_ORG_PREV] = 0; c.flags[FLAG_SIDE] = 0; }
+    const size_t ri = (size_t) y * w0, ro = (size_t) y * stride;
+    int carry = 0;
+    for (int base = 0; base < w0; base += 256) {
+        const int col = base + tid;
+        const bool keep = (col < w0) && c.vs[ri + col] == 0;
+        int total;
+        const int rank = carry + block_rank_256(keep, s_wave, total);
+        if (keep && rank < stride) {
+            const gu8 *s = c.rgb0 + (ri + col) * ch;
+            uint32_t p = 0;
+            if (ch == 4) p = *(const gu32 *) s;
+            else for (int k = 0; k < ch; k++) p |= (uint32_t) s[k] << (8 * k);
+            c.pix[ro + rank] = p;
+            if (c.bias) c.bias[ro + rank] = c.bias0 ? c.bias0[ri + col] : 0.0f;
+            if (c.rig) c.rig[ro + rank] = c.rig0 ? c.rig0[ri + col] : 0.0f;
+        }
+        carry += total;
+    }
+    for (int x = carry + tid; x < stride; x += 256) {
+        c.pix[ro + x] = 0u;
+        if (c.bias) c.bias[ro + x] = 0.0f;
+        if (c.rig) c.rig[ro + x] = 0.0f;
+    }
+}
+
 template <int NRG>
 __global__ void k_emap_full(const DevCarver *cs, DpK p, int w, int h, int stride)
 {

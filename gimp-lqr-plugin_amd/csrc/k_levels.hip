@@ -394,6 +394,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
             while (LDS_FLAG(s_polled) < L && LDS_FLAG(s_fail) != 1 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
             passed = LDS_FLAG(s_polled) >= L;
             if (passed) A.lo = uni64(s_A[L & 1]);
+            else if (LDS_FLAG(s_fail) != 1) { LDS_FLAG(s_fail) = 1; if (lane == 0) dev_fail(dev_err, DEVERR_TILE_TIMEOUT); }     // (never fall through silently)
             LTT(2);
         }
         // ---- STORE: level L - 1 is final and every slot has consumed its inputs
@@ -493,9 +494,10 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
     if (lane == 0 && n_sync) atomicAdd(&g_lv_stats[1], (unsigned long long) n_sync);
 }
 
-extern "C" void lqrhip_band_levels_debug(int v) { (void) hipMemcpyToSymbol(HIP_SYMBOL(g_lv_dbg), &v, sizeof v); }
+extern "C" void lqrhip_band_levels_debug(int v) { if (lqrhip_init() < 0) return; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_lv_dbg), &v, sizeof v); }
 extern "C" int lqrhip_band_levels_stats(unsigned long long *out, int reset)
 {
+    if (lqrhip_init() < 0) return -1;          // the symbol of the device the library selected (LOCAL_RANK), not device 0's
     (void) hipDeviceSynchronize();
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lv_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
     if (reset) { unsigned long long z[8] = {0}; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_lv_stats), z, sizeof z); }

@@ -63,9 +63,18 @@ __device__ __forceinline__ void px_avg(uint8_t *dst, const uint8_t *a, const uin
 // E14: one block per row (blockIdx.x) of one carver of the batch (blockIdx.y: every carver and attached carver of the
 // batch in ONE launch -- a launch per carver leaves most of the chip idle behind each row's serial rank scan).
 // dup(c) = the seam was computed in this session.
-__global__ __launch_bounds__(256) void k_inflate(const InflateDev *jobs, int w0, int w1, int l, int max_level)
+// Fused self-check (round 6): the levels this session wrote -- [2 max_level - 1, l + max_level - 1] -- must each occur exactly
+// once in every row (k_vs_commit's contract).  The pass reads every level anyway: a bit per level in LDS (atomicOr) finds a level
+// that occurs twice, the row's dup count a missing one.  A failure goes to the host-visible error word (DEVERR_LEVELS); the host
+// then does not adopt the inflated planes, rolls the session back and redoes it (host/lqr_carver.c, group_build_maps).
+__global__ __launch_bounds__(256) void k_inflate(const InflateDev *jobs, int w0, int w1, int l, int max_level, int *dev_err)
 {
     __shared__ int s_wave[4];
+    extern __shared__ unsigned s_seen[];          // [(n_levels + 31) / 32]
+    const int n_levels = l - max_level + 1, lvl0 = 2 * max_level - 1;
+    for (int i = threadIdx.x; i < (n_levels + 31) / 32; i += 256) s_seen[i] = 0u;
+    __syncthreads();
+    bool twice = false;
     const InflateDev j = jobs[blockIdx.y];
     const uint8_t *rgb = j.rgb;
     const int32_t *vs = j.vs;
@@ -82,6 +91,7 @@ __global__ __launch_bounds__(256) void k_inflate(const InflateDev *jobs, int w0,
         int col = base + tid;
         int v = (col < w0) ? vrow[col] : 0;
         bool dup = (col < w0) && v != 0 && v <= l + max_level - 1 && v >= 2 * max_level - 1;
+        if (dup) twice |= (atomicOr(&s_seen[(v - lvl0) >> 5], 1u << ((v - lvl0) & 31)) >> ((v - lvl0) & 31)) & 1u;
         int total;
         int rank = carry + block_rank_256(dup, s_wave, total);   // dups strictly before col
         if (col < w0) {
@@ -100,6 +110,54 @@ __global__ __launch_bounds__(256) void k_inflate(const InflateDev *jobs, int w0,
             if (nvs) nvs[ro + z] = v ? v + l - max_level + 1 : 0;
         }
         carry += total;
+    }
+    if (dev_err && (twice || (tid == 0 && carry != n_levels))) dev_fail(dev_err, DEVERR_LEVELS);
+}
+
+// Session self-check before the levels are committed (round 6): the session's seam log must describe seams -- entry k of
+// every row inside the frame that seam was found in (0 <= x < wc0 - k), and delta_x-connected from row to row.  Anything
+// else means a kernel of the seam loop misbehaved; the host rolls the session back and redoes it on the non-spinning kernels.
+// One block per ROWS rows of one image; the log is n_seams x h ints (1.7 MB for 200 seams of a 4K image).
+__global__ __launch_bounds__(256) void k_seam_check(const DevCarver *cs, int h, int wc0, int n_seams, int delta, int *dev_err)
+{
+    const GCarver c = gview_phys(cs[blockIdx.y]);
+    const int y = blockIdx.x * 256 + threadIdx.x;
+    if (y >= h) return;
+    bool bad = false;
+    for (int k = 0; k < n_seams; k++) {
+        const int x = c.seam_log[(size_t) k * h + y];
+        bad |= (x < 0) || (x >= wc0 - k);
+        if (y > 0) { const int xu = c.seam_log[(size_t) k * h + y - 1]; bad |= (x - xu > delta) || (xu - x > delta); }
+    }
+    if (bad) dev_fail(dev_err, DEVERR_SEAMLOG);
+}
+
+// Undo a session's commit: levels at or above first_level are this session's (every older level is below it: inflate shifts
+// the levels of a finished session to [.., 2 depth - 2] and the next session starts at 2 depth - 1), plus finish_vsmap's w0.
+__global__ __launch_bounds__(256) void k_vs_rollback(const DevCarver *cs, size_t n, int first_level, int finish_level)
+{
+    const GCarver c = gview_phys(cs[blockIdx.y]);
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) {
+        const int v = c.vs[i];
+        if (v >= first_level || (finish_level > 0 && v == finish_level)) c.vs[i] = 0;
+    }
+}
+
+// Fault injection for tests/test_faults_gpu.py (lqrhip_debug_inject): damage one entry of the session's seam log (what = 0: out of
+// the frame, 1: a jump of 40 columns), or clear / duplicate one committed level in the base layout (2 / 3)
+__global__ void k_inject(const DevCarver *cs, int what, int h, int w0, int log_index, int first_level)
+{
+    const GCarver c = gview_phys(cs[0]);
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int y = h / 2;
+    if (what == 0) c.seam_log[(size_t) log_index * h + y] = -7;
+    else if (what == 1) { gi32 *e = c.seam_log + (size_t) log_index * h + y; *e = (*e >= 40) ? *e - 40 : *e + 40; }
+    else {
+        gi32 *row = c.vs + (size_t) y * w0;
+        int at = -1, other = -1;
+        for (int x = 0; x < w0; x++) { if (row[x] == first_level) at = x; else if (row[x] == first_level + 1) other = x; }
+        if (what == 2 && at >= 0) row[at] = 0;
+        if (what == 3 && at >= 0 && other >= 0) row[other] = first_level;
     }
 }
 

@@ -7,7 +7,7 @@
 //   k_backtrack.hip  E7              k_vpath, k_vpath1 (they also pick the side the carve moves)
 //   k_carve.hip      E8              k_carve
 //   k_band.hip       E5/E9           k_dp_sweep, k_band_update, k_band_update_mw, k_band_update_tw (one workgroup per image)
-//   k_tiles.hip      E5/E9           k_dp_tile, k_dp_tile_p, k_band_tiles (an image spread over several compute units)
+//   k_tiles.hip      E5/E9           k_dp_tile, k_dp_tile_p (an image spread over several compute units)
 //   k_levels.hip     E9              k_band_levels (the band on several compute units, tiles assigned level by level)
 //   k_oneoff.hip     E8(vs)/E11/E12/E14, auto-size  k_vs_commit, k_inflate, k_compact(_jobs), k_transpose, k_mask_line_max
 //   lqr_shim.hip     the lqrhip_* C ABI of include/lqr_hip.h: allocation cache, batches, the per-seam launch sequence
@@ -181,6 +181,8 @@ struct DpK {
 // leaves; the host finds it at its next synchronisation and returns LQRHIP_EHIP (-> LQR_ERROR).
 #define DEVERR_TILE_TIMEOUT 1
 #define DEVERR_BAND_PREDICTION 2
+#define DEVERR_SEAMLOG 3            // k_seam_check: the session's seam log does not describe seams
+#define DEVERR_LEVELS 4             // k_inflate: a level of the session missing or twice in a row of the base layout
 __device__ __forceinline__ void dev_fail(int *flag, int code)
 {
     __hip_atomic_store(flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -488,12 +490,6 @@ static_assert(dpp_halo(2) % (2 * DPP_R) == 0 && dpp_halo(4) % (2 * DPP_R) == 0, 
 constexpr int DPP_BLK_BITS = 12;                // bits of the block index in a granule's tag
 #define DPT_ROWS 32
 #define DPT_OWN 192
-#define BT_BLK_ABORT 0x7ffu
-constexpr int BT_MAX_BLK = 256;           // blocks of 32 rows: images up to 8192 rows (the tag has 11 bits for the block)
-constexpr int BT_T_MAX = 12;              // workgroups per image: base tiles + reserve tiles
-constexpr int BT_HDR = 16;                // 8-byte words of an image's header in the exchange area: [0] base tiles finished,
-                                          // [1] requests made, [2 ..] the requests {epoch << 32 | side << 31 | start block << 16 | tile}
-constexpr int BT_NEVER = 1 << 30;
 // k_band_levels (k_levels.hip): slots per image at most, tiles per image at most (one 64-bit mask: rows up to 4096 px)
 constexpr int LV_PMAX = 16;
 constexpr int LV_MAX_TILES = 64;

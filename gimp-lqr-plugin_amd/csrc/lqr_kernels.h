@@ -7,6 +7,7 @@
 
 // k_energy.hip
 __global__ void k_wk_init(const DevCarver *cs, int w, int h, int stride, int ch);
+__global__ __launch_bounds__(256) void k_wk_init_visible(const DevCarver *cs, int w0, int h, int stride, int ch);
 template <int NRG> __global__ void k_emap_full(const DevCarver *cs, DpK p, int w, int h, int stride);
 __global__ void k_mask_add(float *plane, int w0, const uint8_t *mask, int channels, int mw, int x0, int y0, int x1, int y1,
                            int nx, int ny, int transposed, int is_rig, int bias_factor);
@@ -30,8 +31,6 @@ template <int NW, bool LR, bool RIG> __global__ __launch_bounds__(128 * NW) void
 template <bool LR, bool RIG> __global__ __launch_bounds__(64) void k_dp_tile(const DevCarver *cs, DpK p, int w, int h, int stride, int y0);
 template <int PX, bool LR, bool RIG, bool UPDATE, int DELTA = 1, bool RIGM = false>
 __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err);
-template <bool LR, bool RIG>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_band_tiles(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err, int t_base, int hset);
 
 // k_levels.hip
 template <bool LR, bool RIG, int DELTA, bool RIGM>
@@ -39,7 +38,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // k_oneoff.hip
 __global__ __launch_bounds__(256) void k_vs_commit(const DevCarver *cs, int w0, int h0, int wc0, int n_seams, int first_level, int finish);
-__global__ __launch_bounds__(256) void k_inflate(const InflateDev *jobs, int w0, int w1, int l, int max_level);
+__global__ __launch_bounds__(256) void k_inflate(const InflateDev *jobs, int w0, int w1, int l, int max_level, int *dev_err);
+__global__ __launch_bounds__(256) void k_seam_check(const DevCarver *cs, int h, int wc0, int n_seams, int delta, int *dev_err);
+__global__ __launch_bounds__(256) void k_vs_rollback(const DevCarver *cs, size_t n, int first_level, int finish_level);
+__global__ void k_inject(const DevCarver *cs, int what, int h, int w0, int log_index, int first_level);
 __global__ __launch_bounds__(256) void k_compact(const uint8_t *rgb, const int32_t *vs, const float *bias, const float *rig,
                                                   uint8_t *nrgb, float *nbias, float *nrig, int32_t *nvmap, int w0, int w, int ch, int level, int depth);
 __global__ __launch_bounds__(256) void k_compact_jobs(const InflateDev *jobs, int w0, int w, int level);

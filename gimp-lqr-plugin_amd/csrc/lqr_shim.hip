@@ -27,20 +27,7 @@ static int *g_dev_err = nullptr;           // its device address
 static int g_dpp_max_wgs = 0;
 static int g_dpp_max_wgs_plain = 0, g_dpp_max_wgs_general = 0;      // ... of the plain / the delta_x = 2..4, rigidity-mask instantiations
 static int g_dpp_max_wgs_px4 = 0;                                   // ... of the plain 4-px instantiations alone (fewer registers than the 2-px ones)
-static int g_dpp_max_wgs_tiles = 0;                                 // ... of k_band_tiles
 static int g_dpp_max_wgs_levels = 0;                                // ... of k_band_levels
-
-static int band_tiles_resident(int n_cu)
-{
-    int per_cu = 1 << 20;
-    auto q = [&](auto kern) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 128, 0) != hipSuccess) { (void) hipGetLastError(); n = 0; }
-        per_cu = std::min(per_cu, n);
-    };
-    q(k_band_tiles<false, false>); q(k_band_tiles<false, true>); q(k_band_tiles<true, false>); q(k_band_tiles<true, true>);
-    return std::max(0, per_cu - 1) * n_cu;
-}
 
 // ===========================================================================
 // host side of the shim
@@ -74,12 +61,14 @@ struct LqrHipBatch {
     size_t exch_elems = 0;
     int exch_ntiles = 0, exch_n = 0, exch_px = 0;      // geometry the exchange area was last laid out for
     int tile_epoch = 0;                     // launches of k_dp_tile_p on this batch (part of the granule tags)
-    int bt_launches = 0;                    // launches of k_band_tiles on this batch (which of the two header sets)
     bool dirty = true;
     int shared_n = 1;                       // ... how many batches of the group there are (lqrhip_batch_set_shared)
     bool shared = false;                    // other batches of the same group run concurrently on their own streams:
                                             // no persistent (spin-waiting, co-residency-dependent) kernels
+    bool safe = false;                      // a session is being redone after a fault: kernels without spin waits only
 };
+static bool g_no_spin = false;             // set by a spin time-out (check_dev_error): the process stays on the non-spinning kernels
+static inline bool no_spin(const LqrHipBatch *b) { return b->safe || g_no_spin; }
 
 struct ProfRec {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -122,7 +111,6 @@ static int dpp_resident_workgroups(int dev)
     QG(false, false); QG(false, true); QG(true, false); QG(true, true);
 #undef QG
     g_dpp_max_wgs_general = std::max(0, per_cu - 1) * prop.multiProcessorCount;
-    g_dpp_max_wgs_tiles = band_tiles_resident(prop.multiProcessorCount);
     {
         int per_cu = 1 << 20;
         auto ql = [&](auto kern) {
@@ -192,22 +180,47 @@ extern "C" int lqrhip_init(void)
     return dev;
 }
 
-// A kernel recorded a failure (dev_fail): report it once, as an error return, and clear the word.  The word is one per
-// process and whoever synchronises first finds it -- not necessarily the batch whose kernel failed.  A persistent sweep that
-// gave up half way leaves its batch's exchange area (tags, finished-tile counter) and, for an update, the plane pointers
-// in the device descriptors in an unknown state, so EVERY live batch is marked for a fresh lay-out of both.
+// A kernel recorded a failure (dev_fail): report it once, as LQRHIP_EFAULT, and clear the word.  The word is one per
+// process and whoever synchronises first finds it -- not necessarily the batch whose kernel failed (the host rolls back and
+// redoes the session of EVERY sub-batch of the group).  A persistent sweep that gave up half way leaves its batch's exchange
+// area (tags, finished-tile counter) and, for an update, the plane pointers in the device descriptors in an unknown state,
+// so EVERY live batch is marked for a fresh lay-out of both.
 static std::vector<LqrHipBatch *> g_live_batches;
 static void invalidate_all_batches(void);
+// [0] spin time-outs, [1] failed activity predictions, [2] seam-log self-check failures, [3] level self-check failures,
+// [4] sessions rolled back, [5] faults injected (lqrhip_debug_inject), [6] sessions carved on the non-spinning kernels
+static unsigned long long g_fault_stats[8];
+// After a spin time-out the persistent (co-residency-dependent) kernels are not chosen again in this process: a device that is
+// shared or partitioned now will be in a minute, and every further resize would first wait out the time-out (~0.3 s) and then be
+// redone.  lqrhip_set_no_spin(0) re-arms them (tests).
+extern "C" void lqrhip_set_no_spin(int on) { g_no_spin = on != 0; }
+extern "C" int lqrhip_get_no_spin(void) { return g_no_spin ? 1 : 0; }
 static int check_dev_error(void)
 {
     if (!g_dev_err_host || *g_dev_err_host == 0) return 0;
     const int code = *g_dev_err_host;
     *g_dev_err_host = 0;
     invalidate_all_batches();
-    g_err = code == DEVERR_TILE_TIMEOUT ? "persistent tiled DP sweep: a neighbour tile never became resident (GPU shared or partitioned?); "
-                                          "results of this resize are invalid"
-                                        : "band update: activity prediction failed; results of this resize are invalid";
-    return LQRHIP_EHIP;
+    switch (code) {
+    case DEVERR_TILE_TIMEOUT:
+        g_fault_stats[0]++;
+        if (!g_no_spin) fprintf(stderr, "liblqr-hip: a persistent kernel's workgroups were not co-resident in time (GPU shared or partitioned?): "
+                                        "this process now uses the non-spinning kernels\n");
+        g_no_spin = true;
+        g_err = "persistent tiled DP sweep: a neighbour tile never became resident (GPU shared or partitioned?); results of this session are invalid";
+        break;
+    case DEVERR_BAND_PREDICTION: g_fault_stats[1]++; g_err = "band update: activity prediction failed; results of this session are invalid"; break;
+    case DEVERR_SEAMLOG: g_fault_stats[2]++; g_err = "self-check: the session's seam log does not describe delta_x-connected seams inside the frame; results of this session are invalid"; break;
+    case DEVERR_LEVELS: g_fault_stats[3]++; g_err = "self-check: a level of the session is missing or occurs twice in a row of the visibility map; results of this session are invalid"; break;
+    default: g_err = "device-side failure " + std::to_string(code) + "; results of this session are invalid"; break;
+    }
+    return LQRHIP_EFAULT;
+}
+extern "C" int lqrhip_fault_stats(unsigned long long *out8, int reset)
+{
+    memcpy(out8, g_fault_stats, sizeof g_fault_stats);
+    if (reset) memset(g_fault_stats, 0, sizeof g_fault_stats);
+    return 0;
 }
 
 // Device allocations go through a small size-class cache: the carve path allocates and frees
@@ -668,6 +681,7 @@ extern "C" int lqrhip_sub_batches(int n)
 }
 
 extern "C" void lqrhip_batch_set_shared(LqrHipBatch *b, int shared) { b->shared = shared != 0; b->shared_n = shared > 1 ? shared : 1; }
+extern "C" void lqrhip_batch_set_safe(LqrHipBatch *b, int safe) { b->safe = safe != 0; if (safe) g_fault_stats[6]++; }
 
 extern "C" LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n)
 {
@@ -834,7 +848,7 @@ extern "C" int lqrhip_prof_get_union(const char *kernel, double *ms_union)
     return 0;
 }
 
-extern "C" int lqrhip_wk_init(LqrHipBatch *b)
+extern "C" int lqrhip_wk_init(LqrHipBatch *b, int from_visible)
 {
     LqrHipCarver *c0 = b->cs[0];
     int w = c0->w0, h = c0->h0, rc;
@@ -844,8 +858,12 @@ extern "C" int lqrhip_wk_init(LqrHipBatch *b)
     }
     if ((rc = batch_upload(b))) return rc;
     for (auto *c : b->cs) c->frozen_epoch = 0;
-    dim3 grid((c0->stride + 255) / 256, h, (unsigned) b->cs.size());
-    hipLaunchKernelGGL(k_wk_init, grid, dim3(256), 0, b->stream, b->d_desc, w, h, c0->stride, c0->ch);
+    if (from_visible) {
+        hipLaunchKernelGGL(k_wk_init_visible, dim3(h, (unsigned) b->cs.size()), dim3(256), 0, b->stream, b->d_desc, w, h, c0->stride, c0->ch);
+    } else {
+        dim3 grid((c0->stride + 255) / 256, h, (unsigned) b->cs.size());
+        hipLaunchKernelGGL(k_wk_init, grid, dim3(256), 0, b->stream, b->d_desc, w, h, c0->stride, c0->ch);
+    }
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -888,7 +906,7 @@ static int launch_dp_tiled(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
 // `general`: delta_x = 2 and / or a rigidity mask (with rigidity): those instantiations exist for 2 px per lane only
 static int dp_persistent_px(const LqrHipBatch *b, int w, bool general = false, int delta = 1, int count = -1)
 {
-    if (b->shared) return 0;
+    if (b->shared || no_spin(b)) return 0;
     const int bound = general ? g_dpp_max_wgs_general : g_dpp_max_wgs;
     const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, bound) : bound;
     const size_t n = count < 0 ? b->cs.size() : (size_t) count;
@@ -1074,60 +1092,6 @@ static int frozen_catchup(LqrHipBatch *b, int to, int w_at_to, int h)
     return 0;
 }
 
-// batches up to this many pixels use the tiled full-width update (measured break-even with the band kernel at 4K, Mseams*px/s
-// tiled / band: 7 images 118 k / 97 k, 8: 130 / 109, 9: 119 / 121, 12: 130 / 139+, 16: 158 / 175+)
-// Tiles per image for k_band_tiles (0: not usable here).  All of a group's sub-batches run side by side, each with a
-// persistent grid of its own: together they must fit the residency bound of the 2-px tiled instantiations (same register
-// budget: the occupancy query below covers k_band_tiles).
-static int g_band_tiles = -1;            // -1: automatic; 0: never; n: force n tiles per image (tests)
-extern "C" void lqrhip_set_band_tiles(int t) { g_band_tiles = t; }
-static int band_tiles_T(const LqrHipBatch *b, int h)
-{
-    if (g_band_tiles == 0 || (h + 31) / 32 > BT_MAX_BLK) return 0;
-    const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_tiles) : g_dpp_max_wgs_tiles;
-    const int per_batch = limit / std::max(b->shared_n, 1);
-    int T = std::min(BT_T_MAX, per_batch / (int) std::max<size_t>(b->cs.size(), 1));
-    if (g_band_tiles > 0) T = std::min(T, g_band_tiles);
-    return T >= (g_band_tiles > 0 ? 1 : 8) ? T : 0;
-}
-// T workgroups per image: two thirds of them base tiles around the seam, the rest reserve tiles that an edge tile wakes
-// when the band comes near the edge of the set (lqrhip_set_band_tiles_reserve pins the number of reserves for tests)
-static int g_band_tiles_rsv = -1;
-extern "C" void lqrhip_set_band_tiles_reserve(int n) { g_band_tiles_rsv = n; }
-static int launch_band_tiles(LqrHipBatch *b, const DpK &k, int w, int h, int lr, int T)
-{
-    LqrHipCarver *c0 = b->cs[0];
-    const size_t n = b->cs.size();
-    int rc;
-    int n_rsv = g_band_tiles_rsv >= 0 ? std::min(g_band_tiles_rsv, T - 1) : T / 3;
-    n_rsv = std::max(0, std::min(n_rsv, BT_HDR - 2));
-    const int t_base = T - n_rsv;
-    const int ntiles_img = (w + 63) / 64;
-    const size_t need_elems = ((size_t) ntiles_img * dpp_ex_tile(2) + 2 * BT_HDR) * n;
-    if (b->exch_elems < need_elems) {
-        HIPCK(hipStreamSynchronize(b->stream));
-        dfree(b->exch);
-        b->exch_elems = 0;
-        if ((rc = dmalloc(&b->exch, need_elems))) return rc;
-        b->exch_elems = need_elems;
-        b->exch_ntiles = 0;
-    }
-    if (b->exch_ntiles != ntiles_img || b->exch_n != (int) n || b->exch_px != 102) {       // 102: this kernel's layout and tags
-        HIPCK(hipMemsetAsync(b->exch, 0, need_elems * sizeof(unsigned long long), b->stream));
-        b->exch_ntiles = ntiles_img; b->exch_n = (int) n; b->exch_px = 102;
-    }
-    // (the images' headers -- tiles finished, tickets drawn, requests -- start every launch at zero: there are two sets, a launch
-    // uses one and clears the other for the next launch; granules and request words carry the epoch)
-    const int hset = (b->bt_launches++) & 1;
-    const int epoch = 1 + ((b->tile_epoch++) % ((1 << 19) - 2));           // never 0; 19 bits above changed / active bits and block index
-    const dim3 grid(T, (unsigned) n);
-#define LAUNCH_BT(LRV, RIGV) hipLaunchKernelGGL((k_band_tiles<LRV, RIGV>), grid, dim3(128), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err, t_base, hset)
-    if (lr) { if (k.use_rig) LAUNCH_BT(true, true); else LAUNCH_BT(true, false); }
-    else { if (k.use_rig) LAUNCH_BT(false, true); else LAUNCH_BT(false, false); }
-#undef LAUNCH_BT
-    HIPCK(hipGetLastError());
-    return 0;
-}
 // Slots (workgroups) per image for k_band_levels (0: not usable here): as many as the group's images leave room for within the
 // residency bound, at most LV_PMAX; lqrhip_set_band_levels pins it (tests, experiments).  The default for large groups is 6:
 // the active tiles of a 4K level are 4.5 on average, a window of 6 consecutive tiles never collides, and 64 x 6 workgroups hold
@@ -1135,7 +1099,7 @@ static int launch_band_tiles(LqrHipBatch *b, const DpK &k, int w, int h, int lr,
 extern "C" void lqrhip_set_band_levels(int slots) { g_band_levels = slots; }
 static int band_levels_P(const LqrHipBatch *b, int w, int h, int delta)
 {
-    if (g_band_levels == 0 || delta < 1 || delta > 4 || (h + lv_rows(delta, true) - 1) / lv_rows(delta, true) > LV_MAX_LEVELS || (w + 63) / 64 > LV_MAX_TILES) return 0;
+    if (no_spin(b) || g_band_levels == 0 || delta < 1 || delta > 4 || (h + lv_rows(delta, true) - 1) / lv_rows(delta, true) > LV_MAX_LEVELS || (w + 63) / 64 > LV_MAX_TILES) return 0;
     const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_levels) : g_dpp_max_wgs_levels;
     const int per_batch = limit / std::max(b->shared_n, 1);
     int P = std::min(LV_PMAX, per_batch / (int) std::max<size_t>(b->cs.size(), 1));
@@ -1177,18 +1141,23 @@ static int launch_band_levels(LqrHipBatch *b, const DpK &k, int w, int h, int lr
     HIPCK(hipGetLastError());
     return 0;
 }
+// batches up to this many pixels use the tiled full-width update (measured break-even with the band kernel at 4K, Mseams*px/s
+// tiled / band: 7 images 118 k / 97 k, 8: 130 / 109, 9: 119 / 121, 12: 130 / 139+, 16: 158 / 175+)
 static const long long g_tiled_update_px = 8LL * 3840 * 2160;
 
 // One seam of a lock-step batch: k_vpath* (pick + backtrack, publishes the side to move) -> k_carve ->
 // k_emap_update -> one form of update_mmap (or the full DP after a side switch), all on the batch's stream.
 static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
                           int full_rebuild, int leftright_next);
+static void inject_after_step(LqrHipBatch *b, int h, int log_index);
+static void inject_after_commit(LqrHipBatch *b, int w0, int h0, int first_level);
 // LQRHIP_DUMP=<prefix> (debugging aid): after every seam step the first image's seam, flags and DP planes go to
 // <prefix>_<call>.bin -- header {w, h, stride, log_index, FLAG_COUNT}, flags, seam_x[h], m[stride * h], least[stride * h]
 extern "C" int lqrhip_seam_step(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h, int log_index, int leftright_pick,
                                 int full_rebuild, int leftright_next)
 {
     const int rc = seam_step_impl(b, p, w, h, log_index, leftright_pick, full_rebuild, leftright_next);
+    if (rc == 0) inject_after_step(b, h, log_index);
     static const char *dump = getenv("LQRHIP_DUMP");
     if (rc == 0 && dump) {
         static int call = 0;
@@ -1286,11 +1255,6 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     const bool tiled_update = fast_ok ? ((g_update_mode < 0 ? (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px : g_update_mode == 1) &&
                                          dp_persistent_ok(b, w))
                                       : (p->delta_x >= 1 && p->delta_x <= 4 && g_update_mode != 0 && g_update_mode != 2 && g_update_mode != 3 && dp_persistent_px(b, w, true, p->delta_x) != 0);
-    // Batches of 8 to ~40 images: the band spread over several CUs per image (k_band_tiles).  Measured (Mseams*px/s, 4K, tiles /
-    // k_band_update_tw or the full-width tiled update): 4 images 80 k / 93 k (the full-width tiled update stays), 8: 145 / 127,
-    // 12: 195 / 152, 16: 246 / 193, 24: 294 / 260, 32: 382 / 341, 40: 423 / 398, 48: 434 / 448, 64: 488 / 510-540 -- beyond ~500
-    // resident tile workgroups the carves of the sibling streams are starved of registers, so large groups
-    // keep k_band_update_tw.
     {
         // round 5: the band on P slots per image, tiles assigned level by level (k_band_levels): the default for groups of 8 to 64
         // images (measured, Mseams*px/s at 4K, levels / k_band_update_tw: 8 images 148 / 127, 16: 256 / 180, 48: 479 / 404).  64 images
@@ -1312,22 +1276,6 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
             ProfScope ps("dp_update", b->stream, 0);
             if ((rc = launch_dp<true>(b, k, wnew, h, leftright_next))) return rc;
 #endif
-            HIPCK(hipGetLastError());
-            return 0;
-        }
-    }
-    {
-        // round 4's k_band_tiles (static tile sets that grow on demand through reserve tiles): on request only (update mode 4) -- the
-        // level-synchronous kernel above does the same job with half the workgroups and one spin instead of four protocols, and the
-        // one unexplained failure of round 4's suite was in a run whose cases include this kernel
-        const int T = (fast_ok && g_update_mode == 4) ? band_tiles_T(b, h) : 0;
-        if (T > 0) {
-            {
-                ProfScope ps("band_update", b->stream, 0);
-                if ((rc = launch_band_tiles(b, k, wnew, h, leftright_next, T))) return rc;
-            }
-            ProfScope ps("dp_update", b->stream, 0);
-            if ((rc = launch_dp<true>(b, k, wnew, h, leftright_next))) return rc;
             HIPCK(hipGetLastError());
             return 0;
         }
@@ -1390,10 +1338,70 @@ extern "C" int lqrhip_vs_commit(LqrHipBatch *b, int w0, int h0, int wc0, int n_s
     hipLaunchKernelGGL(k_vs_commit, dim3(h0, (unsigned) b->cs.size()), dim3(256), lds, b->stream, b->d_desc, w0, h0, wc0, n_seams,
                        first_level, finish);
     HIPCK(hipGetLastError());
+    inject_after_commit(b, w0, h0, first_level);
     // the session is over: bring the frozen planes to the carved frame, the log restarts at 0
     if ((rc = frozen_catchup(b, n_seams, wc0 - n_seams, h0))) return rc;
     for (auto *c : b->cs) c->frozen_epoch = 0;
     return 0;
+}
+
+// ---- session self-check, roll-back, fault injection (round 6) ---------------------------------------------------------------
+// The seam loop's kernels are latency-bound protocols (spin barriers, data-tagged hand-overs); a defect or a device that
+// preempts them must not end in LQR_OK with a wrong map.  Two structural checks run inside every session: k_seam_check on the
+// seam log BEFORE the levels are committed, and the level count / uniqueness test fused into k_inflate.  Both cost < 1 % of a
+// session (1.7 MB of log per 4K image; the inflate pass reads the levels anyway) and are on by default.
+static int g_selfcheck = 1, g_recovery = 1;
+extern "C" void lqrhip_set_selfcheck(int on) { g_selfcheck = on != 0; }
+extern "C" void lqrhip_set_recovery(int on) { g_recovery = on != 0; }
+extern "C" int lqrhip_get_recovery(void) { return g_recovery; }
+extern "C" int lqrhip_session_check(LqrHipBatch *b, int h, int wc0, int n_seams, int delta_x)
+{
+    int rc;
+    if (!g_selfcheck || n_seams < 1) return 0;
+    if ((rc = batch_upload(b))) return rc;
+    hipLaunchKernelGGL(k_seam_check, dim3((h + 255) / 256, (unsigned) b->cs.size()), dim3(256), 0, b->stream, b->d_desc, h, wc0, n_seams, delta_x, g_dev_err);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+// Undo what a failed session left: drain the stream, drop the error record, clear the session's levels from the base layout
+// (a no-op when they were never committed).  The working planes are garbage afterwards: the host re-lays them out from the
+// base layout (lqrhip_wk_init(b, 1)) before it redoes the session.
+extern "C" int lqrhip_session_rollback(LqrHipBatch *b, int w0, int h0, int first_level, int finish)
+{
+    (void) hipStreamSynchronize(b->stream);
+    (void) hipGetLastError();
+    if (g_dev_err_host) *g_dev_err_host = 0;
+    invalidate_all_batches();
+    int rc;
+    if ((rc = batch_upload(b))) return rc;
+    const size_t n = (size_t) w0 * h0;
+    hipLaunchKernelGGL(k_vs_rollback, dim3((unsigned) std::min<size_t>((n + 255) / 256, 4096), (unsigned) b->cs.size()), dim3(256), 0, b->stream, b->d_desc, n, first_level, finish ? w0 : 0);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(b->stream));
+    for (auto *c : b->cs) c->frozen_epoch = 0;
+    g_fault_stats[4]++;
+    return 0;
+}
+// Fault injection (tests/test_faults_gpu.py).  kind 1: a spin time-out, 2: a failed activity prediction -- the error word is
+// written from the host while the kernels of seam step `at_step` of the next session run, which is exactly what the kernels see
+// when one of them gives up (they all leave their spins); 3 / 4: one entry of the seam log out of the frame / disconnected (after
+// that step); 5 / 6: one committed level cleared / duplicated (between the commit and the inflate pass).  `times`: how many
+// sessions in a row are hit (1: the redo succeeds; 2: it fails too).  0 disarms.
+static int g_inject_kind = 0, g_inject_step = 0, g_inject_times = 0;
+extern "C" void lqrhip_debug_inject(int kind, int at_step, int times) { g_inject_kind = kind; g_inject_step = at_step; g_inject_times = kind ? std::max(times, 1) : 0; }
+static void inject_after_step(LqrHipBatch *b, int h, int log_index)
+{
+    if (g_inject_times <= 0 || log_index != g_inject_step) return;
+    if (g_inject_kind == 1 || g_inject_kind == 2) { *g_dev_err_host = g_inject_kind == 1 ? DEVERR_TILE_TIMEOUT : DEVERR_BAND_PREDICTION; }
+    else if (g_inject_kind == 3 || g_inject_kind == 4) hipLaunchKernelGGL(k_inject, dim3(1), dim3(64), 0, b->stream, b->d_desc, g_inject_kind - 3, h, 0, log_index, 0);
+    else return;
+    g_inject_times--; g_fault_stats[5]++;
+}
+static void inject_after_commit(LqrHipBatch *b, int w0, int h0, int first_level)
+{
+    if (g_inject_times <= 0 || (g_inject_kind != 5 && g_inject_kind != 6)) return;
+    hipLaunchKernelGGL(k_inject, dim3(1), dim3(64), 0, b->stream, b->d_desc, g_inject_kind - 3, h0, w0, 0, first_level);
+    g_inject_times--; g_fault_stats[5]++;
 }
 
 // E14 / E11: every carver of the batch (roots and their attached carvers) goes through ONE launch (a job table in device
@@ -1462,9 +1470,11 @@ extern "C" int lqrhip_inflate(LqrHipBatch *b, int w0, int h0, int l, int max_lev
         if ((rc = pj.add(c, c->vs, nvs, (size_t) w1 * h0))) return rc;
     }
     if ((rc = pj.upload(b->stream))) return rc;
-    hipLaunchKernelGGL(k_inflate, dim3(h0, (unsigned) pj.dev.size()), dim3(256), 0, b->stream, pj.d_jobs, w0, w1, l, max_level);
+    const size_t lds = (size_t) ((l - max_level + 1 + 31) / 32 + 1) * sizeof(unsigned);      // one bit per level of the session (the fused self-check)
+    hipLaunchKernelGGL(k_inflate, dim3(h0, (unsigned) pj.dev.size()), dim3(256), lds, b->stream, pj.d_jobs, w0, w1, l, max_level, g_selfcheck ? g_dev_err : (int *) nullptr);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(b->stream));
+    if ((rc = check_dev_error())) return rc;        // nothing adopted: the staged planes go back to the pool, the host rolls the session back
     pj.commit();
     for (auto &j : pj.jobs) j.c->w0 = w1;
     size_t i = 0;

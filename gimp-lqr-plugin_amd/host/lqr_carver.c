@@ -106,12 +106,21 @@ typedef struct {
 static int g_debug_snapshot = 0;
 void lqrx_set_debug(gint on) { g_debug_snapshot = on; }
 
+/* the shim's code behind the last non-OK return: LQRHIP_EFAULT (a kernel gave up, a self-check failed) is what
+ * group_build_maps can recover from */
+static int g_last_rc = 0;
 static LqrRetVal hip_ret(int rc)
 {
     if (rc == 0) return LQR_OK;
+    g_last_rc = rc;
     fprintf(stderr, "liblqr-hip: device error %d: %s\n", rc, lqrhip_last_error());
     return rc == LQRHIP_ENOMEM ? LQR_NOMEM : LQR_ERROR;
 }
+/* Recovery (round 6).  The plug-in tests lqr_carver_resize's return value only against LQR_NOMEM (src/render.c:42-46,318) and
+ * then writes the carver to the user's layer (:366): a resize must not end in LQR_ERROR because a spin protocol timed out on a
+ * busy device.  A session (one visibility-map build) that ends in LQRHIP_EFAULT is rolled back -- the base layout is as before,
+ * the host's bookkeeping restored -- and carved again on the kernels without spin waits; only if that fails too does the caller
+ * see LQR_ERROR, with the carver as it was before the session.  lqrhip_set_recovery(0) switches the redo off (tests). */
 #define HIP_CATCH(expr) LQR_CATCH(hip_ret(expr))
 
 /* ======================= progress ======================================== */
@@ -475,7 +484,7 @@ static LqrRetVal take_debug_snapshot(LqrCarver *r)
     return LQR_OK;
 }
 
-static LqrRetVal group_build_vsmap(Group *g, int depth)
+static LqrRetVal group_build_vsmap(Group *g, int depth, int *reported)
 {
     LqrCarver *r0 = g->r[0];
     LqrHipDpParams p;
@@ -493,10 +502,13 @@ static LqrRetVal group_build_vsmap(Group *g, int depth)
         int full = 0, lr_pick = r0->leftright, w_before = r0->w;
         if ((l - r0->max_level + r0->session_rescale_current) % r0->session_update_step == 0 && r0->progress &&
             r0->progress->update) {
-            /* report completed work, not enqueued work */
+            /* report completed work, not enqueued work (a session that is being redone does not report twice) */
             HIP_ALL(g, lqrhip_batch_sync(B));
-            r0->progress->update((gdouble) (l - r0->max_level + r0->session_rescale_current) /
-                                 (gdouble) r0->session_rescale_total);
+            if (l > *reported) {
+                r0->progress->update((gdouble) (l - r0->max_level + r0->session_rescale_current) /
+                                     (gdouble) r0->session_rescale_total);
+                *reported = l;
+            }
         }
         if (w_before - 1 > 1) {
             if (r0->lr_switch_frequency && ((l - r0->max_level + lr_switch_interval / 2) % lr_switch_interval) == 0) {
@@ -513,6 +525,10 @@ static LqrRetVal group_build_vsmap(Group *g, int depth)
     if (g_debug_snapshot)
         for (i = 0; i < g->n; i++) LQR_CATCH(take_debug_snapshot(g->r[i]));
 
+    /* the seam loop is over: nothing of it is committed to the base layout before its kernels have all ended without a device-side
+     * failure and the seam log has passed its self-check */
+    HIP_ALL(g, lqrhip_session_check(B, r0->h, wc0, n_seams, r0->delta_x));
+    HIP_ALL(g, lqrhip_batch_sync(B));
     HIP_ALL(g, lqrhip_vs_commit(B, r0->w0, r0->h0, wc0, n_seams, first_level, finish));
     /* inflate (E14): every seam of this session is doubled in the base layout */
     HIP_ALL(g, lqrhip_inflate(B, r0->w0, r0->h0, depth - 1, r0->max_level));
@@ -525,23 +541,60 @@ static LqrRetVal group_build_vsmap(Group *g, int depth)
     return LQR_OK;
 }
 
-static LqrRetVal group_build_maps(Group *g, int depth)
+/* one session: (re)lay the working planes out if needed, energy, DP, the seam loop, commit, inflate */
+static LqrRetVal session_run(Group *g, int depth, int redo, int *reported)
 {
     LqrCarver *r0 = g->r[0];
     LqrHipDpParams p;
     int i;
-    if (depth <= r0->max_level) return LQR_OK;
-    if (!r0->active || r0->root) return LQR_ERROR;
     for (i = 0; i < g->n; i++) set_width_one(g->r[i], g->r[i]->w_start - g->r[i]->max_level + 1);    /* the carved frame */
-    if (!r0->wk_valid) {
-        if (r0->max_level != 1 || r0->w0 != r0->w_start) return LQR_ERROR;     /* working planes lost on a non-flat carver */
-        HIP_ALL(g, lqrhip_wk_init(B));
+    if (!r0->wk_valid || redo) {
+        /* a flat carver: identity; a multi-size image (a redone deeper session, working planes lost in a failed one): the
+         * pixels of the base layout without a level, in order */
+        const int from_visible = (r0->max_level != 1 || r0->w0 != r0->w_start);
+        HIP_ALL(g, lqrhip_wk_init(B, from_visible));
         for (i = 0; i < g->n; i++) g->r[i]->wk_valid = 1;
     }
     dp_params(r0, &p);
     HIP_ALL(g, lqrhip_emap_build(B, &p, r0->w, r0->h));
     HIP_ALL(g, lqrhip_mmap_build(B, &p, r0->w, r0->h, r0->leftright));
-    return group_build_vsmap(g, depth);
+    return group_build_vsmap(g, depth, reported);
+}
+
+static LqrRetVal group_build_maps(Group *g, int depth)
+{
+    LqrCarver *r0 = g->r[0];
+    LqrRetVal ret;
+    int i, k, reported = -1, *snap;
+    if (depth <= r0->max_level) return LQR_OK;
+    if (!r0->active || r0->root) return LQR_ERROR;
+    /* what a session changes on the host before it succeeds: the roots' width, level and side */
+    snap = (int *) malloc((size_t) g->n * 3 * sizeof *snap);
+    if (!snap) return LQR_NOMEM;
+    for (i = 0; i < g->n; i++) { snap[3 * i] = g->r[i]->w; snap[3 * i + 1] = g->r[i]->level; snap[3 * i + 2] = g->r[i]->leftright; }
+    g_last_rc = 0;
+    ret = session_run(g, depth, 0, &reported);
+    for (k = 0; k < 2 && ret != LQR_OK; k++) {
+        const int fault = (ret == LQR_ERROR && g_last_rc == LQRHIP_EFAULT);
+        const int wc0 = r0->w_start - r0->max_level + 1, n_seams = (depth ? depth : r0->w_start + 1) - r0->max_level;
+        /* the carver as it was before the session: the base layout (levels of this session removed if they were committed),
+         * the bookkeeping; the working planes are gone */
+        if (fault)
+            for (i = 0; i < g->nb; i++) (void) lqrhip_session_rollback(g->b[i], r0->w0, r0->h0, 2 * r0->max_level - 1, wc0 - n_seams <= 1);
+        for (i = 0; i < g->n; i++) {
+            LqrCarver *c = g->r[i];
+            c->w = snap[3 * i]; c->level = snap[3 * i + 1]; c->leftright = snap[3 * i + 2];
+            c->wk_valid = 0; c->ro_valid = 0; c->ro_line = 0;
+        }
+        if (!fault || !lqrhip_get_recovery() || k == 1) break;
+        fprintf(stderr, "liblqr-hip: the session is carved again on the kernels without spin waits\n");
+        for (i = 0; i < g->nb; i++) lqrhip_batch_set_safe(g->b[i], 1);
+        g_last_rc = 0;
+        ret = session_run(g, depth, 1, &reported);
+        for (i = 0; i < g->nb; i++) lqrhip_batch_set_safe(g->b[i], 0);
+    }
+    free(snap);
+    return ret;
 }
 
 /* ======================= vmaps (E12) ===================================== */
@@ -841,8 +894,7 @@ LqrRetVal lqrx_carver_get_energy(LqrCarver *r, gfloat *buffer)
     LQR_CATCH(group_open(&g, &r, 1));
     if (r->w != r->w_start - r->max_level + 1) ret = group_flatten(&g);
     if (ret == LQR_OK && !r->wk_valid) {
-        if (r->max_level != 1 || r->w0 != r->w_start) ret = LQR_ERROR;
-        else if ((ret = hip_ret(lqrhip_wk_init(g.b[0]))) == LQR_OK) r->wk_valid = 1;
+        if ((ret = hip_ret(lqrhip_wk_init(g.b[0], r->max_level != 1 || r->w0 != r->w_start))) == LQR_OK) r->wk_valid = 1;
     }
     if (ret == LQR_OK) {
         dp_params(r, &p);

@@ -13,9 +13,10 @@
  * on the batch's HIP stream; only lqrhip_batch_sync and the read-back calls
  * block.  Every function returns 0 on success, LQRHIP_ENOMEM on device OOM and
  * another negative value on any other HIP error; none of them aborts, and no kernel
- * traps: a device-side failure (a persistent grid that was not co-resident) is
- * recorded in a host-visible word and returned by the next lqrhip_batch_sync /
- * lqrhip_device_sync as LQRHIP_EHIP.
+ * traps: a device-side failure (a persistent grid that was not co-resident, a failed
+ * self-check of the session) is recorded in a host-visible word and returned by the next
+ * lqrhip_batch_sync / lqrhip_device_sync / lqrhip_inflate as LQRHIP_EFAULT; the host side then rolls
+ * the session back (lqrhip_session_rollback) and redoes it on the kernels without spin waits.
  *
  * Threading: like the plug-in's use of liblqr (GTK main loop / PDB run), the library
  * is single-threaded by contract -- the allocation cache, the error word and the
@@ -34,6 +35,7 @@ extern "C" {
 #define LQRHIP_ENOMEM (-2)
 #define LQRHIP_EHIP (-1)
 #define LQRHIP_EARG (-3)
+#define LQRHIP_EFAULT (-4)   /* a kernel of the session gave up or a self-check failed: roll back, redo (lqrhip_session_rollback) */
 #define LQRHIP_MAX_DELTA 16
 
 typedef struct LqrHipCarver LqrHipCarver;   /* device-resident planes of one carver */
@@ -89,15 +91,11 @@ int lqrhip_sub_batches(int n);
 /* Images of carved-frame width w that one lock-step batch may hold and still run delta_x = 2 / rigidity-mask carvers on the
  * tiled kernels (0: unknown); larger batches of such carvers are carved group after group (lqrx_carver_resize_batch). */
 int lqrhip_general_batch_limit(int w);
-/* Test hook: tiles per image of the multi-CU band update k_band_tiles (-1 automatic, 0 never, n at most n). */
-void lqrhip_set_band_tiles(int tiles);
-/* Test hook: how many of those are reserve tiles, woken when the band nears the edge of the set (-1: a third of them). */
-void lqrhip_set_band_tiles_reserve(int n);
 void lqrhip_set_sub_batches(int n);
 LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n);
 /* tell a batch how many batches of its group run concurrently on their own streams (0 or 1: alone): kernels whose grid
  * must be co-resident are then never chosen (k_dp_tile_p spins on neighbour tiles) or sized so that ALL the siblings' grids
- * fit together (k_band_tiles) */
+ * fit together (k_band_levels) */
 void lqrhip_batch_set_shared(LqrHipBatch *b, int shared);
 void lqrhip_batch_destroy(LqrHipBatch *b);
 int lqrhip_batch_sync(LqrHipBatch *b);
@@ -106,9 +104,10 @@ int lqrhip_batch_sync(LqrHipBatch *b);
 void lqrhip_batch_abort(LqrHipBatch *b);
 void *lqrhip_batch_stream(LqrHipBatch *b);      /* hipStream_t, for event timing in bench.py */
 
-/* base layout -> working planes, identity map (carver must be flat):
- * what liblqr's raw[y][x] = y*w+x initialisation means for compacted planes */
-int lqrhip_wk_init(LqrHipBatch *b);
+/* base layout -> working planes: what liblqr's raw[y][x] = y*w+x initialisation means for compacted planes.
+ * from_visible = 0: identity map (the carver is flat).  from_visible = 1: the carved frame of a multi-size image, i.e. the
+ * pixels of the base layout that carry no level yet, in order (a session redone after a fault; working planes that were lost) */
+int lqrhip_wk_init(LqrHipBatch *b, int from_visible);
 /* E3+E4 lqr_carver_build_emap: full energy map of the w x h carved frame */
 int lqrhip_emap_build(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h);
 /* E5 lqr_carver_build_mmap: full cumulative-min DP, tie rule by `leftright` */
@@ -129,6 +128,30 @@ int lqrhip_seam_log_reserve(LqrHipBatch *b, int n_seams, int h);
  * levels first_level, first_level+1, ... in the base layout; `finish` applies
  * liblqr's finish_vsmap (last column gets level w0). */
 int lqrhip_vs_commit(LqrHipBatch *b, int w0, int h0, int wc0, int n_seams, int first_level, int finish);
+/* Session self-check, enqueued behind the last seam step and in front of lqrhip_vs_commit: the seam log of the session (n_seams
+ * seams of h rows, carved frame wc0 wide at its start) must hold delta_x-connected seams inside their frames; a violation is
+ * reported as LQRHIP_EFAULT by the next lqrhip_batch_sync.  lqrhip_inflate carries the second check (every level of the session
+ * exactly once per row) and returns LQRHIP_EFAULT itself, without adopting anything.  lqrhip_set_selfcheck(0) turns both off. */
+int lqrhip_session_check(LqrHipBatch *b, int h, int wc0, int n_seams, int delta_x);
+void lqrhip_set_selfcheck(int on);
+/* whether the host side redoes a session that ended in LQRHIP_EFAULT (default 1); 0: roll back and return LQR_ERROR (tests) */
+void lqrhip_set_recovery(int on);
+int lqrhip_get_recovery(void);
+/* After LQRHIP_EFAULT: drain the batch's stream, drop the error record, remove the session's levels (>= first_level, and
+ * finish_vsmap's w0) from the visibility map if they were committed.  The working planes are invalid afterwards. */
+int lqrhip_session_rollback(LqrHipBatch *b, int w0, int h0, int first_level, int finish);
+/* kernels without spin waits only (k_dp_tile, k_band_update_tw / _mw / k_band_update, k_dp_sweep): set for the redo of a session */
+void lqrhip_batch_set_safe(LqrHipBatch *b, int safe);
+/* after a spin time-out the whole process stays on those kernels (a shared or partitioned device); 0 re-arms the persistent ones */
+void lqrhip_set_no_spin(int on);
+int lqrhip_get_no_spin(void);
+/* [0] spin time-outs, [1] failed activity predictions, [2] seam-log check failures, [3] level check failures, [4] sessions
+ * rolled back, [5] faults injected, [6] sessions carved on the non-spinning kernels after a fault */
+int lqrhip_fault_stats(unsigned long long *out8, int reset);
+/* Test hook: provoke a fault in the next session(s).  kind 1 spin time-out / 2 failed prediction (the error word is written while
+ * the kernels of seam step at_step run), 3 / 4 a seam-log entry out of the frame / disconnected, 5 / 6 a committed level cleared /
+ * duplicated; times = sessions hit in a row; kind 0 disarms. */
+void lqrhip_debug_inject(int kind, int at_step, int times);
 /* E14 lqr_carver_inflate(l) on roots and their attached carvers */
 int lqrhip_inflate(LqrHipBatch *b, int w0, int h0, int l, int max_level);
 /* E11 lqr_carver_flatten (render.c:325,636): keep pixels visible at `level` */
@@ -173,7 +196,8 @@ void lqrhip_prof_enable(int on);
 /* how E9 (update_mmap) runs: -1 by batch size (tiled full-width keep-rule sweep up to 8 4K images, the band
  * kernel k_band_update_tw above), 0 band kernel always, 1 tiled sweep whenever its grid fits the device,
  * 2 the per-row-barrier band kernel k_band_update_mw (the default for rows wider than 4200 px), 3 the generic
- * one-wave band kernel k_band_update + k_dp_sweep (what delta_x > 2 runs on) whatever the parameters, 4 k_band_tiles, 5 k_band_levels */
+ * one-wave band kernel k_band_update + k_dp_sweep (what delta_x > 4 runs on) whatever the parameters, 5 k_band_levels
+ * (4 was round 4's k_band_tiles, removed in round 6: it now behaves as 0) */
 void lqrhip_set_update_mode(int mode);
 /* Cap on the workgroups of the persistent tiled DP sweep (k_dp_tile_p), whose tiles spin on their neighbours and
  * must all be resident: -1 = the bound derived from the occupancy query at lqrhip_init, n >= 0 = min(n, that bound).
@@ -192,12 +216,10 @@ int lqrhip_prof_get_union(const char *kernel, double *ms_union);
 int lqrhip_moved_bytes(unsigned long long *bytes, int reset);
 /* Test hook: slots (workgroups) per image of k_band_levels (-1 automatic, 0 never, n exactly n). */
 void lqrhip_set_band_levels(int slots);
-/* k_band_levels' events since the last reset: [0] images stopped by two active tiles on one slot (the full-width sweep took over),
- * [1] synchronous (mispredicted) loads, [2] tile-levels processed, [3] slot-levels idle */
+/* k_band_levels' events since the last reset: [0] images stopped by THREE active tiles on one slot (a slot takes two, one per
+ * wave; the full-width sweep took over), [1] synchronous (mispredicted or second-tile) loads, [2] tile-levels processed,
+ * [3] slot-levels idle, [4] levels in which a slot had two tiles */
 int lqrhip_band_levels_stats(unsigned long long *out8, int reset);
-/* k_band_tiles' rare events since the last reset: [0] images not covered by their tile set, [1] images aborted at an edge,
- * [2] reserve tiles woken, [3] requests that found no reserve left */
-int lqrhip_band_tiles_stats(unsigned long long *out8, int reset);
 
 #ifdef __cplusplus
 }

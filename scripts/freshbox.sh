@@ -1,7 +1,7 @@
 #!/bin/bash
 # Both unexplained failures (round 4: test_seeded_batches[r3]; round 5: test_build_variants[-1]) happened in the first two minutes of a
 # full-suite run on a FRESH box.  This is those first test files, as the first GPU work of a fresh box, then twice more on the warm box.
-# usage (one gpurun call = one fresh box): gpurun -- 'bash scripts/freshbox_r05.sh TAG'
+# usage (one gpurun call = one fresh box): gpurun -- 'bash scripts/freshbox.sh TAG'
 tag=${1:-a}; mkdir -p gpurun_out/freshbox; L=gpurun_out/freshbox/$tag.log
 date > $L
 for i in 1 2 3; do

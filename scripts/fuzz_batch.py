@@ -50,7 +50,8 @@ while budget.more(n):
     if rng.random() < 0.2:
         kw.update(delta_x=int(rng.choice([2, 3])))
     masks = rng.random() < 0.2
-    mode = int(rng.choice([-1, 0, 1, 2, 4, 4]))
+    mode = int(rng.choice([-1, 0, 1, 2, 4, 4]))       # (4 was k_band_tiles, removed in round 6: those draws run k_band_levels now)
+    mode = 5 if mode == 4 else mode
     sub = int(rng.choice([1, 1, 2, 3]))
     if rng_lv.random() < 0.34:
         mode = 5

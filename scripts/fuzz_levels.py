@@ -1,10 +1,8 @@
-"""Randomised parity run for the multi-CU band update (k_band_tiles, update mode 4): engine vs oracle through the C ABI with
-the tile count forced to 1..12 per image -- small counts put the edges of the tile set next to the seam (coverage test,
-abort and hand-over to the full-width sweep), large ones cover small images entirely.  Also compares the DP planes after the
-last incremental update bit for bit.
-FUZZ_LEVELS=1: the same cases on k_band_levels (update mode 5) with 1..16 slots per image -- one slot stops at the first level with
-two active tiles (hand-over to the full-width sweep), many slots leave most of them idle.
-    python scripts/fuzz_tiles.py [seconds] [seed]"""
+"""Randomised parity run for the multi-CU band update k_band_levels (update mode 5): engine vs oracle through the C ABI with
+1..16 slots per image forced -- one slot stops at the first level with three active tiles (hand-over to the full-width sweep),
+many slots leave most of them idle.  Also compares the DP planes after the last incremental update bit for bit.
+(Round 4's k_band_tiles, which this script was written for, is gone; the case mix and the seeds' draws are unchanged.)
+    python scripts/fuzz_levels.py [seconds] [seed]"""
 import ctypes, os, sys, time
 sys.path.insert(0, "tests")
 import numpy as np
@@ -17,9 +15,8 @@ repeat = int(os.environ.get("FUZZ_REPEAT", "1"))
 rng = np.random.default_rng(seed)
 o, e = L.oracle_api(), L.engine_api()
 lib = e.lib
-lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]; lib.lqrhip_set_band_tiles.argtypes = [ctypes.c_int]; lib.lqrhip_set_band_tiles_reserve.argtypes = [ctypes.c_int]
+lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]
 lib.lqrhip_set_band_levels.argtypes = [ctypes.c_int]
-levels = bool(os.environ.get("FUZZ_LEVELS"))
 fails = FC.Failures(lib)
 if os.environ.get("LQR_LV_DBG"):        # k_band_levels' experiment switches (4 no near copy, 8 an image's slots on different XCDs)
     lib.lqrhip_band_levels_debug.argtypes = [ctypes.c_int]; lib.lqrhip_band_levels_debug(int(os.environ["LQR_LV_DBG"]))
@@ -37,11 +34,8 @@ try:
             if n > only:
                 break
             continue
-        if levels:
-            T = int([1, 2, 3, 4, 6, 8, 12, 16][(T * 7 + rsv + 1) % 8])          # slots per image (derived from what the seed drew: same cases)
-            lib.lqrhip_set_update_mode(5); lib.lqrhip_set_band_levels(T)
-        else:
-            lib.lqrhip_set_update_mode(4); lib.lqrhip_set_band_tiles(T); lib.lqrhip_set_band_tiles_reserve(rsv)
+        T = int([1, 2, 3, 4, 6, 8, 12, 16][(T * 7 + rsv + 1) % 8])          # slots per image (derived from what the seed drew: same cases)
+        lib.lqrhip_set_update_mode(5); lib.lqrhip_set_band_levels(T)
         planes = kw.get("switch_freq") == 0 and nh == img.shape[0] and nw < img.shape[1]
         for rep in range(repeat if only >= 0 else 1):
             try:
@@ -58,11 +52,11 @@ try:
                     assert np.array_equal(ea, eb) and np.array_equal(ma, mb) and np.array_equal(da[1:], db[1:]), "DP planes"
                 ca.destroy(); cb.destroy()
             except Exception as ex:
-                fails.record(n, "T=%d rsv=%d %s" % (T, rsv, what), ex)
+                fails.record(n, "slots=%d %s" % (T, what), ex)
             finally:
                 o.lqrx_set_debug(0); e.lqrx_set_debug(0)
         n += 1
 finally:
-    lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_tiles(-1); lib.lqrhip_set_band_tiles_reserve(-1); lib.lqrhip_set_band_levels(-1)
-FC.summary("levels fuzz" if levels else "tiles fuzz", n, budget, fails, seed)
+    lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_levels(-1)
+FC.summary("levels fuzz", n, budget, fails, seed)
 sys.exit(1 if fails.total else 0)

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-5 evidence for profiles/, all from ONE commit: the driver's bench line (with configs 2/3/5 and the per-kernel
+# Evidence for profiles/, all from ONE commit: the driver's bench line (with configs 2/3/5 and the per-kernel
 # breakdown on it), rocprofv3 --kernel-trace --stats of the same command and of the single-image workloads, and the HBM
 # traffic of every kernel from two SEPARATE PMC passes (FETCH_SIZE, WRITE_SIZE; never combined with other trace domains)
 # for the batch and for the single 4K image -> pmc_kernels.json, which bench.py reads for roofline.traffic / pmc_bytes.
-#   scripts/profile_r05.sh TAG [what...]      what: batch stats pmc (default: all)
-tag=${1:-r05x}; shift
+#   scripts/profile.sh TAG [what...]      what: batch stats pmc (default: all)
+tag=${1:-r06x}; shift
 what=${*:-batch stats pmc}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -1,14 +1,13 @@
 #!/bin/bash
-# Round 5, the soak on the round's LAST kernels (near copies, LDS flags, tiles numbered per XCD, the level kernel at 64 images, the lean
-# rigidity instantiation): the whole GPU suite, then count-bounded fuzz runs with their own seeds, plain, on poisoned blocks, and with an
+# The soak: the whole GPU suite, then count-bounded fuzz runs with their own seeds, plain, on poisoned blocks, and with an
 # image's slots deliberately on different XCDs (LQR_LV_DBG=8: the near copies are written and never seen).
-mkdir -p gpurun_out/soak4; L=gpurun_out/soak4
+mkdir -p gpurun_out/soak; L=gpurun_out/soak
 date > $L/summary.txt
 python -m pytest tests -m gpu -q -p no:cacheprovider > $L/suite.log 2>&1; echo "suite rc $? $(grep -E 'passed|failed' $L/suite.log | tail -1)" | tee -a $L/summary.txt
 run() { name=$1; shift; "$@" > $L/$name.log 2>&1; echo "$name rc $?: $(tail -1 $L/$name.log)" | tee -a $L/summary.txt; grep '^FAIL' $L/$name.log | cut -c1-500 | head -5 | tee -a $L/summary.txt; }
-run levels_plain    env FUZZ_LEVELS=1 FUZZ_COUNT=900 python scripts/fuzz_tiles.py 0 60601
-run levels_poison   env FUZZ_LEVELS=1 FUZZ_COUNT=500 LQRHIP_POISON=r3 python scripts/fuzz_tiles.py 0 60602
-run levels_crossxcd env FUZZ_LEVELS=1 FUZZ_COUNT=500 LQR_LV_DBG=8 python scripts/fuzz_tiles.py 0 60603
+run levels_plain    env FUZZ_COUNT=900 python scripts/fuzz_levels.py 0 60601
+run levels_poison   env FUZZ_COUNT=500 LQRHIP_POISON=r3 python scripts/fuzz_levels.py 0 60602
+run levels_crossxcd env FUZZ_COUNT=500 LQR_LV_DBG=8 python scripts/fuzz_levels.py 0 60603
 run batch_plain     env FUZZ_COUNT=400 GPU_MAX_HW_QUEUES=8 python scripts/fuzz_batch.py 0 60604
 run batch_poison    env FUZZ_COUNT=300 GPU_MAX_HW_QUEUES=16 LQRHIP_POISON=r3 python scripts/fuzz_batch.py 0 60605
 run batch_crossxcd  env FUZZ_COUNT=200 LQR_LV_DBG=8 python scripts/fuzz_batch.py 0 60606

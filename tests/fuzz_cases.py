@@ -7,7 +7,7 @@ import numpy as np
 
 import datasets as D
 
-MODES = {"auto": -1, "band": 0, "band-mw": 2, "tiles": 4, "levels": 5}
+MODES = {"auto": -1, "band": 0, "band-mw": 2, "levels": 5}
 
 
 def draw_case(rng, small=False):

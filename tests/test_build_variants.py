@@ -1,6 +1,6 @@
 """The engine's build carries one internal, unversioned LLVM option (-mllvm -amdgpu-sched-strategy=max-ilp: it only
 reschedules instructions; Makefile).  The parity suite must be green with and without it: this test (-m gpu) compiles
-the library a second time WITHOUT the option into tests/c/build/ and runs a cross-section of the parity cases -- every
+the library a second time WITHOUT the option into tests/c/build/nosched-<hash of the sources>/ and runs a cross-section of the parity cases -- every
 update_mmap form, both tie rules, rigidity, delta_x 2, masks, the tolerance boundary -- through that build."""
 import ctypes
 import os
@@ -21,16 +21,33 @@ PKG = os.path.join(ROOT, "gimp-lqr-plugin_amd")
 OUT = os.path.join(ROOT, "tests", "c", "build")
 
 
+def source_hash():
+    """sha1 over everything the library is built from: a second build is only ever reused for exactly these sources (round 5
+    shipped a prebuilt variant four hours older than the kernels; whether `make` rebuilds depends on mtimes that a copy of
+    the tree need not preserve)"""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(PKG, "csrc", "*")) + glob.glob(os.path.join(PKG, "host", "*")) + glob.glob(os.path.join(ROOT, "include", "*")) + [os.path.join(PKG, "Makefile")]):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 @pytest.fixture(scope="module")
 def plain_build():
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc on this machine")
-    os.makedirs(OUT, exist_ok=True)
-    so = os.path.join(OUT, "liblqr-hip-default-sched.so")
-    # the package's own Makefile with the option switched off (SCHED=), objects and library under tests/c/build/; make
-    # rebuilds only what is older than its sources
-    subprocess.check_call(["make", "-C", PKG, "-j8", "SCHED=", "BUILD=" + os.path.join(OUT, "nosched"), "OUT=" + so], stdout=subprocess.DEVNULL)
+    key = source_hash()
+    out = os.path.join(OUT, "nosched-" + key)
+    for old in os.listdir(OUT) if os.path.isdir(OUT) else []:          # variants of other source states (and round 5's unkeyed one)
+        if (old.startswith("nosched") and old != "nosched-" + key) or old == "liblqr-hip-default-sched.so":
+            p = os.path.join(OUT, old)
+            shutil.rmtree(p) if os.path.isdir(p) else os.remove(p)
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "liblqr-hip-default-sched.so")
+    # the package's own Makefile with the option switched off (SCHED=), objects and library in a directory keyed by the sources' hash
+    subprocess.check_call(["make", "-C", PKG, "-j8", "SCHED=", "BUILD=" + os.path.join(out, "obj"), "OUT=" + so], stdout=subprocess.DEVNULL)
     return L.Api(so, "")
 
 

@@ -26,7 +26,6 @@ BUDGETS = [
     (r"^k_carve$", 96, 0, 0, "5 waves per SIMD: the carve's 0.4 of the HBM roof next to the chain kernels (DESIGN 4.9, 4.14)"),
     (r"^k_band_update_tw<4, ", 256, 0, 0, "8 waves per workgroup = 2 per SIMD; it claims all 256 registers on purpose (no sibling kernel's wave beside it); no scratch in the row loop"),
     (r"^k_band_levels<", 256, 0, 0, "2 waves per SIMD (amdgpu_waves_per_eu(2, 2)): the residency bound the slot count is taken from; one site each for loads, rows and stores or 330 VGPRs spill (DESIGN 4.16)"),
-    (r"^k_band_tiles<", 256, 32, 8, "2 waves per SIMD (amdgpu_waves_per_eu(2, 2)): the residency bound of 768 workgroups; the few spills sit outside the row loop"),
     (r"^k_dp_tile_p<[24], (true|false), (true|false), false, 1, false>$", 128, 0, 0, "E5, plain: 4 waves per SIMD"),
     (r"^k_dp_tile_p<2, (true|false), (true|false), true, 1, false>$", 232, 0, 0, "E9 full width, 32-row block staged in registers: 2 waves per SIMD"),
     (r"^k_dp_tile_p<4, (true|false), (true|false), true, 1, false>$", 216, 0, 0, "E9 full width, 4 px per lane: 2 waves per SIMD"),
@@ -37,7 +36,7 @@ BUDGETS = [
     (r"^k_dp_tile<", 96, 0, 0, "one wave per tile, 5 per SIMD"),
 ]
 # kernels that are allowed to use scratch at all (slow paths for rows wider than 8192 px / known, outside the row loops)
-SCRATCH_OK = (r"^k_dp_sweep<16, ", r"^k_dp_sweep<8, true>$", r"^k_band_tiles<")
+SCRATCH_OK = (r"^k_dp_sweep<16, ", r"^k_dp_sweep<8, true>$")
 
 
 def violations(meta):
@@ -77,14 +76,14 @@ def test_every_kernel_is_within_its_budget(meta):
 
 
 def test_checker_is_red_on_a_fattened_kernel(meta):
-    """the same check on doctored metadata: the carve at round 2's 142 VGPRs, k_band_tiles at lesson (vii)'s 262, scratch in
+    """the same check on doctored metadata: the carve at round 2's 142 VGPRs, k_band_levels at 262 (one wave per SIMD), scratch in
     the trapezoid band kernel -- each must be reported"""
     fat = copy.deepcopy(meta)
     fat["k_carve"]["vgpr_count"] = 142
-    fat["k_band_tiles<false, false>"]["vgpr_count"] = 262
+    fat["k_band_levels<false, false, 1, false>"]["vgpr_count"] = 262
     fat["k_band_update_tw<4, true, false>"]["private_segment_fixed_size"] = 64
     bad = violations(fat)
-    assert len(bad) >= 3 and any(b.startswith("k_carve:") for b in bad) and any("k_band_tiles<false, false>" in b for b in bad) \
+    assert len(bad) >= 3 and any(b.startswith("k_carve:") for b in bad) and any("k_band_levels<false, false, 1, false>" in b for b in bad) \
         and any("k_band_update_tw<4, true, false>" in b for b in bad), bad
 
 

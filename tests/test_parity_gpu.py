@@ -16,17 +16,16 @@ import lqr_ctypes as L
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "band", "band-mw", "tiles", "levels"], autouse=True)
+@pytest.fixture(params=["auto", "band", "band-mw", "levels"], autouse=True)
 def update_mode(request, engine):
     """Every test runs four times: with the engine's default choice of update_mmap kernel (the tiled
     full-width sweep at these sizes), with the band kernel the large batches use, with the
-    per-row-barrier band kernel k_band_update_mw (the default for rows wider than 4200 px), and with the
-    multi-CU band update k_band_tiles (round 4: batches of 8 to ~40 images), and with k_band_levels (round 5: the band on
-    several compute units, tiles assigned level by level)."""
+    per-row-barrier band kernel k_band_update_mw (the default for rows wider than 4200 px), and with k_band_levels (round 5: the
+    band on several compute units, tiles assigned level by level; round 4's k_band_tiles was removed in round 6)."""
     import ctypes
     lib = engine.lib
     lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]
-    lib.lqrhip_set_update_mode({"auto": -1, "band": 0, "band-mw": 2, "tiles": 4, "levels": 5}[request.param])
+    lib.lqrhip_set_update_mode({"auto": -1, "band": 0, "band-mw": 2, "levels": 5}[request.param])
     yield request.param
     lib.lqrhip_set_update_mode(-1)
 

@@ -68,56 +68,15 @@ def test_host_transfers_odd_sizes(engine, w, h, ch):
         c.destroy()
 
 
-def test_band_tiles_seeded_cases_with_forced_tile_counts():
-    """scripts/fuzz_tiles.py: the multi-CU band update with 1..12 tiles per image -- sets narrower than the band (coverage
-    test, abort at the edge of the set and hand-over to the full-width sweep), sets wider than the image, both tie rules,
-    rigidity; seam maps, pixels and the DP planes after the last incremental update against the oracle"""
-    import fuzz_common as FC
-    FC.run_script("fuzz_tiles.py", [0, 4400], {}, 400)          # count-bounded: all 400 cases must have run
-
-
-def test_band_tiles_batch_of_12_images(oracle, engine):
-    """a lock-step batch of the size the engine itself sends to k_band_tiles (8 to ~40 images): every image against the oracle"""
-    import ctypes
-    lib = engine.lib
+def test_batch_of_12_images_on_the_engines_own_choice(oracle, engine):
+    """a lock-step batch of the size the engine sends to the multi-CU band update (8 and more images): every image against the oracle"""
     n, w, h = 12, 1200, 330
     imgs = [D.photo_like(w, h, 1200 + i) if i % 2 else D.noise(w, h, 1200 + i) for i in range(n)]
     cs = [L.Carver(engine, im).configure() for im in imgs]
-    lib.lqrhip_prof_reset(); lib.lqrhip_prof_enable(1)
     assert L.resize_batch(engine, cs, w - 60, h) == L.LQR_OK
-    lib.lqrhip_prof_enable(0)
-    st = (ctypes.c_ulonglong * 8)()
     for c, im in zip(cs, imgs):
         ref = H.run_case(oracle, im, w - 60, h)
         assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"])
         assert np.array_equal(c.read_image(), ref["image"])
     for c in cs:
         c.destroy()
-
-
-@pytest.mark.parametrize("seed", [607398534, 7001])        # the first one is the image of the fuzz case below
-def test_band_tiles_chains_of_reserve_tiles(oracle, engine, seed):
-    """3 base tiles and 9 reserves on a tall noise image with a discard band: the band of changes walks outward through
-    several reserve tiles, one waking the next.  A reserve tile may only give up waiting when every tile that ever started
-    has ended (k_band_tiles's header count): the first version left when the BASE tiles were done, and a request made two
-    hops out in the second-to-last block then waited for a tile that had gone (fuzz seed 30311 case 1308: time-out)."""
-    lib = engine.lib
-    lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]; lib.lqrhip_set_band_tiles.argtypes = [ctypes.c_int]; lib.lqrhip_set_band_tiles_reserve.argtypes = [ctypes.c_int]
-    w, h = 1125, 834
-    img = D.noise(w, h, seed, channels=2)
-    kw = dict(nrg_func=3, switch_freq=9, res_order=1, pres=D.ellipse_mask(w, h), disc=D.band_mask(w, h, w // 5, w // 3))
-    lib.lqrhip_set_update_mode(4); lib.lqrhip_set_band_tiles(12); lib.lqrhip_set_band_tiles_reserve(9)
-    try:
-        ca, _ = H.init_carver(oracle, img, w - 46, h, **kw)
-        assert ca.resize(w - 46, h) == L.LQR_OK
-        vref, iref = ca.vmap_dump()["data"], ca.read_image()
-        for rep in range(10):            # (who leaves first is a matter of timing: the old exit failed one run in a few)
-            cb, _ = H.init_carver(engine, img, w - 46, h, **kw)
-            assert cb.resize(w - 46, h) == L.LQR_OK, rep
-            assert np.array_equal(vref, cb.vmap_dump()["data"])
-            assert np.array_equal(iref, cb.read_image())
-            if rep < 9:
-                cb.destroy()
-        ca.destroy(); cb.destroy()
-    finally:
-        lib.lqrhip_set_update_mode(-1); lib.lqrhip_set_band_tiles(-1); lib.lqrhip_set_band_tiles_reserve(-1)

@@ -34,12 +34,12 @@ def test_oracle_keeps_the_stale_value(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["auto", "band", "band-mw", "generic", "tiles", "levels"])
+@pytest.mark.parametrize("mode", ["auto", "band", "band-mw", "generic", "levels"])
 def test_engine_keeps_the_stale_value(oracle, engine, mode):
     """auto = tiled full-width update (k_dp_tile_p), band = k_band_update_tw, band-mw = k_band_update_mw, generic =
     k_band_update / k_dp_sweep (update mode 3: the kernels delta_x > 2 runs on)"""
     engine.lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]
-    engine.lib.lqrhip_set_update_mode({"auto": -1, "band": 0, "band-mw": 2, "generic": 3, "tiles": 4, "levels": 5}[mode])
+    engine.lib.lqrhip_set_update_mode({"auto": -1, "band": 0, "band-mw": 2, "generic": 3, "levels": 5}[mode])
     extra = {}
     try:
         cols, b = seam_columns(engine, **extra)
