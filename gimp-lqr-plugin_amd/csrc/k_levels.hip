@@ -56,6 +56,14 @@ extern "C" int lqrhip_band_levels_timing(unsigned long long *out) { (void) hipDe
 #endif
 __device__ int g_lv_dbg;               // experiment switches (lqrhip_band_levels_debug): 1 no speculative granule fetch, 2 sleep longer in the poll, 4 no near copy, 8 an image's slots on different XCDs
 
+// timing jitter for the soak build (make EXTRA=-DLQR_JITTER; switch 16 of lqrhip_band_levels_debug): pseudo-random sleeps at the protocol's
+// hand-over sites, as in k_dp_tile_p; the product build has no site (any edit of this kernel can flip its row schedule)
+#ifdef LQR_JITTER
+#define LJIT(site) do { if (dbg & 16) { unsigned h__ = (unsigned) (slot * 131 + L * 17 + (site) * 7 + epoch * 2654435761u + q * 40503u + image * 977u); h__ ^= h__ >> 13; h__ *= 0x5bd1e995u; h__ ^= h__ >> 15; \
+    for (unsigned i__ = h__ & 15u; i__ > 0; i__--) __builtin_amdgcn_s_sleep(127); } } while (0)
+#else
+#define LJIT(site) do { } while (0)
+#endif
 // a value every lane holds (read from LDS), as a scalar
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v)
 {
@@ -363,7 +371,9 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
             passed = true;
             if (L > 0) {
                 const int spec_t = (hold_L < 0 && cur_full && cur_L == L && L < nblk && !(dbg & 1)) ? cur_t : -1;
+                LJIT(1);
                 const int wl_rc = wait_level(L, spec_t, A_prev, fw, g);
+                LJIT(2);
                 LTT(0);
                 if (wl_rc) { LDS_FLAG(s_fail) = 1; passed = false; }
                 else if (L < nblk) {
@@ -399,6 +409,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
         }
         // ---- STORE: level L - 1 is final and every slot has consumed its inputs
         LTT(1);
+        LJIT(3);
         if (hold_L >= 0 && passed) { store_u(hold_L * R); hold_L = -1; }
         LTT(3);
         if (L == nblk) break;
@@ -435,6 +446,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
                 cur_t = -1; cur_L = ld_L; cur_full = false;
             }
             LTT(1);
+            LJIT(4);
             if (ld_t >= 0) { set_tile(ld_t); issue_full(ld_L); cur_t = ld_t; cur_L = ld_L; cur_full = true; }
 #ifdef LQR_TIMING
             if (t >= 0 && ld_t >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -462,6 +474,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
             LTT(6);
             hold_L = L;
             cur_full = false;                    // (the registers hold results now)
+            LJIT(5);
             if (L + 1 < nblk && own_lane) {
                 gu64 *dst = gran + ((size_t) (L & 1) * ntiles + t) * OWN + PX * (lane - HL);
                 const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 10) | (unsigned) (L + 1)) << 32;
@@ -476,6 +489,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
             word = 0x800u | (any_o ? 0x100u : 0u) | (any_l ? 0x200u : 0u) | (any_r ? 0x400u : 0u) | (unsigned) t;
         } else if (mine && passed) n_idle++;
         // the slot's word for this wave's tile of the level (its granules were issued above; a reader checks their tags itself)
+        LJIT(6);
         if (lane == 0 && (t >= 0 || mine) && LDS_FLAG(s_fail) == 0) {
             const unsigned long long tag = (unsigned long long) (((unsigned) epoch << 10) | (unsigned) (L + 1)) << 32;
             gu64 *fdst = flagw + (size_t) (L & 1) * 2 * LV_PMAX + 2 * slot + (mine ? 0 : 1);

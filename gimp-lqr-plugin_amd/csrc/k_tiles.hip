@@ -122,7 +122,17 @@ __device__ unsigned long long g_tile_dbg[2 * 16];
 #else
 #define TT(i) do { } while (0)
 #endif
-__device__ int g_dpp_dbg;          // experiment switches (lqrhip_dp_tile_debug): 1 no near copies, 2 tile = workgroup index (neighbours on different XCDs) and no near copies
+__device__ int g_dpp_dbg;          // experiment switches (lqrhip_dp_tile_debug): 1 no near copies, 2 tile = workgroup index (neighbours on different XCDs) and no near copies,
+                                   // 4 timing jitter: pseudo-random sleeps (0 .. ~15 x 8 k cycles) at the protocol's hand-over sites -- a race that needs an unusual
+                                   // interleaving of tiles and waves gets thousands of them per launch (scripts/jitter_soak.py; round 6's hunt for the one-offs of rounds 4 / 5)
+// A build of its own (make EXTRA=-DLQR_JITTER): even a uniform scalar branch per site moved the rigidity-mask instantiation from 256 to
+// 294 registers (tests/test_kernel_budgets.py); the product kernels carry no site.
+#ifdef LQR_JITTER
+#define JIT(site) do { if (dbg & 4) { unsigned h__ = (unsigned) (tile * 131 + j * 17 + (site) * 7 + epoch * 2654435761u + q * 40503u); h__ ^= h__ >> 13; h__ *= 0x5bd1e995u; h__ ^= h__ >> 15; \
+    for (unsigned i__ = h__ & 15u; i__ > 0; i__--) __builtin_amdgcn_s_sleep(127); } } while (0)
+#else
+#define JIT(site) do { } while (0)
+#endif
 template <int PX, bool LR, bool RIG, bool UPDATE, int DELTA, bool RIGM>
 __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err)
 {
@@ -361,6 +371,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     unsigned long long g[PX];
                     int spins = 0;
                     bool failed = false;
+                    JIT(1);
                     const bool lane_near = need && (lane < 32 ? near_l : near_r);
                     while (true) {
                         gu64 *s2 = src + ((lane_near && (spins & 3) != 3) ? near_off : 0);
@@ -380,6 +391,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
 #pragma unroll
                         for (int k = 0; k < PX; k++) mp[k] = in[k] ? __uint_as_float((unsigned) g[k]) : INF;
                     }
+                    JIT(2);
                     if (lane == 0) LDS_FLAG(s_polled) = j;          // the partner's prefetch may start (see the issue site)
                 }
                 TT(1);
@@ -414,6 +426,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                 if (yb + R > ylast && j + 1 < nblk) {
                     // publish the block's last row (still in mp): the outer HALO own columns on each side are the
                     // neighbours' halo; lanes 16..31 write the left-going granules, lanes 32..47 the right-going ones
+                    JIT(3);
                     if (own_lane) {
                         const int side = lane < 32 ? 0 : 1;
                         gu64 *dst = ex_img + (size_t) tile * EX_TILE + (size_t) ((j & 1) * 2 + side) * HALO + PX * (lane - (side ? 32 : HL));
@@ -431,6 +444,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             TT(5);
             if (s_fail) return;                  // uniform: written before the barrier, read by both waves after it
+            JIT(4 + (mine ? 1 : 0));
             // this wave's next batch, issued AFTER the barrier: the ~50 load instructions (~1500 cycles of issue) then
             // run under the partner's compute instead of in front of it
             if (mine) {
@@ -442,6 +456,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     while (LDS_FLAG(s_polled) < j + 1 && !LDS_FLAG(s_fail) && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
                 }
                 TT(6);
+                JIT(6);
                 if constexpr (UPDATE) store_u(yb);        // the batch this wave has just computed, before its registers are reloaded
                 TT(7);
                 issue(yb + DPP_W * R);
@@ -452,6 +467,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
 #ifdef LQR_TIMING
     if (UPDATE && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && lane == 0) { for (int i = 0; i < 10; i++) g_tile_dbg[q * 16 + i] = tdbg[i]; g_tile_dbg[q * 16 + 10] = __builtin_readcyclecounter() - ttstart; }
 #endif
+    { const int j = nblk; (void) j; JIT(7); }
     if (UPDATE && threadIdx.x == 0) {
         // the update wrote m2 / least2: the tile that finishes last swaps the image's plane pointers in the device
         // descriptor (every tile read the descriptor before it could finish) and re-arms the counter

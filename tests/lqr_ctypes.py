@@ -20,6 +20,23 @@ from gimp_lqr_plugin_amd.binding import _apis, _malloc_copy, _libc   # noqa: F40
 
 ORACLE_LIB = os.path.join(ROOT, "oracle", "liblqr_oracle.so")
 
+_engine_api = engine_api
+
+
+def engine_api():
+    """the package's engine_api(), plus the kernels' experiment switches from the environment (soaks and A/B runs of the tests and fuzz
+    scripts): LQR_LV_DBG -> lqrhip_band_levels_debug (4 no near copy, 8 an image's slots on different XCDs, 16 timing jitter in an
+    LQR_JITTER build), LQR_DPP_DBG -> lqrhip_dp_tile_debug (1 no near copies, 2 round 4's tile numbering, 4 timing jitter)"""
+    import ctypes
+    api = _engine_api()
+    if not getattr(api, "_dbg_env_applied", False):
+        api._dbg_env_applied = True
+        for env, fn in (("LQR_LV_DBG", "lqrhip_band_levels_debug"), ("LQR_DPP_DBG", "lqrhip_dp_tile_debug")):
+            if os.environ.get(env):
+                f = getattr(api.lib, fn); f.argtypes = [ctypes.c_int]; f.restype = None
+                f(int(os.environ[env]))
+    return api
+
 
 def oracle_api():
     if "oracle" not in _apis:
