@@ -113,11 +113,12 @@ def check(api, entry):
 SMALL = vectors("fixtures", "fuzz", "extras")
 CONFIGS = vectors("configs")
 CONFIG4 = vectors("config4")
+CONFIG5_HALF = vectors("config5half")       # round 6: config 5 at HALF scale (3840 x 2160, 500 seams, masks, rigidity 10) and its delta_x 2 / rigidity-mask variants
 
 
 def test_manifest_is_complete():
     assert len(vectors("fixtures")) == 17 and len(vectors("fuzz")) == 60 and len(vectors("extras")) == 40
-    assert len(CONFIG4) == 64 and len(CONFIGS) >= 5 and len(vectors("interactive")) == 40
+    assert len(CONFIG4) == 64 and len(CONFIGS) >= 5 and len(vectors("interactive")) == 40 and len(CONFIG5_HALF) == 3
     assert len(MANIFEST["exe_sha256"]) == 64
     for v in MANIFEST["vectors"]:
         assert os.path.exists(os.path.join(REF, v["file"])), v["file"]
@@ -137,6 +138,13 @@ def test_oracle_reproduces_the_genuine_engine_on_baseline_configs(oracle, entry)
     """BASELINE.json's configs 1 and 2 at full size, 3 at full size (both directions, both seam maps), 5 and its variants at
     quarter scale"""
     check(oracle, entry)
+
+
+def test_oracle_reproduces_the_genuine_engine_on_config5_at_half_scale(oracle):
+    """config 5 at the largest size the 32-bit runner's arena holds (config 4's images are 3840 x 2160 too): 500 seams of a 4K image with
+    the preservation ellipse, the discard band and rigidity 10; delta_x 2; a rigidity mask (~50 s of the oracle each, side by side)"""
+    with ThreadPoolExecutor(3) as ex:
+        list(ex.map(lambda e: check(oracle, e), CONFIG5_HALF))
 
 
 def test_oracle_reproduces_the_genuine_engine_on_config4_images(oracle):
@@ -221,6 +229,12 @@ def test_engine_reproduces_the_genuine_engine(engine, entry):
 @pytest.mark.gpu
 @pytest.mark.parametrize("entry", CONFIGS, ids=ids(CONFIGS))
 def test_engine_reproduces_the_genuine_engine_on_baseline_configs(engine, entry):
+    check(engine, entry)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry", CONFIG5_HALF, ids=ids(CONFIG5_HALF))
+def test_engine_reproduces_the_genuine_engine_on_config5_at_half_scale(engine, entry):
     check(engine, entry)
 
 
