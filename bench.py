@@ -102,7 +102,9 @@ def parse():
     ap.add_argument("--dp-px", type=int, default=0, help="pin the persistent tiled sweep's pixels per lane (2 or 4; 0: by batch size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phases", action="store_true", help="skip the upload / read-out phase measurement")
+    ap.add_argument("--vpath-mode", type=int, default=-1, help="backtrack: -1 the engine's choice (parallel k_vp_* up to 16 images), 0 k_vpath1 always, 1 parallel always")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--image-seed-offset", type=int, default=None, help="single process only: generate the images rank k of an N-rank run would (offset = k * images per GPU); tests/test_bench_multirank_gpu.py")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the extra legs after the headline: BASELINE configs 2, 3 and 5 (fhd, single4k, config5), 3 steps each")
     ap.add_argument("--no-kernel-breakdown", action="store_true", help="skip the extra untimed step that HIP-event times every kernel")
@@ -189,7 +191,7 @@ def config5_masks(w, h, rigmask):
 # the engine's profiling names -> the kernels behind them (large batch, small batch / single image): for the PMC look-up
 KERNEL_NAMES = {
     "carve": (["k_carve"], ["k_carve"]),
-    "vpath": (["k_vpath1", "k_vpath"], ["k_vpath1", "k_vpath"]),
+    "vpath": (["k_vpath1", "k_vpath"], ["k_vp_maps", "k_vpath1", "k_vpath"]),      # (small groups: k_vp_maps + k_vp_solve + k_vp_paths, one scope)
     "band_update": (["k_band_update_tw", "k_band_update_mw", "k_band_update"], ["k_band_update_tw", "k_band_update"]),
     "band_levels": (["k_band_levels"], ["k_band_levels"]),
     "dp_update": (["k_dp_sweep"], ["k_dp_sweep"]),
@@ -279,6 +281,8 @@ def main():
     lib.lqrhip_set_update_mode(args.update_mode)
     lib.lqrhip_set_band_levels.argtypes = [C.c_int]
     lib.lqrhip_set_band_levels(args.band_levels)
+    lib.lqrhip_set_vpath_mode.argtypes = [C.c_int, C.c_int]
+    lib.lqrhip_set_vpath_mode(args.vpath_mode, 0)
     if os.environ.get("LQR_LV_DBG"):
         lib.lqrhip_band_levels_debug.argtypes = [C.c_int]
         lib.lqrhip_band_levels_debug(int(os.environ["LQR_LV_DBG"]))
@@ -289,13 +293,22 @@ def main():
         lib.lqrhip_set_dp_persistent_px.argtypes = [C.c_int]
         lib.lqrhip_set_dp_persistent_px(args.dp_px)
     lib.lqrhip_moved_bytes.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # LQR_BENCH_DIST_BACKEND=gloo: the N > 1 control flow (barriers, max over ranks, the strong leg, the gather) on a box with ONE
+    # GPU -- ranks share device LOCAL_RANK mod device count and the collectives run on host tensors.  Not a measurement: it exists so
+    # that this code is not executed for the first time on the day an 8-GPU node appears (tests/test_bench_multirank_gpu.py).
+    backend = os.environ.get("LQR_BENCH_DIST_BACKEND", "nccl")
+    local_dev = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")        # where collective operands live
 
     dist = None
     if world > 1 or "RANK" in os.environ:       # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     def measure(wl, steps, warmup, headline, n_images=None):
         """one workload: set-up, `warmup` untimed + exactly `steps` timed steps, per-kernel breakdown, phases, CPU baseline;
@@ -332,7 +345,7 @@ def main():
         def max_over_ranks(x):
             if dist is None:
                 return x
-            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
 
@@ -340,7 +353,7 @@ def main():
         # carvers are created from HOST copies of them, as the plug-in creates its carver from a host buffer -- that is the
         # measured upload phase (lqr_carver_new uploads, lqr_carver_init allocates the working planes)
         t_setup = time.perf_counter()
-        images = make_images(nimg, W, H, 100 + rank * nimg, dev)
+        images = make_images(nimg, W, H, 100 + (rank * nimg if args.image_seed_offset is None else args.image_seed_offset), dev)
         torch.cuda.synchronize()
         host_imgs = [images[i].cpu().numpy() for i in range(nimg)]
         ptrs = [images[i].data_ptr() for i in range(nimg)]
@@ -503,7 +516,7 @@ def main():
             assert host_out[0].shape == (NH, NW, 4)
             del host_out
             upload_ms = max_over_ranks(upload_ms)
-        gather_ms = None
+        gather_ms = gathered_checksums = None
         outs = torch.empty((nimg, NH, NW, 4), dtype=torch.uint8, device=dev)
         if carvers[0].getters()["orientation"] == 0:
             for i, c in enumerate(carvers):
@@ -514,11 +527,13 @@ def main():
         if dist is not None and not args.no_gather:
             sync(); barrier()
             tg = time.perf_counter()
-            gathered = [torch.empty_like(outs) for _ in range(world)] if rank == 0 else None
-            dist.gather(outs, gathered, dst=0)
+            src = outs if backend == "nccl" else outs.cpu()
+            gathered = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
+            dist.gather(src, gathered, dst=0)
             sync()
             gather_ms = (time.perf_counter() - tg) * 1e3
-            del gathered
+            gathered_checksums = [int(g.to(torch.int64).sum().item()) for g in gathered] if rank == 0 else None       # what arrived from each rank
+            del gathered, src
         checksum = int(outs.to(torch.int64).sum().item())
         g = carvers[0].getters()
         assert (g["width"], g["height"]) == (NW, NH), g
@@ -544,6 +559,7 @@ def main():
             "roofline": roofline,
             "kernels_ms": {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in kern.items() if v[1]},
             "gather_ms": None if gather_ms is None else round(gather_ms, 2),
+            "gathered_checksums": gathered_checksums if gather_ms is not None else None,
             "setup_s": round(t_setup, 2),
             "hbm_used_gb": round(used_gb, 1), "hbm_total_gb": round(total_gb, 1),
             "output_checksum": checksum,
@@ -559,7 +575,7 @@ def main():
 
         # ---- config 4 as stated, on the same line when N > 1: 64 images in total = 64 // N per GPU (strong scaling)
         if headline and batch and world > 1 and not args.strong:
-            ns = strong_images_per_gpu(world)
+            ns = min(strong_images_per_gpu(world), nimg)
             el = timed(carvers[:ns], ptrs[:ns], steps, 1, 0)
             result["strong"] = {"images_total": ns * world, "images_per_gpu": ns, "scaling": "strong",
                                 "ms_per_step": round(el * 1e3 / steps, 3),
@@ -668,6 +684,7 @@ def main():
                                  **{k: v["value"] for k, v in result["configs"].items()})
     if dist is not None:
         result["rccl_ranks"] = dist.get_world_size()
+        result["dist_backend"] = backend
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

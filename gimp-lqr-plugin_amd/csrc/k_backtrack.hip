@@ -285,7 +285,123 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, i
 }
 
 
+// ---------------------------------------------------------------------------
+// Parallel backtrack (round 6): k_vp_maps -> k_vp_solve, for single images.
+//
+// k_vpath1 is one wave walking H dependent steps: 57 - 70 us per 4K seam whatever the chip has idle (20 % of a single image's seam
+// round).  Two multi-wave rewrites inside the workgroup lost to it (the backtrack on three waves).  The walk is function
+// composition -- column at row y - 1 = x + least[y][x] -- and composition is associative, so the chip can do most of it before
+// anybody knows where the seam ends:
+//   1. k_vp_maps: the rows are cut into chunks of R = VP_REACH / delta_x rows; for EVERY column x the walk across chunk c is done
+//      -- a workgroup per 256 columns and chunk stages the chunk's bytes in LDS and every thread walks its R steps there (dependent LDS
+//      reads, 4 K independent walks per chunk in flight) -- and written down: the displacement D_c[x] across the chunk (vp_map) and the
+//      displacement after every step (vp_path, four steps to a dword, [chunk][step / 4][x]).  No dependence on the argmin.
+//   2. k_vp_solve: one workgroup per image finds the argmin of the last row (as k_vpath1), then needs only ONE step per chunk,
+//      x <- x + D_c[x]: VP_STAGE chunks at a time, the part of the maps the path can reach from the stage's start (VP_REACH columns
+//      per chunk either way) loaded into LDS by all threads at once, then VP_STAGE dependent LDS reads; with every chunk's start
+//      known all threads pick the seam's rows out of vp_path (independent loads), record them (seam_x, the session log) and
+//      publish the side the carve moves (publish_side).
+// Two launches (a third one for the paths, walked again per chunk, cost more than it saved: a dependent launch is ~10 us).
+// Same results as k_vpath1 by construction (integer function composition); back pointers marked invalid by the carve do not
+// survive to the backtrack (see k_vpath1) -- a stray one is treated as 0, as k_vpath does, so that no walk can leave its window.
+// ---------------------------------------------------------------------------
+template <int DELTA>
+__global__ __launch_bounds__(256) void k_vp_maps(const DevCarver *cs, int w, int h, int stride)
+{
+    constexpr int R = vp_chunk_rows(DELTA), RD = R * DELTA, WIN = 256 + 2 * RD, R4 = (R + 3) / 4;        // RD <= VP_REACH
+    __shared__ __attribute__((aligned(4))) int8_t s_rows[R][WIN + 8];
+    const GCarver c = gview(cs[blockIdx.z]);
+    const int chunk = blockIdx.y, ytop = h - 1 - chunk * R, nrows = min(R, ytop);      // steps at rows ytop, ytop - 1, .. ytop - nrows + 1 (row 0 has none)
+    const int X0 = blockIdx.x * 256, base = X0 - RD, tid = threadIdx.x;
+    // stage: bytes [base, base + WIN) of the chunk's rows, as dwords (the plane's origin may make the address unaligned: fine on
+    // gfx950); columns outside [0, stride) are not loaded -- no path of the image goes there
+    constexpr int WD = (WIN + 3) / 4;
+    for (int i = tid; i < nrows * WD; i += 256) {
+        const int r = i / WD, d = i - r * WD, col = base + 4 * d;
+        uint32_t v = 0u;
+        if (col >= 0 && col + 3 < stride) v = *(const gu32 *) (c.least + (size_t) (ytop - r) * stride + col);
+        else for (int k = 0; k < 4; k++) if (col + k >= 0 && col + k < stride) v |= (uint32_t) (uint8_t) c.least[(size_t) (ytop - r) * stride + col + k] << (8 * k);
+        *(uint32_t *) &s_rows[r][4 * d] = v;
+    }
+    __syncthreads();
+    const int x = X0 + tid;
+    if (x >= w) return;
+    int p = x - base;
+    gu32 *path = (gu32 *) c.vp_path + (size_t) chunk * R4 * stride + x;
+#pragma unroll
+    for (int r4 = 0; r4 < R4; r4++) {
+        uint32_t pk = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = 4 * r4 + k;
+            pk |= (uint32_t) (uint8_t) (int8_t) (p + base - x) << (8 * k);          // the displacement BEFORE step r: the seam's column on row ytop - r
+            if (r < nrows) { const int d = s_rows[r < R ? r : 0][p]; p += (d == LEAST_INVALID) ? 0 : d; }
+        }
+        path[(size_t) r4 * stride] = pk;
+    }
+    c.vp_map[(size_t) chunk * stride + x] = (int8_t) (p + base - x);
+}
+
+template <int DELTA>
+__global__ __launch_bounds__(VPATH_THREADS) void k_vp_solve(const DevCarver *cs, int w, int h, int stride, int lr, int log_index, int moved_unit)
+{
+    constexpr int R = vp_chunk_rows(DELTA), RD = R * DELTA, S = VP_STAGE, CW = 2 * RD * S + 4, R4 = (R + 3) / 4;     // CW: cone width of a stage, a multiple of 4
+    const GCarver c = gview(cs[blockIdx.x]);
+    const int org = c.flags[FLAG_ORG];           // read before wave 0 publishes the next one
+    __shared__ float s_val[VPATH_THREADS / 64];
+    __shared__ int s_idx[VPATH_THREADS / 64];
+    __shared__ __attribute__((aligned(4))) int8_t s_cone[S][CW + 4];
+    extern __shared__ int s_xs[];                // [nchunks + 1]: the seam's column on the first row of every chunk, and on row 0
+    __shared__ int s_acc[VPATH_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int xmin = row_argmin(c.m + (size_t) (h - 1) * stride, w, lr, s_val, s_idx);
+    const int nchunks = (h - 1 + R - 1) / R;
+    int x = max(xmin, 0);                        // uniform
+    for (int c0 = 0; c0 < nchunks; c0 += S) {
+        const int ns = min(S, nchunks - c0);
+        const int base = (x - RD * S) & ~3;      // the path stays inside [x - RD S, x + RD S] during the stage
+        constexpr int WD = CW / 4 + 1;
+        for (int i = tid; i < ns * WD; i += VPATH_THREADS) {
+            const int j = i / WD, d = i - j * WD, col = base + 4 * d;
+            uint32_t v = 0u;
+            if (col >= 0 && col + 3 < stride) v = *(const gu32 *) (c.vp_map + (size_t) (c0 + j) * stride + col);
+            else for (int k = 0; k < 4; k++) if (col + k >= 0 && col + k < stride) v |= (uint32_t) (uint8_t) c.vp_map[(size_t) (c0 + j) * stride + col + k] << (8 * k);
+            *(uint32_t *) &s_cone[j][4 * d] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int xx = x;
+            for (int j = 0; j < ns; j++) { s_xs[c0 + j] = xx; xx += s_cone[j][xx - base]; }
+            s_xs[c0 + ns] = xx;
+        }
+        __syncthreads();
+        x = s_xs[c0 + ns];
+    }
+    // every row's column: the chunk's start + the recorded displacement before that row's step; row 0 is where the last chunk ends
+    gi32 *seam = c.seam_x, *logp = c.seam_log + (size_t) log_index * h;
+    int acc = 0;
+    for (int y = tid; y < h; y += VPATH_THREADS) {
+        int v;
+        if (y == 0) v = s_xs[nchunks];
+        else {
+            const int s = h - 1 - y, chunk = s / R, r = s - chunk * R, xs = s_xs[chunk];
+            v = xs + (int) ((const gi8 *) c.vp_path)[(((size_t) chunk * R4 + (r >> 2)) * stride + xs) * 4 + (r & 3)];
+        }
+        seam[y] = v; logp[y] = v; acc += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) s_acc[tid >> 6] = acc;
+    __syncthreads();
+    if (tid >= 64) return;
+    int total = 0;
+    if (lane == 0) for (int k = 0; k < VPATH_THREADS / 64; k++) total += s_acc[k];
+    publish_side(c, org, total, w, h, lane, moved_unit);
+}
+
 // ---- the instantiations the shim launches (lqr_kernels.h declares them)
+#define INST_VP(D) template __global__ void k_vp_maps<D>(const DevCarver *, int, int, int); \
+    template __global__ void k_vp_solve<D>(const DevCarver *, int, int, int, int, int, int);
+INST_VP(1) INST_VP(2) INST_VP(3) INST_VP(4)
 template __global__ void k_vpath1<1>(const DevCarver *, int, int, int, int, int, int);
 template __global__ void k_vpath1<2>(const DevCarver *, int, int, int, int, int, int);
 template __global__ void k_vpath1<3>(const DevCarver *, int, int, int, int, int, int);

@@ -91,6 +91,8 @@ struct DevCarver {
     int32_t *seam_x;
     int32_t *seam_log;
     int32_t *flags;
+    int8_t *vp_map;         // parallel backtrack (k_vp_*): per chunk of rows, the displacement of every column across the chunk
+    int8_t *vp_path;        // ... and after every step inside it ([chunk][step / 4][column][step % 4])
 };
 
 // Pointers fetched from a descriptor in memory are "generic" to the compiler, which then
@@ -126,6 +128,7 @@ struct GCarver {
     gi8 *least, *least2;
     gf32 *bias, *rig;
     gi32 *seam_x, *seam_log, *flags;
+    gi8 *vp_map, *vp_path;
 };
 
 // physical view: plane pointers as allocated (row y starts at y * stride); what the carve and the one-off
@@ -138,6 +141,7 @@ __device__ __forceinline__ GCarver gview_phys(const DevCarver &d)
     g.m2 = (gf32 *) d.m2; g.least2 = (gi8 *) d.least2;
     g.bias = (gf32 *) d.bias; g.rig = (gf32 *) d.rig;
     g.seam_x = (gi32 *) d.seam_x; g.seam_log = (gi32 *) d.seam_log; g.flags = (gi32 *) d.flags;
+    g.vp_map = (gi8 *) d.vp_map; g.vp_path = (gi8 *) d.vp_path;
     return g;
 }
 // logical view: the carved planes advanced by the image's current origin, so that x = 0 is the first pixel of
@@ -507,4 +511,9 @@ struct InflateDev {
     int ch;
 };
 #define EU_ROWS 62          // k_emap_update: rows per block (+2 halo rows)
+// parallel backtrack (k_backtrack.hip, k_vp_*): a chunk is VP_REACH / delta_x rows, so that a path moves at most VP_REACH columns
+// inside a chunk (the displacement fits a byte); k_vp_solve walks VP_STAGE chunks per LDS-resident stage
+constexpr int VP_REACH = 56;
+constexpr int VP_STAGE = 20;        // (4K: 39 chunks = 2 stages; the cone of a stage is 2 * 56 * 20 columns wide: 45 KB of LDS)
+constexpr int vp_chunk_rows(int delta) { return VP_REACH / delta; }
 #define VP_ROWS 62

@@ -18,6 +18,9 @@ __global__ __launch_bounds__(256) void k_frozen_catchup(const DevCarver *cs, int
 __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, int w, int h, int stride, int lr, int delta, int log_index, int moved_unit);
 template <int DELTA> __global__ __launch_bounds__(VPATH_THREADS) void k_vpath1(const DevCarver *cs, int w, int h, int stride, int lr, int log_index, int moved_unit);
 
+template <int DELTA> __global__ __launch_bounds__(256) void k_vp_maps(const DevCarver *cs, int w, int h, int stride);
+template <int DELTA> __global__ __launch_bounds__(VPATH_THREADS) void k_vp_solve(const DevCarver *cs, int w, int h, int stride, int lr, int log_index, int moved_unit);
+
 // k_carve.hip
 __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h, int stride, int delta, int move_dp);
 

@@ -199,6 +199,10 @@ void lqrhip_prof_enable(int on);
  * one-wave band kernel k_band_update + k_dp_sweep (what delta_x > 4 runs on) whatever the parameters, 5 k_band_levels
  * (4 was round 4's k_band_tiles, removed in round 6: it now behaves as 0) */
 void lqrhip_set_update_mode(int mode);
+/* E7 form: -1 = the parallel two-kernel backtrack (k_vp_maps / k_vp_solve) for groups of up to par_max images (default 2; 0 keeps the
+ * current value) of 1000 rows and more, the one-wave walk k_vpath1 otherwise; 0 = k_vpath1 always; 1 = the parallel form
+ * always (delta_x 1 .. 4) */
+void lqrhip_set_vpath_mode(int mode, int par_max);
 /* Cap on the workgroups of the persistent tiled DP sweep (k_dp_tile_p), whose tiles spin on their neighbours and
  * must all be resident: -1 = the bound derived from the occupancy query at lqrhip_init, n >= 0 = min(n, that bound).
  * Grids above the cap run as k_dp_tile (one launch per 32 rows).  0 forces that path (tests). */

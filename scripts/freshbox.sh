@@ -4,7 +4,7 @@
 # usage (one gpurun call = one fresh box): gpurun -- 'bash scripts/freshbox.sh TAG'
 tag=${1:-a}; mkdir -p gpurun_out/freshbox; L=gpurun_out/freshbox/$tag.log
 date > $L
-for i in 1 2 3; do
+for i in $(seq ${PASSES:-1}); do
   python -m pytest tests/test_abi.py tests/test_batch_fuzz_gpu.py tests/test_build_variants.py -m gpu -q -p no:cacheprovider >> $L 2>&1
   echo "box $tag pass $i rc $? $(grep -E 'passed|failed' $L | tail -1)"
 done

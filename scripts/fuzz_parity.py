@@ -36,6 +36,8 @@ rng = np.random.default_rng(seed)
 o = L.oracle_api()
 e = L.engine_api()
 e.lib.lqrhip_set_update_mode.argtypes = [ctypes.c_int]
+if os.environ.get("LQR_VP"):             # the parallel backtrack forced for every case (default: images of 1400 rows and more only)
+    e.lib.lqrhip_set_vpath_mode.argtypes = [ctypes.c_int, ctypes.c_int]; e.lib.lqrhip_set_vpath_mode(int(os.environ["LQR_VP"]), 0)
 fails = FC.Failures(e.lib)
 n = 0
 while budget.more(n):
