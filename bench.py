@@ -310,11 +310,12 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    def measure(wl, steps, warmup, headline, n_images=None):
+    def measure(wl, steps, warmup, headline, n_images=None, delta=None):
         """one workload: set-up, `warmup` untimed + exactly `steps` timed steps, per-kernel breakdown, phases, CPU baseline;
         `headline`: also the gather / strong / all-cores legs; `n_images`: images per GPU of a batch workload other than the
         command line's.  Returns the JSON object of the workload."""
         W, H, NW, NH = WORKLOADS[wl]
+        dlt = delta if delta is not None else args.delta
         batch = wl == "batch4k"
         nimg = (n_images or args.images_per_gpu) if batch else 1
         if batch and args.strong and not n_images:
@@ -360,7 +361,7 @@ def main():
         bufs = [L._malloc_copy(im) for im in host_imgs]      # liblqr takes ownership of a malloc'ed buffer (render.c:222)
         sync()
         tu = time.perf_counter()
-        carvers = [L.Carver.from_buffer(eng, bufs[i], W, H, 4, delta_x=args.delta, rigidity=rigidity) for i in range(nimg)]
+        carvers = [L.Carver.from_buffer(eng, bufs[i], W, H, 4, delta_x=dlt, rigidity=rigidity) for i in range(nimg)]
         sync()
         upload_ms = (time.perf_counter() - tu) * 1e3
         for c in carvers:
@@ -543,9 +544,9 @@ def main():
         variant = ""
         if wl == "config5":
             variant = ", preservation ellipse +1000, discard band -1000, rigidity %g, delta_x %d%s" % (
-                rigidity, args.delta, ", rigidity mask (top half)" if rigm is not None else "")
-        elif args.delta != 1 or rigidity:
-            variant = ", rigidity %g, delta_x %d" % (rigidity, args.delta)
+                rigidity, dlt, ", rigidity mask (top half)" if rigm is not None else "")
+        elif dlt != 1 or rigidity:
+            variant = ", rigidity %g, delta_x %d" % (rigidity, dlt)
         result = {
             "metric": "Mseams*pixels/sec on 4K RGBA", "value": round(value, 1), "unit": "Mseams*px/s",
             "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -595,7 +596,7 @@ def main():
                 sample = "1 image %dx%d -> %dx%d (first %d seams of the workload), 1 core" % (cw, chh, cnw, cnh, (W - cnw) + (H - cnh))
 
             def oracle_carver(im):
-                o = L.Carver(orc, im, delta_x=args.delta, rigidity=rigidity).configure(switch_freq=args.switch_freq, enl_step=1.5)
+                o = L.Carver(orc, im, delta_x=dlt, rigidity=rigidity).configure(switch_freq=args.switch_freq, enl_step=1.5)
                 add_masks([o])
                 return o
             oc = oracle_carver(img0_host)
@@ -638,7 +639,7 @@ def main():
             bufs = [L._malloc_copy(im) for im in host_keep]
             sync()
             tu = time.perf_counter()
-            cs2 = [L.Carver.from_buffer(eng, bufs[i], W, H, 4, delta_x=args.delta, rigidity=rigidity) for i in range(nimg)]
+            cs2 = [L.Carver.from_buffer(eng, bufs[i], W, H, 4, delta_x=dlt, rigidity=rigidity) for i in range(nimg)]
             sync()
             warm = max_over_ranks((time.perf_counter() - tu) * 1e3)
             for c in cs2:
@@ -670,11 +671,15 @@ def main():
         keep = ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernels_ms", "phases", "cpu_baseline", "parity_vs_oracle", "hbm_used_gb")
         # (batch4k_96img: the headline's 64 images are four chains of 16 in flight and the chain's latency, not the chip, bounds
         # them -- half as many images again run through the same four streams in a fifth more time: DESIGN.md 4.11 / 9)
-        legs = [("batch4k_8img", "batch4k", 8), ("fhd", "fhd", None), ("single4k", "single4k", None), ("config5", "config5", None), ("batch4k_96img", "batch4k", 96)]
-        for name, wl, images in legs:
-            if images and images == args.images_per_gpu:
+        # (round 6: delta_x 10 / 8 -- the upper half of the plug-in's dialog range, src/interface.c:47 -- on the tiled kernels' general instantiations)
+        legs = [("batch4k_8img", "batch4k", 8, None, 3), ("fhd", "fhd", None, None, 3), ("single4k", "single4k", None, None, 3), ("config5", "config5", None, None, 3),
+                ("batch4k_96img", "batch4k", 96, None, 3), ("single4k_delta10", "single4k", None, 10, 1), ("batch4k_16img_delta8", "batch4k", 16, 8, 1)]
+        for name, wl, images, leg_delta, leg_steps in legs:
+            if images and images == args.images_per_gpu and leg_delta is None:
                 continue
-            r = measure(wl, 3, 1, False, n_images=images)
+            if leg_delta is not None and args.delta != 1:
+                continue
+            r = measure(wl, leg_steps, 1, False, n_images=images, delta=leg_delta)
             for rk in (r.get("roofline") or {}, r.get("phases") or {}):
                 rk.pop("note", None)                      # said once, on the headline
             result["configs"][name] = {k: r[k] for k in keep if k in r}

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vpath(const DevCarver *cs, in
 // ---------------------------------------------------------------------------
 // rows per chunk by delta_x: the path drifts up to ROWS * delta_x columns inside a chunk and must stay within lanes 4 .. 60 of the 64
 // spread around its start (<= 28), and the window loaded VP1_AHEAD chunks ahead must still hold those 64 columns
-constexpr int vp1_rows(int delta) { return delta == 1 ? 28 : delta == 2 ? 12 : delta == 3 ? 8 : 4; }
+constexpr int vp1_rows(int delta) { return delta == 1 ? 28 : delta == 2 ? 12 : delta == 3 ? 8 : 4; }      // (delta_x 4 .. 7: 4 rows)
 #define VP1_AHEAD 3
 template <int r>
 __device__ __forceinline__ void vp1_step(const int e, int &o, int &path)
@@ -345,12 +345,13 @@ __global__ __launch_bounds__(256) void k_vp_maps(const DevCarver *cs, int w, int
 template <int DELTA>
 __global__ __launch_bounds__(VPATH_THREADS) void k_vp_solve(const DevCarver *cs, int w, int h, int stride, int lr, int log_index, int moved_unit)
 {
-    constexpr int R = vp_chunk_rows(DELTA), RD = R * DELTA, S = VP_STAGE, CW = 2 * RD * S + 4, R4 = (R + 3) / 4;     // CW: cone width of a stage, a multiple of 4
+    constexpr int R = vp_chunk_rows(DELTA), RD = R * DELTA, S = VP_STAGE, R4 = (R + 3) / 4;
+    constexpr int CP = (2 * RD * S + 4 + 15 + 16) & ~15;       // LDS pitch of a stage's rows: the cone [x - RD S, x + RD S] from a base rounded down to 4, in 16-byte units
     const GCarver c = gview(cs[blockIdx.x]);
     const int org = c.flags[FLAG_ORG];           // read before wave 0 publishes the next one
     __shared__ float s_val[VPATH_THREADS / 64];
     __shared__ int s_idx[VPATH_THREADS / 64];
-    __shared__ __attribute__((aligned(4))) int8_t s_cone[S][CW + 4];
+    __shared__ __attribute__((aligned(16))) int8_t s_cone[S][CP];
     extern __shared__ int s_xs[];                // [nchunks + 1]: the seam's column on the first row of every chunk, and on row 0
     __shared__ int s_acc[VPATH_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -360,13 +361,29 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vp_solve(const DevCarver *cs,
     for (int c0 = 0; c0 < nchunks; c0 += S) {
         const int ns = min(S, nchunks - c0);
         const int base = (x - RD * S) & ~3;      // the path stays inside [x - RD S, x + RD S] during the stage
-        constexpr int WD = CW / 4 + 1;
-        for (int i = tid; i < ns * WD; i += VPATH_THREADS) {
-            const int j = i / WD, d = i - j * WD, col = base + 4 * d;
-            uint32_t v = 0u;
-            if (col >= 0 && col + 3 < stride) v = *(const gu32 *) (c.vp_map + (size_t) (c0 + j) * stride + col);
-            else for (int k = 0; k < 4; k++) if (col + k >= 0 && col + k < stride) v |= (uint32_t) (uint8_t) c.vp_map[(size_t) (c0 + j) * stride + col + k] << (8 * k);
-            *(uint32_t *) &s_cone[j][4 * d] = v;
+        // the stage's part of the maps into LDS, 16 bytes per load (4-byte aligned: fine on gfx950); row j is only needed within RD (j + 1)
+        // columns of x -- the rest of its cone is not loaded (delta_x 10 at 4K is 22 stages: this loop is what a stage costs)
+        // ALL loads of a thread are issued before the first is stored to LDS: as one loop (load, store, load, ...) every iteration waited for
+        // its own round trip -- 5 or 6 of them per stage, 9 us per stage, 245 us per 4K seam at delta_x 10
+        constexpr int W16 = CP / 16, NI = (S * W16 + VPATH_THREADS - 1) / VPATH_THREADS;
+        u32x4 v[NI];
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int i = tid + k * VPATH_THREADS, j = i / W16, d = i - j * W16, col = base + 16 * d;
+            v[k] = (u32x4) {0u, 0u, 0u, 0u};
+            if (i >= ns * W16 || col + 15 < x - RD * (j + 1) || col > x + RD * (j + 1)) continue;
+            const gi8 *src = c.vp_map + (size_t) (c0 + j) * stride + col;
+            if (col >= 0 && col + 15 < stride) v[k] = *(const GLOBAL_AS u32x4 *) src;
+            else {
+                uint32_t q4[4] = {0u, 0u, 0u, 0u};
+                for (int b = 0; b < 16; b++) if (col + b >= 0 && col + b < stride) q4[b >> 2] |= (uint32_t) (uint8_t) src[b] << (8 * (b & 3));
+                v[k] = (u32x4) {q4[0], q4[1], q4[2], q4[3]};
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int i = tid + k * VPATH_THREADS, j = i / W16, d = i - j * W16;
+            if (i < ns * W16) *(u32x4 *) &s_cone[j][16 * d] = v[k];
         }
         __syncthreads();
         if (tid == 0) {
@@ -401,8 +418,11 @@ __global__ __launch_bounds__(VPATH_THREADS) void k_vp_solve(const DevCarver *cs,
 // ---- the instantiations the shim launches (lqr_kernels.h declares them)
 #define INST_VP(D) template __global__ void k_vp_maps<D>(const DevCarver *, int, int, int); \
     template __global__ void k_vp_solve<D>(const DevCarver *, int, int, int, int, int, int);
-INST_VP(1) INST_VP(2) INST_VP(3) INST_VP(4)
+INST_VP(1) INST_VP(2) INST_VP(3) INST_VP(4) INST_VP(5) INST_VP(6) INST_VP(7) INST_VP(8) INST_VP(9) INST_VP(10)
 template __global__ void k_vpath1<1>(const DevCarver *, int, int, int, int, int, int);
 template __global__ void k_vpath1<2>(const DevCarver *, int, int, int, int, int, int);
 template __global__ void k_vpath1<3>(const DevCarver *, int, int, int, int, int, int);
 template __global__ void k_vpath1<4>(const DevCarver *, int, int, int, int, int, int);
+template __global__ void k_vpath1<5>(const DevCarver *, int, int, int, int, int, int);
+template __global__ void k_vpath1<6>(const DevCarver *, int, int, int, int, int, int);
+template __global__ void k_vpath1<7>(const DevCarver *, int, int, int, int, int, int);

@@ -85,7 +85,7 @@ template <bool LR, bool RIG, int DELTA, bool RIGM>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err, int P, int n_img)
 {
-    static_assert(DELTA >= 1 && DELTA <= 4 && (RIG || !RIGM), "delta_x 1 .. 4; a rigidity mask only matters with rigidity");
+    static_assert(DELTA >= 1 && DELTA <= LQR_FAST_MAX_DELTA && (DELTA <= 4 || RIG) && (RIG || !RIGM), "delta_x 1 .. 10 (5 .. 10: the rigidity form, with a zero table if there is none); a rigidity mask only matters with rigidity");
     constexpr int PX = 2, HALO = 32, OWN = 64, HL = 16, R = lv_rows(DELTA, RIGM), TILE = 128;
     static_assert(R * DELTA <= HALO, "a level's errors stay inside the halo");
     typedef LaneVec<2>::F FV;
@@ -252,14 +252,7 @@ void k_band_levels(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long
                 dp_row<PX, LR, RIG, true, false>(mp, left, right, e, mo, (uint32_t) q_lo[r], in, rig_l, rig_r, mc, lnew, ch);
             } else {
                 float nl[DELTA], nr[DELTA], rf[PX];
-#pragma unroll
-                for (int i = 0; i < DELTA; i++) {       // pixel i % PX of the lane i / PX + 1 away: one wave shift per lane
-                    int a = __builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1 - i % PX]), DPP_WAVE_SHR1, 0xf, 0xf, true);
-                    int b2 = __builtin_amdgcn_mov_dpp(__float_as_int(mp[i % PX]), DPP_WAVE_SHL1, 0xf, 0xf, true);
-                    if (i >= PX) { a = __builtin_amdgcn_mov_dpp(a, DPP_WAVE_SHR1, 0xf, 0xf, true); b2 = __builtin_amdgcn_mov_dpp(b2, DPP_WAVE_SHL1, 0xf, 0xf, true); }
-                    nl[i] = __int_as_float(a);
-                    nr[i] = __int_as_float(b2);
-                }
+                lane_reach<PX, DELTA>(mp, nl, nr);
 #pragma unroll
                 for (int k = 0; k < PX; k++) rf[k] = RIGM ? q_rf[RIGM ? r : 0][k] : 1.0f;
                 dp_row_g<PX, DELTA, LR, RIG, RIGM, true, false>(mp, nl, nr, e, mo, (uint32_t) q_lo[r], in, rg, rf, mc, lnew, ch);
@@ -523,5 +516,8 @@ extern "C" int lqrhip_band_levels_stats(unsigned long long *out, int reset)
 #define INST_LV_LR(LRV) INST_LV(LRV, false, 1, false) INST_LV(LRV, true, 1, false) INST_LV(LRV, true, 1, true) \
     INST_LV(LRV, false, 2, false) INST_LV(LRV, true, 2, false) INST_LV(LRV, true, 2, true) \
     INST_LV(LRV, false, 3, false) INST_LV(LRV, true, 3, false) INST_LV(LRV, true, 3, true) \
-    INST_LV(LRV, false, 4, false) INST_LV(LRV, true, 4, false) INST_LV(LRV, true, 4, true)
+    INST_LV(LRV, false, 4, false) INST_LV(LRV, true, 4, false) INST_LV(LRV, true, 4, true) \
+    INST_LV(LRV, true, 5, false) INST_LV(LRV, true, 5, true) INST_LV(LRV, true, 6, false) INST_LV(LRV, true, 6, true) \
+    INST_LV(LRV, true, 7, false) INST_LV(LRV, true, 7, true) INST_LV(LRV, true, 8, false) INST_LV(LRV, true, 8, true) \
+    INST_LV(LRV, true, 9, false) INST_LV(LRV, true, 9, true) INST_LV(LRV, true, 10, false) INST_LV(LRV, true, 10, true)
 INST_LV_LR(false) INST_LV_LR(true)

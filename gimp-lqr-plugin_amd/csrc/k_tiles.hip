@@ -136,7 +136,7 @@ __device__ int g_dpp_dbg;          // experiment switches (lqrhip_dp_tile_debug)
 template <int PX, bool LR, bool RIG, bool UPDATE, int DELTA, bool RIGM>
 __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err)
 {
-    static_assert(DELTA >= 1 && DELTA <= 4 && DELTA <= 2 * PX && (RIG || !RIGM), "delta_x 1 .. 4; a rigidity mask only matters with rigidity");
+    static_assert(DELTA >= 1 && DELTA <= LQR_FAST_MAX_DELTA && (DELTA <= 4 || (PX == 2 && RIG)) && (RIG || !RIGM), "delta_x 1 .. 10 (5 .. 10: the rigidity form, with a zero table if there is none); a rigidity mask only matters with rigidity");
     typedef typename LaneVec<PX>::F FV;
     typedef typename LaneVec<PX>::L LV;
     typedef GLOBAL_AS FV GFV;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
     // block, as the delta_x = 2 instantiations do with their 16-row blocks): half the hand-overs, barriers and loop
     // iterations of 16-row batches for 80 more staging registers (193 VGPRs, no spill; the residency bound is queried per
     // instantiation).  Measured on one box: 4K 20.0 -> 21.85 k, FHD 12.3 -> 13.1 k, config 5 50.9 -> 55.9 k.
-    constexpr int R = (PX == 2 && DELTA == 1 && (!RIGM || DPP_RIGM32)) ? DPP_R2 : DELTA >= 3 ? 8 : DPP_R;      // delta_x 3, 4: 8-row blocks (errors move up to 4 columns per row)
+    constexpr int R = (PX == 2 && DELTA == 1 && (!RIGM || DPP_RIGM32)) ? DPP_R2 : DELTA >= 5 ? dpp_rb(PX, DELTA) : DELTA >= 3 ? 8 : DPP_R;      // delta_x 3, 4: 8-row blocks (errors move up to 4 columns per row); 5 .. 10: 6 .. 3 rows
     FV q_e[R], q_mo[R], q_rf[RIGM ? R : 1];
     LV q_lo[R];
     constexpr int RB = dpp_rb(PX, DELTA), NBB = RB / R;          // rows, batches per block
@@ -246,14 +246,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     } else {
                         // the neighbouring lanes' pixels next to this lane's: DELTA on each side (DELTA <= PX)
                         float nl[DELTA], nr[DELTA], rf[PX];
-#pragma unroll
-                        for (int i = 0; i < DELTA; i++) {       // pixel i % PX of the lane i / PX + 1 away: one wave shift per lane
-                            int a = __builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1 - i % PX]), DPP_WAVE_SHR1, 0xf, 0xf, true);
-                            int b2 = __builtin_amdgcn_mov_dpp(__float_as_int(mp[i % PX]), DPP_WAVE_SHL1, 0xf, 0xf, true);
-                            if (i >= PX) { a = __builtin_amdgcn_mov_dpp(a, DPP_WAVE_SHR1, 0xf, 0xf, true); b2 = __builtin_amdgcn_mov_dpp(b2, DPP_WAVE_SHL1, 0xf, 0xf, true); }
-                            nl[i] = __int_as_float(a);
-                            nr[i] = __int_as_float(b2);
-                        }
+                        lane_reach<PX, DELTA>(mp, nl, nr);       // the neighbouring lanes' pixels next to this lane's: DELTA on each side
 #pragma unroll
                         for (int k = 0; k < PX; k++) rf[k] = RIGM ? q_rf[RIGM ? r : 0][k] : 1.0f;
                         dp_row_g<PX, DELTA, LR, RIG, RIGM, UPDATE, MASK>(mp, nl, nr, e, mo, UPDATE ? (uint32_t) q_lo[r] : 0u, in, rg, rf, mc, lnew, ch);
@@ -292,14 +285,7 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                 dp_row<PX, LR, RIG, true, false>(mp, left, right, e, mo, (uint32_t) q_lo[r], in, rig_l, rig_r, mc, lnew, ch);
             } else {
                 float nl[DELTA], nr[DELTA], rf[PX];
-#pragma unroll
-                for (int i = 0; i < DELTA; i++) {       // pixel i % PX of the lane i / PX + 1 away: one wave shift per lane
-                    int a = __builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1 - i % PX]), DPP_WAVE_SHR1, 0xf, 0xf, true);
-                    int b2 = __builtin_amdgcn_mov_dpp(__float_as_int(mp[i % PX]), DPP_WAVE_SHL1, 0xf, 0xf, true);
-                    if (i >= PX) { a = __builtin_amdgcn_mov_dpp(a, DPP_WAVE_SHR1, 0xf, 0xf, true); b2 = __builtin_amdgcn_mov_dpp(b2, DPP_WAVE_SHL1, 0xf, 0xf, true); }
-                    nl[i] = __int_as_float(a);
-                    nr[i] = __int_as_float(b2);
-                }
+                lane_reach<PX, DELTA>(mp, nl, nr);
 #pragma unroll
                 for (int k = 0; k < PX; k++) rf[k] = RIGM ? q_rf[RIGM ? r : 0][k] : 1.0f;
                 dp_row_g<PX, DELTA, LR, RIG, RIGM, true, false>(mp, nl, nr, e, mo, (uint32_t) q_lo[r], in, rg, rf, mc, lnew, ch);
@@ -494,5 +480,8 @@ INST_TILE(false, false) INST_TILE(false, true) INST_TILE(true, false) INST_TILE(
     INST_P(2, LRV, true, UPD, 1, true) \
     INST_P(2, LRV, false, UPD, 2, false) INST_P(2, LRV, true, UPD, 2, false) INST_P(2, LRV, true, UPD, 2, true) \
     INST_P(2, LRV, false, UPD, 3, false) INST_P(2, LRV, true, UPD, 3, false) INST_P(2, LRV, true, UPD, 3, true) \
-    INST_P(2, LRV, false, UPD, 4, false) INST_P(2, LRV, true, UPD, 4, false) INST_P(2, LRV, true, UPD, 4, true)
+    INST_P(2, LRV, false, UPD, 4, false) INST_P(2, LRV, true, UPD, 4, false) INST_P(2, LRV, true, UPD, 4, true) \
+    INST_P(2, LRV, true, UPD, 5, false) INST_P(2, LRV, true, UPD, 5, true) INST_P(2, LRV, true, UPD, 6, false) INST_P(2, LRV, true, UPD, 6, true) \
+    INST_P(2, LRV, true, UPD, 7, false) INST_P(2, LRV, true, UPD, 7, true) INST_P(2, LRV, true, UPD, 8, false) INST_P(2, LRV, true, UPD, 8, true) \
+    INST_P(2, LRV, true, UPD, 9, false) INST_P(2, LRV, true, UPD, 9, true) INST_P(2, LRV, true, UPD, 10, false) INST_P(2, LRV, true, UPD, 10, true)
 INST_P_LR(false, false) INST_P_LR(false, true) INST_P_LR(true, false) INST_P_LR(true, true)

@@ -440,7 +440,6 @@ __device__ __forceinline__ void dp_row_g(const float (&mp)[PX], const float (&nl
                                          const float (&mo)[PX], const uint32_t lo, const bool (&in)[PX], const float (&rg)[2 * DELTA + 1],
                                          const float (&rf)[PX], float (&mc)[PX], uint32_t &lnew, bool (&ch)[PX])
 {
-    static_assert(DELTA <= 2 * PX, "the two neighbouring lanes hold the whole reach");
     const float INF = __int_as_float(0x7f800000);
     float nm[PX];
     lnew = 0;
@@ -476,6 +475,31 @@ __device__ __forceinline__ void dp_row_g(const float (&mp)[PX], const float (&nl
         mc[k] = (!MASK || in[k]) ? v : INF;
     }
 }
+// nl[i] / nr[i] for dp_row_g: the row above at this lane's first pixel - 1 - i / last pixel + 1 + i, i < DELTA -- pixel i % PX of the lane
+// i / PX + 1 lanes away.  The adjacent lane by a DPP wave shift (bound_ctrl: lane 0's left / lane 63's right neighbour read as 0), the
+// second one by two (delta_x <= 4, rounds 3 - 4); lanes further away (delta_x 5 .. 10, round 6) by ds_bpermute, whose lane index wraps
+// around the wave.  Either way what the outermost lanes receive is wrong by construction: they are halo, the error moves inwards
+// DELTA columns per row, and a block is HALO / DELTA rows.
+template <int PX, int DELTA>
+__device__ __forceinline__ void lane_reach(const float (&mp)[PX], float (&nl)[DELTA], float (&nr)[DELTA])
+{
+    const int lane4 = (int) (threadIdx.x & 63) << 2;
+#pragma unroll
+    for (int i = 0; i < DELTA; i++) {
+        const int away = i / PX + 1;
+        int a, b2;
+        if (away <= 2) {
+            a = __builtin_amdgcn_mov_dpp(__float_as_int(mp[PX - 1 - i % PX]), DPP_WAVE_SHR1, 0xf, 0xf, true);
+            b2 = __builtin_amdgcn_mov_dpp(__float_as_int(mp[i % PX]), DPP_WAVE_SHL1, 0xf, 0xf, true);
+            if (away == 2) { a = __builtin_amdgcn_mov_dpp(a, DPP_WAVE_SHR1, 0xf, 0xf, true); b2 = __builtin_amdgcn_mov_dpp(b2, DPP_WAVE_SHL1, 0xf, 0xf, true); }
+        } else {
+            a = __builtin_amdgcn_ds_bpermute(lane4 - 4 * away, __float_as_int(mp[PX - 1 - i % PX]));
+            b2 = __builtin_amdgcn_ds_bpermute(lane4 + 4 * away, __float_as_int(mp[i % PX]));
+        }
+        nl[i] = __int_as_float(a);
+        nr[i] = __int_as_float(b2);
+    }
+}
 // PX floats / PX back-pointer bytes of one lane, as one load or store
 template <int PX> struct LaneVec;
 template <> struct LaneVec<2> { typedef float F __attribute__((ext_vector_type(2))); typedef uint16_t L; };
@@ -487,7 +511,7 @@ template <> struct LaneVec<4> { typedef f32x4 F; typedef uint32_t L; };
 constexpr int dpp_halo(int px) { return 16 * px; }              // halo columns on each side = rows per block
 constexpr int dpp_own(int px) { return 64 * px - 2 * dpp_halo(px); }     // columns a tile owns
 constexpr int dpp_ex_tile(int px) { return 2 * 2 * dpp_halo(px); }       // granules a tile publishes: [block parity][side: 0 to the left, 1 to the right][column]
-constexpr int dpp_rb(int px, int delta) { return delta >= 3 ? 8 : dpp_halo(px) / delta; }      // rows per block
+constexpr int dpp_rb(int px, int delta) { return delta >= 5 ? dpp_halo(2) / delta : delta >= 3 ? 8 : dpp_halo(px) / delta; }      // rows per block (delta_x 5 .. 10: 6, 5, 4, 4, 3, 3)
 constexpr int DPP_R = 16;                       // rows per batch
 constexpr int DPP_W = 2;                        // waves taking turns
 static_assert(dpp_halo(2) % (2 * DPP_R) == 0 && dpp_halo(4) % (2 * DPP_R) == 0, "a block (halo / delta_x rows, delta_x <= 2) is a whole number of batches");
@@ -497,8 +521,9 @@ constexpr int DPP_BLK_BITS = 12;                // bits of the block index in a 
 // k_band_levels (k_levels.hip): slots per image at most, tiles per image at most (one 64-bit mask: rows up to 4096 px)
 constexpr int LV_PMAX = 16;
 constexpr int LV_MAX_TILES = 64;
-constexpr int LV_MAX_LEVELS = 512;        // levels per image at most (10 bits of the tags; rows up to 4096 at delta_x >= 3)
-constexpr int lv_rows(int delta, bool rigm = false) { return delta == 1 ? (rigm ? 16 : 32) : delta == 2 ? 16 : 8; }      // rows per level: halo (32 columns) / delta_x (a rigidity mask: 16, for the registers)
+constexpr int LV_MAX_LEVELS = 1020;       // levels per image at most (10 bits of the tags hold level + 1; 4K rows at delta_x 10: 720 levels of 3 rows)
+constexpr int lv_rows(int delta, bool rigm = false) { return delta == 1 ? (rigm ? 16 : 32) : delta == 2 ? 16 : delta <= 4 ? 8 : 32 / delta; }      // rows per level: halo (32 columns) / delta_x (a rigidity mask: 16, for the registers)
+constexpr int LQR_FAST_MAX_DELTA = 10;    // delta_x up to which the tiled kernels have instantiations (the plug-in's UI: src/interface.c:47, MAX_DELTA_X 10)
 
 // a job of the one-launch plane passes (inflate, flatten, transpose): one carver (root or attached) of a batch
 struct InflateDev {

@@ -113,6 +113,9 @@ static int dpp_resident_workgroups(int dev)
     q(k_dp_tile_p<2, LRV, false, UPD, 4, false>); q(k_dp_tile_p<2, LRV, true, UPD, 4, false>); q(k_dp_tile_p<2, LRV, true, UPD, 4, true>)
     QG(false, false); QG(false, true); QG(true, false); QG(true, true);
 #undef QG
+#define QW(DV) q(k_dp_tile_p<2, false, true, false, DV, false>); q(k_dp_tile_p<2, false, true, true, DV, false>); q(k_dp_tile_p<2, true, true, false, DV, true>); q(k_dp_tile_p<2, true, true, true, DV, true>)
+    QW(5); QW(6); QW(7); QW(8); QW(9); QW(10);         // delta_x 5 .. 10 (round 6): few staged rows, wide candidate scans
+#undef QW
     g_dpp_max_wgs_general = std::max(0, per_cu - 1) * prop.multiProcessorCount;
     {
         int per_cu = 1 << 20;
@@ -127,6 +130,9 @@ static int dpp_resident_workgroups(int dev)
     ql(k_band_levels<LRV, false, 4, false>); ql(k_band_levels<LRV, true, 4, false>); ql(k_band_levels<LRV, true, 4, true>)
         QL(false); QL(true);
 #undef QL
+#define QLW(DV) ql(k_band_levels<false, true, DV, false>); ql(k_band_levels<true, true, DV, false>); ql(k_band_levels<false, true, DV, true>); ql(k_band_levels<true, true, DV, true>)
+        QLW(5); QLW(6); QLW(7); QLW(8); QLW(9); QLW(10);
+#undef QLW
         g_dpp_max_wgs_levels = std::max(0, per_cu - 1) * prop.multiProcessorCount;
     }
     return g_dpp_max_wgs_plain;
@@ -930,14 +936,19 @@ static bool dp_persistent_ok(const LqrHipBatch *b, int w) { return dp_persistent
 // rigidity-mask carvers on the tiled kernels (k_dp_tile_p's general instantiations: one workgroup per 64 columns per image,
 // all co-resident).  Beyond it such a batch would fall to the one-wave-per-image band kernel (~30x slower), so the host
 // carves larger batches of such carvers group after group (host/lqr_carver.c, lqrx_carver_resize_batch).  0: no bound known.
-extern "C" int lqrhip_general_batch_limit(int w)
+extern "C" int lqrhip_general_batch_limit_delta(int w, int delta);
+extern "C" int lqrhip_general_batch_limit(int w) { return lqrhip_general_batch_limit_delta(w, 2); }
+extern "C" int lqrhip_general_batch_limit_delta(int w, int delta)
 {
     if (lqrhip_init() < 0 || w < 1) return 0;
     const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_general) : g_dpp_max_wgs_general;
     const int tiled = limit / ((w + dpp_own(2) - 1) / dpp_own(2));
     // round 5: groups of 8 and more such carvers run on k_band_levels (7 or more slots per image, rows up to 4096 px), which takes
     // far larger groups than the full-width tiled kernels; its full DPs (3 per resize) then go to k_dp_sweep, one workgroup per image
-    if (g_band_levels != 0 && g_update_mode < 0 && (w + 63) / 64 <= LV_MAX_TILES) {
+    // (delta_x 5 .. 10, round 6: the full-width tiled kernels only -- a change moves up to ten columns per row, the band is the whole
+    // width after a few hundred rows and the level kernel's images stop at a collision: 16 x 4K at delta_x 8 spent 6.6 of 9.6 ms per seam
+    // in the sweep that takes over)
+    if (delta <= 4 && g_band_levels != 0 && g_update_mode < 0 && (w + 63) / 64 <= LV_MAX_TILES) {
         const int lim_lv = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_levels) : g_dpp_max_wgs_levels;
         const int lv = lim_lv / 7;
         if (lv >= 8) return std::max(tiled, lv);
@@ -957,7 +968,7 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
     for (auto *c : b->cs) rigm |= (c->rig != nullptr);
     rigm = rigm && k.use_rig;                                  // without rigidity the mask multiplies nothing
     const bool general = k.delta != 1 || rigm;
-    if (k.delta < 1 || k.delta > 4) return LQRHIP_EARG;
+    if (k.delta < 1 || k.delta > LQR_FAST_MAX_DELTA) return LQRHIP_EARG;
     const int px = dp_persistent_px(b, w, general, k.delta, count);
     if (!px) return LQRHIP_EARG;
     const int ntiles = (w + dpp_own(px) - 1) / dpp_own(px);
@@ -1009,10 +1020,22 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
 #define LAUNCH_TILE_G_LR(RIGV, DV, RMV) do { if (lr) LAUNCH_TILE_G(true, RIGV, DV, RMV); else LAUNCH_TILE_G(false, RIGV, DV, RMV); } while (0)
     if (general) {
 #define LAUNCH_TILE_G_D(DV) do { if (!k.use_rig) LAUNCH_TILE_G_LR(false, DV, false); else if (!rigm) LAUNCH_TILE_G_LR(true, DV, false); else LAUNCH_TILE_G_LR(true, DV, true); } while (0)
-        if (k.delta == 1) LAUNCH_TILE_G_LR(true, 1, true);
-        else if (k.delta == 2) LAUNCH_TILE_G_D(2);
-        else if (k.delta == 3) LAUNCH_TILE_G_D(3);
-        else LAUNCH_TILE_G_D(4);
+        // delta_x 5 .. 10 (round 6): the rigidity form only -- without rigidity the host's table is all zeros, and x + 0.0f is x for every
+        // candidate (no cumulative minimum is -0.0f: energies are sums of non-negative gradients and finite biases)
+#define LAUNCH_TILE_G_W(DV) do { if (rigm) LAUNCH_TILE_G_LR(true, DV, true); else LAUNCH_TILE_G_LR(true, DV, false); } while (0)
+        switch (k.delta) {
+        case 1: LAUNCH_TILE_G_LR(true, 1, true); break;
+        case 2: LAUNCH_TILE_G_D(2); break;
+        case 3: LAUNCH_TILE_G_D(3); break;
+        case 4: LAUNCH_TILE_G_D(4); break;
+        case 5: LAUNCH_TILE_G_W(5); break;
+        case 6: LAUNCH_TILE_G_W(6); break;
+        case 7: LAUNCH_TILE_G_W(7); break;
+        case 8: LAUNCH_TILE_G_W(8); break;
+        case 9: LAUNCH_TILE_G_W(9); break;
+        default: LAUNCH_TILE_G_W(10); break;
+        }
+#undef LAUNCH_TILE_G_W
 #undef LAUNCH_TILE_G_D
     }
     else if (px == 2) LAUNCH_TILE_PX(2); else LAUNCH_TILE_PX(4);
@@ -1035,11 +1058,11 @@ static int launch_dp(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
         for (auto *c : b->cs) rigm |= (c->rig != nullptr);
         rigm = rigm && k.use_rig;
         if (k.delta == 1 && !rigm) return dp_persistent_ok(b, w) ? launch_dp_persistent<false>(b, k, w, h, lr) : launch_dp_tiled(b, k, w, h, lr);
-        if (k.delta >= 1 && k.delta <= 4 && dp_persistent_px(b, w, true, k.delta)) return launch_dp_persistent<false>(b, k, w, h, lr);
+        if (k.delta >= 1 && k.delta <= LQR_FAST_MAX_DELTA && dp_persistent_px(b, w, true, k.delta)) return launch_dp_persistent<false>(b, k, w, h, lr);
         // round 5: a general batch too large for one persistent grid (it runs its incremental updates on k_band_levels): the full DP
         // group after group of as many images as fit, instead of one 1024-thread workgroup per image (k_dp_sweep: 4 - 8 ms per sweep
         // of 16 x 4K against 2 x 0.5)
-        if (k.delta >= 1 && k.delta <= 4 && !b->shared) {
+        if (k.delta >= 1 && k.delta <= LQR_FAST_MAX_DELTA && !b->shared) {
             const int total = (int) b->cs.size();
             int per = total;
             while (per > 1 && !dp_persistent_px(b, w, true, k.delta, per)) per = (per + 1) / 2;
@@ -1107,7 +1130,7 @@ static int frozen_catchup(LqrHipBatch *b, int to, int w_at_to, int h)
 extern "C" void lqrhip_set_band_levels(int slots) { g_band_levels = slots; }
 static int band_levels_P(const LqrHipBatch *b, int w, int h, int delta)
 {
-    if (no_spin(b) || g_band_levels == 0 || delta < 1 || delta > 4 || (h + lv_rows(delta, true) - 1) / lv_rows(delta, true) > LV_MAX_LEVELS || (w + 63) / 64 > LV_MAX_TILES) return 0;
+    if (no_spin(b) || g_band_levels == 0 || delta < 1 || delta > LQR_FAST_MAX_DELTA || (h + lv_rows(delta, true) - 1) / lv_rows(delta, true) > LV_MAX_LEVELS || (w + 63) / 64 > LV_MAX_TILES) return 0;
     const int limit = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_levels) : g_dpp_max_wgs_levels;
     const int per_batch = limit / std::max(b->shared_n, 1);
     int P = std::min(LV_PMAX, per_batch / (int) std::max<size_t>(b->cs.size(), 1));
@@ -1142,7 +1165,20 @@ static int launch_band_levels(LqrHipBatch *b, const DpK &k, int w, int h, int lr
 #define LAUNCH_LV(LRV, RIGV, DV, RMV) hipLaunchKernelGGL((k_band_levels<LRV, RIGV, DV, RMV>), grid, dim3(128), 0, b->stream, b->d_desc, k, w, h, c0->stride, b->exch, epoch, g_dev_err, P, (int) n)
 #define LAUNCH_LV_LR(RIGV, DV, RMV) do { if (lr) LAUNCH_LV(true, RIGV, DV, RMV); else LAUNCH_LV(false, RIGV, DV, RMV); } while (0)
 #define LAUNCH_LV_D(DV) do { if (!k.use_rig) LAUNCH_LV_LR(false, DV, false); else if (!rigm) LAUNCH_LV_LR(true, DV, false); else LAUNCH_LV_LR(true, DV, true); } while (0)
-    if (k.delta == 1) LAUNCH_LV_D(1); else if (k.delta == 2) LAUNCH_LV_D(2); else if (k.delta == 3) LAUNCH_LV_D(3); else LAUNCH_LV_D(4);
+#define LAUNCH_LV_W(DV) do { if (rigm) LAUNCH_LV_LR(true, DV, true); else LAUNCH_LV_LR(true, DV, false); } while (0)      // delta_x 5 .. 10: the rigidity form (zero table without rigidity)
+    switch (k.delta) {
+    case 1: LAUNCH_LV_D(1); break;
+    case 2: LAUNCH_LV_D(2); break;
+    case 3: LAUNCH_LV_D(3); break;
+    case 4: LAUNCH_LV_D(4); break;
+    case 5: LAUNCH_LV_W(5); break;
+    case 6: LAUNCH_LV_W(6); break;
+    case 7: LAUNCH_LV_W(7); break;
+    case 8: LAUNCH_LV_W(8); break;
+    case 9: LAUNCH_LV_W(9); break;
+    default: LAUNCH_LV_W(10); break;
+    }
+#undef LAUNCH_LV_W
 #undef LAUNCH_LV_D
 #undef LAUNCH_LV_LR
 #undef LAUNCH_LV
@@ -1210,12 +1246,14 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     const int moved_unit = 2 * (4 + (move_dp ? 5 : 0) + (has_rigmask ? 4 : 0));
     // Backtrack: for single images the two-kernel parallel form (k_vp_maps / k_vp_solve, k_backtrack.hip: the chip walks every column
     // through every chunk of rows, the serial part is one step per chunk); for groups the one-wave-per-image walk, whose launches
-    // keep the chip busy anyway.  Measured on one box, us per seam with every kernel event-timed, k_vpath1 / parallel: 4K 70 / 44 (single4k
-    // 20.9 -> 22.7 k Mseams*px/s), 8K 108 / 79 (config 5 55.5 -> 59.1 k), FHD 32 / 30, 2 x 4K 57 / 44 (51.0 -> 53.4 k), 4 x 4K 59 / 61,
+    // keep the chip busy anyway.  Measured on one box, us per seam with every kernel event-timed, k_vpath1 / parallel: 4K 70 / 41 (single4k
+    // 20.9 -> 22.7 k Mseams*px/s), 8K 108 / 64 (config 5 55.5 -> 60.8 k), FHD 32 / 30, 2 x 4K 57 / 44 (51.0 -> 53.4 k), 4 x 4K 59 / 61,
     // 8 x 4K 60 / 79: each launch is ~10 us of dependent-dispatch latency, and the maps of n images are n times the work.
     const size_t vp_group = (size_t) n * (size_t) std::max(b->shared_n, 1);
-    const bool use_vp = p->delta_x >= 1 && p->delta_x <= 4 && h >= 2 &&
-                        (g_vpath_mode == 1 || (g_vpath_mode < 0 && vp_group <= (size_t) g_vpath_par_max && h >= g_vpath_min_rows));
+    // delta_x 5 .. 10: always -- the one-wave walks there take 0.2 (k_vpath1<5>) to 1.15 ms (k_vpath, delta_x 10) per 4K seam, the parallel
+    // form ~0.06 whatever delta_x is (a chunk is 56 / delta_x rows, the cone of a stage as wide as at delta_x 1)
+    const bool use_vp = p->delta_x >= 1 && p->delta_x <= LQR_FAST_MAX_DELTA && h >= 2 && g_vpath_mode != 0 &&
+                        (g_vpath_mode == 1 || p->delta_x >= 5 || (vp_group <= (size_t) g_vpath_par_max && h >= g_vpath_min_rows));
     if (use_vp) {
         const int R = vp_chunk_rows(p->delta_x), nchunks = (h - 1 + R - 1) / R, R4 = (R + 3) / 4;
         const size_t need = (size_t) (nchunks + 1) * stride + 64;
@@ -1232,7 +1270,10 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
 #define LAUNCH_VP(DV) do { \
         hipLaunchKernelGGL(k_vp_maps<DV>, dim3((w + 255) / 256, nchunks, n), dim3(256), 0, b->stream, b->d_desc, w, h, stride); \
         hipLaunchKernelGGL(k_vp_solve<DV>, dim3(n), dim3(VPATH_THREADS), (size_t) (nchunks + 2) * sizeof(int), b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit); } while (0)
-        if (p->delta_x == 1) LAUNCH_VP(1); else if (p->delta_x == 2) LAUNCH_VP(2); else if (p->delta_x == 3) LAUNCH_VP(3); else LAUNCH_VP(4);
+        switch (p->delta_x) {
+        case 1: LAUNCH_VP(1); break; case 2: LAUNCH_VP(2); break; case 3: LAUNCH_VP(3); break; case 4: LAUNCH_VP(4); break; case 5: LAUNCH_VP(5); break;
+        case 6: LAUNCH_VP(6); break; case 7: LAUNCH_VP(7); break; case 8: LAUNCH_VP(8); break; case 9: LAUNCH_VP(9); break; default: LAUNCH_VP(10); break;
+        }
 #undef LAUNCH_VP
     } else {
         ProfScope ps("vpath", b->stream, 0);
@@ -1244,6 +1285,12 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
             hipLaunchKernelGGL(k_vpath1<3>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit);
         else if (p->delta_x == 4)
             hipLaunchKernelGGL(k_vpath1<4>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit);
+        else if (p->delta_x == 5)
+            hipLaunchKernelGGL(k_vpath1<5>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit);
+        else if (p->delta_x == 6)
+            hipLaunchKernelGGL(k_vpath1<6>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit);
+        else if (p->delta_x == 7)
+            hipLaunchKernelGGL(k_vpath1<7>, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, log_index, moved_unit);
         else
             hipLaunchKernelGGL(k_vpath, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, p->delta_x,
                                log_index, moved_unit);
@@ -1288,7 +1335,7 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     const bool fast_ok = p->delta_x == 1 && !rigm && g_update_mode != 3;
     const bool tiled_update = fast_ok ? ((g_update_mode < 0 ? (size_t) n * (size_t) w * (size_t) h <= (size_t) g_tiled_update_px : g_update_mode == 1) &&
                                          dp_persistent_ok(b, w))
-                                      : (p->delta_x >= 1 && p->delta_x <= 4 && g_update_mode != 0 && g_update_mode != 2 && g_update_mode != 3 && dp_persistent_px(b, w, true, p->delta_x) != 0);
+                                      : (p->delta_x >= 1 && p->delta_x <= LQR_FAST_MAX_DELTA && g_update_mode != 0 && g_update_mode != 2 && g_update_mode != 3 && dp_persistent_px(b, w, true, p->delta_x) != 0);
     {
         // round 5: the band on P slots per image, tiles assigned level by level (k_band_levels): the default for groups of 8 to 64
         // images (measured, Mseams*px/s at 4K, levels / k_band_update_tw: 8 images 148 / 127, 16: 256 / 180, 48: 479 / 404).  64 images
@@ -1299,7 +1346,7 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
         // round 5: also delta_x 2 .. 4 and rigidity masks (k_band_levels' general instantiations): a batch of such carvers used to be
         // carved in groups of as many as the full-width tiled kernels hold (16 x 4K, delta_x 2: 68 k Mseams*px/s)
         const size_t group_images = (size_t) n * (size_t) std::max(b->shared_n, 1);
-        const bool lv_ok = p->delta_x >= 1 && p->delta_x <= 4 && g_update_mode != 3;
+        const bool lv_ok = p->delta_x >= 1 && (p->delta_x <= 4 || g_update_mode == 5) && p->delta_x <= LQR_FAST_MAX_DELTA && g_update_mode != 3;        // (delta_x 5 .. 10: on request only, see lqrhip_general_batch_limit_delta)
         const int PL = (lv_ok && (g_update_mode == 5 || (g_update_mode < 0 && group_images >= 8 && (group_images <= 64 || !fast_ok)))) ? band_levels_P(b, wnew, h, p->delta_x) : 0;
         if (PL > 0) {
             {

@@ -301,11 +301,11 @@ static void set_width_tree(LqrCarver *r, int w1)
     for (l = r->attached; l; l = l->next) set_width_tree(l->current, w1);
 }
 
-/* delta_x = 2 .. 4, or a rigidity mask that matters: the carver runs on the tiled kernels' general instantiations, which need
- * the whole group co-resident on ONE stream */
+/* delta_x = 2 .. 10 (the whole range of the plug-in's dialog, src/interface.c:47), or a rigidity mask that matters: the carver runs
+ * on the tiled kernels' general instantiations, which need the whole group co-resident on ONE stream */
 static int is_general(const LqrCarver *c)
 {
-    return (c->delta_x >= 2 && c->delta_x <= 4) || (c->delta_x == 1 && c->has_rigmask && c->rigidity != 0);
+    return (c->delta_x >= 2 && c->delta_x <= 10) || (c->delta_x == 1 && c->has_rigmask && c->rigidity != 0);
 }
 
 static LqrRetVal group_open(Group *g, LqrCarver **rs, int n)
@@ -745,7 +745,7 @@ LqrRetVal lqrx_carver_resize_batch(LqrCarver **carvers, gint n, gint w1, gint h1
             int wmax = c->w_start > c->h_start ? c->w_start : c->h_start, lim;   /* either direction may be carved, shrinking or enlarging */
             if (w1 > wmax) wmax = w1;
             if (h1 > wmax) wmax = h1;
-            lim = lqrhip_general_batch_limit(wmax);
+            lim = lqrhip_general_batch_limit_delta(wmax, c->delta_x);
             if (lim >= 1 && n > lim) {
                 /* every sub-group is carved whatever the others returned (the images are independent); the first error is reported */
                 LqrRetVal first = LQR_OK;

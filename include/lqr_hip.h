@@ -91,6 +91,8 @@ int lqrhip_sub_batches(int n);
 /* Images of carved-frame width w that one lock-step batch may hold and still run delta_x = 2 / rigidity-mask carvers on the
  * tiled kernels (0: unknown); larger batches of such carvers are carved group after group (lqrx_carver_resize_batch). */
 int lqrhip_general_batch_limit(int w);
+/* the same for a given delta_x: 2 .. 4 may also run on k_band_levels (groups of 8 and more), 5 .. 10 on the full-width tiled kernels only */
+int lqrhip_general_batch_limit_delta(int w, int delta_x);
 void lqrhip_set_sub_batches(int n);
 LqrHipBatch *lqrhip_batch_create(LqrHipCarver **carvers, int n);
 /* tell a batch how many batches of its group run concurrently on their own streams (0 or 1: alone): kernels whose grid

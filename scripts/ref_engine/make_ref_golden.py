@@ -5,7 +5,7 @@ Evaluation mode of the x87 code: "sse" (control word 0x27f, the float-only DP fu
 x86-64 / SSE2 build of the same source performs it -- the platform this repository's "bit-exact" refers to.  For every
 vector the manifest also records whether the build AS SHIPPED (control word 0x37f) produces the same result.
 
-    python scripts/ref_engine/make_ref_golden.py [group ...]     groups: fixtures fuzz extras interactive planes configs config4 config5half
+    python scripts/ref_engine/make_ref_golden.py [group ...]     groups: fixtures fuzz extras interactive planes configs config4 config5half deltawide
 """
 import hashlib, json, os, sys, time
 from concurrent.futures import ProcessPoolExecutor
@@ -202,6 +202,8 @@ def main():
                                                                          "config5_quarter_delta2", "config5_quarter_rigmask")]
     if "config5half" in groups:      # round 6: config 5 at half scale and its two variants (each ~4 GB-seconds of the genuine engine)
         tasks += [("config5half", n, dict(kind="config", name=n)) for n in ("config5_half", "config5_half_delta2", "config5_half_rigmask")]
+    if "deltawide" in groups:        # round 6: delta_x 5 .. 10
+        tasks += [("deltawide", "dw_%d_%s" % (d, v), dict(kind="config", name="dw_%d_%s" % (d, v))) for d in (5, 6, 7, 8, 9, 10) for v in ("plain", "rig")]
     if "config4" in groups:
         tasks += [("config4", "image%02d" % i, dict(kind="config", name="config4_%d" % i)) for i in range(64)]
     new = []

@@ -30,8 +30,11 @@ BUDGETS = [
     (r"^k_dp_tile_p<2, (true|false), (true|false), true, 1, false>$", 232, 0, 0, "E9 full width, 32-row block staged in registers: 2 waves per SIMD"),
     (r"^k_dp_tile_p<4, (true|false), (true|false), true, 1, false>$", 216, 0, 0, "E9 full width, 4 px per lane: 2 waves per SIMD"),
     (r"^k_dp_tile_p<2, .*, [1234], (true|false)>$", 272, 0, 0, "general instantiations (delta_x 2..4, rigidity mask): at least one workgroup per SIMD pair, no scratch"),
+    (r"^k_dp_tile_p<2, (true|false), true, (true|false), ([5-9]|10), (true|false)>$", 256, 0, 0, "delta_x 5 .. 10 (round 6): 3 .. 6 staged rows, 11 .. 21 candidates per pixel; two workgroups per SIMD pair, no scratch"),
+    (r"^k_vp_maps<", 32, 0, 0, "the map kernel is LDS-latency-bound: many workgroups per CU (21 KB of LDS each)"),
+    (r"^k_vp_solve<", 96, 0, 0, "one workgroup per image"),
     (r"^k_vpath1<1>$", 192, 0, 0, "one wave chases, 2 waves per SIMD of the 4-wave workgroup"),
-    (r"^k_vpath1<[234]>$", 128, 0, 0, "shorter chunks"),
+    (r"^k_vpath1<[234567]>$", 128, 0, 0, "shorter chunks"),
     (r"^k_emap_update<\d, 12>$", 64, 0, 0, "delta_x <= 2: 8 waves per SIMD"),
     (r"^k_dp_tile<", 96, 0, 0, "one wave per tile, 5 per SIMD"),
 ]

@@ -113,12 +113,13 @@ def check(api, entry):
 SMALL = vectors("fixtures", "fuzz", "extras")
 CONFIGS = vectors("configs")
 CONFIG4 = vectors("config4")
+DELTA_WIDE = vectors("deltawide")           # round 6: delta_x 5 .. 10, plain and with rigidity + a rigidity mask + a preservation mask
 CONFIG5_HALF = vectors("config5half")       # round 6: config 5 at HALF scale (3840 x 2160, 500 seams, masks, rigidity 10) and its delta_x 2 / rigidity-mask variants
 
 
 def test_manifest_is_complete():
     assert len(vectors("fixtures")) == 17 and len(vectors("fuzz")) == 60 and len(vectors("extras")) == 40
-    assert len(CONFIG4) == 64 and len(CONFIGS) >= 5 and len(vectors("interactive")) == 40 and len(CONFIG5_HALF) == 3
+    assert len(CONFIG4) == 64 and len(CONFIGS) >= 5 and len(vectors("interactive")) == 40 and len(CONFIG5_HALF) == 3 and len(DELTA_WIDE) == 12
     assert len(MANIFEST["exe_sha256"]) == 64
     for v in MANIFEST["vectors"]:
         assert os.path.exists(os.path.join(REF, v["file"])), v["file"]
@@ -137,6 +138,11 @@ def test_oracle_reproduces_the_genuine_engine(oracle, entry):
 def test_oracle_reproduces_the_genuine_engine_on_baseline_configs(oracle, entry):
     """BASELINE.json's configs 1 and 2 at full size, 3 at full size (both directions, both seam maps), 5 and its variants at
     quarter scale"""
+    check(oracle, entry)
+
+
+@pytest.mark.parametrize("entry", DELTA_WIDE, ids=ids(DELTA_WIDE))
+def test_oracle_reproduces_the_genuine_engine_with_wide_delta(oracle, entry):
     check(oracle, entry)
 
 
@@ -229,6 +235,13 @@ def test_engine_reproduces_the_genuine_engine(engine, entry):
 @pytest.mark.gpu
 @pytest.mark.parametrize("entry", CONFIGS, ids=ids(CONFIGS))
 def test_engine_reproduces_the_genuine_engine_on_baseline_configs(engine, entry):
+    check(engine, entry)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry", DELTA_WIDE, ids=ids(DELTA_WIDE))
+def test_engine_reproduces_the_genuine_engine_with_wide_delta(engine, entry):
+    """delta_x 5 .. 10 on k_dp_tile_p's general instantiations (round 6) against what the genuine liblqr produced"""
     check(engine, entry)
 
 

@@ -26,7 +26,7 @@ SHAPES = [(40, 2), (40, 3), (300, 56), (300, 57), (300, 58), (255, 113), (256, 1
 
 
 @pytest.mark.parametrize("w,h", SHAPES)
-@pytest.mark.parametrize("delta", [1, 2, 3, 4])
+@pytest.mark.parametrize("delta", [1, 2, 3, 4, 7, 10])
 def test_parallel_backtrack_chunk_tile_and_stage_boundaries(oracle, engine, lib, w, h, delta):
     img = D.photo_like(w, h, 600 + w + h) if (w + h) % 2 else D.noise(w, h, 600 + w + h)
     nw, nh = max(2, w - min(12, w // 3)), max(2, h - min(9, h // 4))
@@ -67,3 +67,92 @@ def test_parallel_backtrack_config3_size_both_directions(oracle, engine, lib):
     ref = H.run_case(oracle, img, 3780, 2120)
     lib.lqrhip_set_vpath_mode(1, 0)
     H.assert_same(ref, H.run_case(engine, img, 3780, 2120), "4K both directions, parallel backtrack")
+
+
+# ---------------------------------------------------------------- delta_x 5 .. 10 on the tiled kernels
+def prof_launches(lb, name):
+    ms, n, by = ctypes.c_double(0), ctypes.c_longlong(0), ctypes.c_double(0)
+    lb.lqrhip_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by))
+    return n.value
+
+
+WIDE_VARIANTS = {
+    "plain": {},
+    "rigidity": dict(rigidity=5.0),
+    "rigmask": dict(rigidity=3.0, rigmask=True),
+    "masks": dict(pres=True, disc=True),
+}
+
+
+@pytest.mark.parametrize("delta", [5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", sorted(WIDE_VARIANTS))
+@pytest.mark.parametrize("path", ["auto", "levels", "generic"])
+def test_wide_delta_dp_planes_and_seams(oracle, engine, lib, delta, variant, path):
+    """delta_x 5 .. 10 -- the upper half of the plug-in's dialog range (src/interface.c:47) -- ran on the one-wave kernels until round 6
+    (~30x slower).  Now: k_dp_tile_p's / k_band_levels' general instantiations with blocks of 32 / delta_x rows, the reach of a row
+    fetched from up to five lanes away.  After 30 incremental updates the DP planes (energies, cumulative minima, back pointers) are
+    bit-identical to the oracle's; whole resizes in both directions; the generic kernels (update mode 3) as the third opinion."""
+    lb = lib
+    lb.lqrhip_set_update_mode.argtypes = [ctypes.c_int]; lb.lqrhip_set_band_levels.argtypes = [ctypes.c_int]
+    w, h = 460, 190
+    img = D.photo_like(w, h, 40 + delta) if delta % 2 else D.noise(w, h, 40 + delta)
+    v = dict(WIDE_VARIANTS[variant])
+    kw = dict(delta_x=delta, switch_freq=0)
+    if v.pop("rigmask", False):
+        kw["rigmask"] = D.top_half_mask(w, h)
+    if v.pop("pres", False):
+        kw["pres"] = D.ellipse_mask(w, h)
+    if v.pop("disc", False):
+        kw["disc"] = D.band_mask(w, h, 90, 150)
+    kw.update(v)
+    lb.lqrhip_set_update_mode({"auto": -1, "levels": 5, "generic": 3}[path])
+    if path == "levels":
+        lb.lqrhip_set_band_levels(5)
+    try:
+        oracle.lqrx_set_debug(1); engine.lqrx_set_debug(1)
+        ca, _ = H.init_carver(oracle, img, w - 30, h, **kw); cb, _ = H.init_carver(engine, img, w - 30, h, **kw)
+        lb.lqrhip_prof_reset(); lb.lqrhip_prof_enable(1)
+        assert ca.resize(w - 30, h) == L.LQR_OK and cb.resize(w - 30, h) == L.LQR_OK
+        lb.lqrhip_prof_enable(0)
+        if path == "auto":
+            assert prof_launches(lb, "dp_update_tiled") > 0 and prof_launches(lb, "band_update") == 0, "delta_x %d fell to the one-wave kernels" % delta
+        if path == "levels":
+            assert prof_launches(lb, "band_levels") > 0
+        (ea, ma, da), (eb, mb, db) = ca.debug_snapshot(), cb.debug_snapshot()
+        assert np.array_equal(ea.view(np.int32), eb.view(np.int32)), "energies"
+        assert np.array_equal(ma.view(np.int32), mb.view(np.int32)), "cumulative minima"
+        assert np.array_equal(da[1:], db[1:]), "back pointers"
+        assert np.array_equal(ca.vmap_dump()["data"], cb.vmap_dump()["data"]) and np.array_equal(ca.read_image(), cb.read_image())
+        ca.destroy(); cb.destroy()
+    finally:
+        oracle.lqrx_set_debug(0); engine.lqrx_set_debug(0)
+        lb.lqrhip_prof_enable(0); lb.lqrhip_set_update_mode(-1); lb.lqrhip_set_band_levels(-1)
+    kw.pop("switch_freq")
+    H.assert_same(H.run_case(oracle, img, w - 25, h - 17, **kw), H.run_case(engine, img, w - 25, h - 17, **kw), "delta %d %s both directions" % (delta, variant))
+
+
+@pytest.mark.parametrize("delta", [5, 8, 10])
+def test_wide_delta_group_of_nine_runs_the_full_width_tiled_kernels(oracle, engine, lib, delta):
+    """a lock-step group with delta_x 5 .. 10 stays on k_dp_tile_p's general instantiations (the band is the whole width after a few hundred
+    rows: the level kernel's images would stop at a collision and fall to the one-workgroup sweep), carved group after group if it is
+    larger than the persistent grid holds; the backtrack is the parallel one whatever the group size"""
+    w, h, n = 640, 300, 9
+    imgs = [D.photo_like(w, h, 900 + i) if i % 2 else D.noise(w, h, 900 + i) for i in range(n)]
+    rig = 2.0 if delta == 8 else 0.0
+    cs = [L.Carver(engine, im, delta_x=delta, rigidity=rig).configure() for im in imgs]
+    lib.lqrhip_prof_reset(); lib.lqrhip_prof_enable(1)
+    assert L.resize_batch(engine, cs, w - 40, h - 12) == L.LQR_OK
+    lib.lqrhip_prof_enable(0)
+    assert prof_launches(lib, "dp_update_tiled") > 0 and prof_launches(lib, "band_update") == 0 and prof_launches(lib, "band_levels") == 0
+    for c, im in zip(cs, imgs):
+        ref = H.run_case(oracle, im, w - 40, h - 12, delta_x=delta, rigidity=rig)
+        assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"]) and np.array_equal(c.read_image(), ref["image"])
+    for c in cs:
+        c.destroy()
+
+
+def test_wide_delta_4k_rows_and_8k_columns(oracle, engine, lib):
+    """tall and wide: 2300 rows at delta_x 10 = 767 blocks of 3 rows (the granule tags' block field), 6000 columns = 94 tiles"""
+    for w, h, d in ((300, 2300, 10), (6000, 120, 7)):
+        img = D.photo_like(w, h, 77)
+        H.assert_same(H.run_case(oracle, img, w - 12, h, delta_x=d), H.run_case(engine, img, w - 12, h, delta_x=d), "%dx%d delta %d" % (w, h, d))
