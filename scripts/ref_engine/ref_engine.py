@@ -127,7 +127,8 @@ class Runner:
        float24: additionally run the FLOAT_ONLY functions under 0x07f (24-bit mantissa), i.e. float arithmetic as an SSE2
        build performs it ("sse" mode = cw 0x27f + float24)"""
 
-    def __init__(self, cw=0x37f, poison=None, float24=False):
+    def __init__(self, cw=0x37f, poison=None, float24=False, float24_only=None):
+        """float24_only: run only THESE functions of FLOAT_ONLY under the 24-bit word (per-function evidence, precision_evidence.py)"""
         self.pe = PE(exe_bytes())
         self.proc = subprocess.Popen([build_runner()], stdin=subprocess.PIPE, stdout=subprocess.PIPE, bufsize=0)
         pe = self.pe
@@ -146,9 +147,10 @@ class Runner:
             self.write(pe.imports[name], struct.pack("<I", addr))
         self.set_cw(cw)
         self.wrapped = {}
-        if float24:
+        if float24 or float24_only:
             for k, name in enumerate(FLOAT_ONLY):
-                self.wrap(k, name, 0x07f)
+                if float24_only is None or name in float24_only:
+                    self.wrap(k, name, 0x07f)
             for k, name in enumerate(DOUBLE_INSIDE):
                 self.wrap(len(FLOAT_ONLY) + k, name, cw)
         if poison is not None:
@@ -294,8 +296,8 @@ class RefApi:
     """stands where binding.Api stands in tests/harness.py (api.carver_class picks RefCarver)"""
     has_ext = False
 
-    def __init__(self, cw=0x37f, poison=None, float24=False):
-        self.r = Runner(cw, poison, float24)
+    def __init__(self, cw=0x37f, poison=None, float24=False, float24_only=None):
+        self.r = Runner(cw, poison, float24, float24_only)
         self.carver_class = RefCarver
         self.cw = cw
 
