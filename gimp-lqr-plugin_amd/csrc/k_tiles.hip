@@ -133,7 +133,7 @@ __device__ int g_dpp_dbg;          // experiment switches (lqrhip_dp_tile_debug)
 #else
 #define JIT(site) do { } while (0)
 #endif
-template <int PX, bool LR, bool RIG, bool UPDATE, int DELTA, bool RIGM>
+template <int PX, bool LR, bool RIG, bool UPDATE, int DELTA, bool RIGM, int HLN>
 __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err)
 {
     static_assert(DELTA >= 1 && DELTA <= LQR_FAST_MAX_DELTA && (DELTA <= 4 || (PX == 2 && RIG)) && (RIG || !RIGM), "delta_x 1 .. 10 (5 .. 10: the rigidity form, with a zero table if there is none); a rigidity mask only matters with rigidity");
@@ -141,7 +141,9 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
     typedef typename LaneVec<PX>::L LV;
     typedef GLOBAL_AS FV GFV;
     typedef GLOBAL_AS LV GLV;
-    constexpr int HALO = dpp_halo(PX), OWN = dpp_own(PX), EX_TILE = dpp_ex_tile(PX), TILE = 64 * PX, HL = 16;      // HL: halo lanes per side
+    static_assert(HLN == 16 || (HLN == 24 && PX == 2 && DELTA == 1 && !RIGM), "24 halo lanes per side: the plain 2-px instantiations only");
+    constexpr int PXC = HLN == 24 ? 3 : PX;         // the geometry code of lqr_common.h
+    constexpr int HALO = dpp_halo(PXC), OWN = dpp_own(PXC), EX_TILE = dpp_ex_tile(PXC), TILE = 64 * PX, HL = HLN;      // HL: halo lanes per side
     __shared__ FV s_mp[64];                      // the row above the next batch, handed from wave to wave
     __shared__ int s_fail;                       // a neighbour never showed up: both waves leave at the next barrier
     __shared__ int s_polled;                     // last block whose halo wave 0 has received (LDS_FLAG: lqr_common.h)
@@ -190,10 +192,10 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
     // block, as the delta_x = 2 instantiations do with their 16-row blocks): half the hand-overs, barriers and loop
     // iterations of 16-row batches for 80 more staging registers (193 VGPRs, no spill; the residency bound is queried per
     // instantiation).  Measured on one box: 4K 20.0 -> 21.85 k, FHD 12.3 -> 13.1 k, config 5 50.9 -> 55.9 k.
-    constexpr int R = (PX == 2 && DELTA == 1 && (!RIGM || DPP_RIGM32)) ? DPP_R2 : DELTA >= 5 ? dpp_rb(PX, DELTA) : DELTA >= 3 ? 8 : DPP_R;      // delta_x 3, 4: 8-row blocks (errors move up to 4 columns per row); 5 .. 10: 6 .. 3 rows
+    constexpr int R = HLN == 24 ? 24 : (PX == 2 && DELTA == 1 && (!RIGM || DPP_RIGM32)) ? DPP_R2 : DELTA >= 5 ? dpp_rb(PX, DELTA) : DELTA >= 3 ? 8 : DPP_R;      // delta_x 3, 4: 8-row blocks (errors move up to 4 columns per row); 5 .. 10: 6 .. 3 rows
     FV q_e[R], q_mo[R], q_rf[RIGM ? R : 1];
     LV q_lo[R];
-    constexpr int RB = dpp_rb(PX, DELTA), NBB = RB / R;          // rows, batches per block
+    constexpr int RB = dpp_rb(PXC, DELTA), NBB = RB / R;         // rows, batches per block (24 halo lanes: 48-row blocks in two 24-row batches, the waves alternating)
     static_assert(RB * DELTA <= HALO && RB % R == 0, "a block's errors stay inside the halo");
     float rg[2 * DELTA + 1];
 #pragma unroll
@@ -350,15 +352,27 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
 #pragma unroll
                     for (int k = 0; k < PX; k++) any_in |= in[k];
                     const bool need = !own_lane && any_in;
-                    const int nb = (lane < 32) ? tile - 1 : tile + 1;                     // left halo <- left neighbour's right-going granules
-                    const int col = !need ? 0 : (lane < 32) ? PX * lane : PX * (lane - 64 + HL);        // lanes that need nothing poll a dummy
-                    gu64 *src = ex_img + (size_t) (need ? nb : tile) * EX_TILE + (size_t) (((j - 1) & 1) * 2 + (lane < 32 ? 1 : 0)) * HALO + col;
+                    int nb, col;
+                    bool src_near;
+                    if constexpr (HLN == 16) {
+                        nb = (lane < 32) ? tile - 1 : tile + 1;                     // left halo <- left neighbour's right-going granules
+                        col = !need ? 0 : (lane < 32) ? PX * lane : PX * (lane - 64 + HL);        // lanes that need nothing poll a dummy
+                        col += (((j - 1) & 1) * 2 + (lane < 32 ? 1 : 0)) * HALO;
+                        src_near = lane < 32 ? near_l : near_r;
+                    } else {
+                        // 48-column halos over 32-column tiles: a halo reaches across the adjacent tile into the one behind it; every tile
+                        // publishes ALL its own columns once ([parity][column]), a halo lane reads the tile that owns its columns
+                        nb = need ? x0 / OWN : tile;                                 // (x0 >= 0 for a lane with a pixel inside the image)
+                        col = (need ? x0 - nb * OWN : 0) + ((j - 1) & 1) * OWN;
+                        src_near = !(dbg & 3) && nb >= tile - cls_k && nb < tile - cls_k + cls_n;          // the owner sits on this XCD
+                    }
+                    gu64 *src = ex_img + (size_t) (need ? nb : tile) * EX_TILE + col;
                     const unsigned want = ((unsigned) epoch << DPP_BLK_BITS) | (unsigned) j;
                     unsigned long long g[PX];
                     int spins = 0;
                     bool failed = false;
                     JIT(1);
-                    const bool lane_near = need && (lane < 32 ? near_l : near_r);
+                    const bool lane_near = need && src_near;
                     while (true) {
                         gu64 *s2 = src + ((lane_near && (spins & 3) != 3) ? near_off : 0);
 #pragma unroll
@@ -414,13 +428,22 @@ __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, 
                     // neighbours' halo; lanes 16..31 write the left-going granules, lanes 32..47 the right-going ones
                     JIT(3);
                     if (own_lane) {
-                        const int side = lane < 32 ? 0 : 1;
-                        gu64 *dst = ex_img + (size_t) tile * EX_TILE + (size_t) ((j & 1) * 2 + side) * HALO + PX * (lane - (side ? 32 : HL));
                         const unsigned long long tag = (unsigned long long) (((unsigned) epoch << DPP_BLK_BITS) | (unsigned) (j + 1)) << 32;
+                        if constexpr (HLN == 16) {
+                            const int side = lane < 32 ? 0 : 1;
+                            gu64 *dst = ex_img + (size_t) tile * EX_TILE + (size_t) ((j & 1) * 2 + side) * HALO + PX * (lane - (side ? 32 : HL));
 #pragma unroll
-                        for (int k = 0; k < PX; k++) {
-                            if (side ? near_r : near_l) __hip_atomic_store(dst + near_off + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_store(dst + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            for (int k = 0; k < PX; k++) {
+                                if (side ? near_r : near_l) __hip_atomic_store(dst + near_off + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_store(dst + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        } else {
+                            gu64 *dst = ex_img + (size_t) tile * EX_TILE + (size_t) (j & 1) * OWN + PX * (lane - HL);
+#pragma unroll
+                            for (int k = 0; k < PX; k++) {
+                                if (!(dbg & 3) && cls_n > 1) __hip_atomic_store(dst + near_off + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_store(dst + k, tag | __float_as_uint(mp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                         }
                     }
                 }
@@ -476,6 +499,7 @@ extern "C" int lqrhip_tile_timing(unsigned long long *out) { (void) hipDeviceSyn
 #define INST_TILE(LRV, RIGV) template __global__ void k_dp_tile<LRV, RIGV>(const DevCarver *, DpK, int, int, int, int);
 INST_TILE(false, false) INST_TILE(false, true) INST_TILE(true, false) INST_TILE(true, true)
 #define INST_P(...) template __global__ void k_dp_tile_p<__VA_ARGS__>(DevCarver *, DpK, int, int, int, unsigned long long *, int, int *);
+#define INST_P_WIDE(LRV, RIGV, UPD) INST_P(2, LRV, RIGV, UPD, 1, false, 24)
 #define INST_P_LR(LRV, UPD) INST_P(4, LRV, false, UPD) INST_P(4, LRV, true, UPD) INST_P(2, LRV, false, UPD) INST_P(2, LRV, true, UPD) \
     INST_P(2, LRV, true, UPD, 1, true) \
     INST_P(2, LRV, false, UPD, 2, false) INST_P(2, LRV, true, UPD, 2, false) INST_P(2, LRV, true, UPD, 2, true) \
@@ -485,3 +509,5 @@ INST_TILE(false, false) INST_TILE(false, true) INST_TILE(true, false) INST_TILE(
     INST_P(2, LRV, true, UPD, 7, false) INST_P(2, LRV, true, UPD, 7, true) INST_P(2, LRV, true, UPD, 8, false) INST_P(2, LRV, true, UPD, 8, true) \
     INST_P(2, LRV, true, UPD, 9, false) INST_P(2, LRV, true, UPD, 9, true) INST_P(2, LRV, true, UPD, 10, false) INST_P(2, LRV, true, UPD, 10, true)
 INST_P_LR(false, false) INST_P_LR(false, true) INST_P_LR(true, false) INST_P_LR(true, true)
+INST_P_WIDE(false, false, false) INST_P_WIDE(false, true, false) INST_P_WIDE(true, false, false) INST_P_WIDE(true, true, false)
+INST_P_WIDE(false, false, true) INST_P_WIDE(false, true, true) INST_P_WIDE(true, false, true) INST_P_WIDE(true, true, true)

@@ -508,9 +508,14 @@ template <> struct LaneVec<4> { typedef f32x4 F; typedef uint32_t L; };
 // ---- geometry of the persistent tiled kernels (k_tiles.hip), needed by their launchers too
 // PX pixels per lane (4, or 2 when the device has room for twice the tiles: half the instructions per wave and row):
 // a tile is 64 * PX columns of which the 16 outer lanes on each side are halo
-constexpr int dpp_halo(int px) { return 16 * px; }              // halo columns on each side = rows per block
-constexpr int dpp_own(int px) { return 64 * px - 2 * dpp_halo(px); }     // columns a tile owns
-constexpr int dpp_ex_tile(int px) { return 2 * 2 * dpp_halo(px); }       // granules a tile publishes: [block parity][side: 0 to the left, 1 to the right][column]
+// `px` below is a geometry code: 2 / 4 = pixels per lane with 16 halo lanes per side; 3 (round 6) = 2 pixels per lane with 24 halo lanes per
+// side -- 32 own columns + 48-column halos, blocks of 48 rows: the hand-over through memory (a third of a 32-row level) is paid 45
+// times per 4K sweep instead of 68, for twice the tiles; used while every tile still has a compute unit to itself (single images)
+constexpr int dppx_px(int px) { return px == 3 ? 2 : px; }
+constexpr int dppx_hl(int px) { return px == 3 ? 24 : 16; }
+constexpr int dpp_halo(int px) { return dppx_hl(px) * dppx_px(px); }              // halo columns on each side = rows per block
+constexpr int dpp_own(int px) { return 64 * dppx_px(px) - 2 * dpp_halo(px); }     // columns a tile owns
+constexpr int dpp_ex_tile(int px) { return px == 3 ? 2 * dpp_own(3) : 2 * 2 * dpp_halo(px); }       // granules a tile publishes: [block parity][side: 0 to the left, 1 to the right][column]; px 3: [block parity][own column]
 constexpr int dpp_rb(int px, int delta) { return delta >= 5 ? dpp_halo(2) / delta : delta >= 3 ? 8 : dpp_halo(px) / delta; }      // rows per block (delta_x 5 .. 10: 6, 5, 4, 4, 3, 3)
 constexpr int DPP_R = 16;                       // rows per batch
 constexpr int DPP_W = 2;                        // waves taking turns

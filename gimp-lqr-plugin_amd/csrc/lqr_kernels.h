@@ -32,7 +32,7 @@ template <int NW, bool LR, bool RIG> __global__ __launch_bounds__(128 * NW) void
 
 // k_tiles.hip
 template <bool LR, bool RIG> __global__ __launch_bounds__(64) void k_dp_tile(const DevCarver *cs, DpK p, int w, int h, int stride, int y0);
-template <int PX, bool LR, bool RIG, bool UPDATE, int DELTA = 1, bool RIGM = false>
+template <int PX, bool LR, bool RIG, bool UPDATE, int DELTA = 1, bool RIGM = false, int HLN = 16>
 __global__ __launch_bounds__(64 * DPP_W) void k_dp_tile_p(DevCarver *cs, DpK p, int w, int h, int stride, unsigned long long *exch, int epoch, int *dev_err);
 
 // k_levels.hip

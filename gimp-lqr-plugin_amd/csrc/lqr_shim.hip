@@ -28,6 +28,7 @@ static int g_dpp_max_wgs = 0;
 static int g_dpp_max_wgs_plain = 0, g_dpp_max_wgs_general = 0;      // ... of the plain / the delta_x = 2..4, rigidity-mask instantiations
 static int g_dpp_max_wgs_px4 = 0;                                   // ... of the plain 4-px instantiations alone (fewer registers than the 2-px ones)
 static int g_dpp_max_wgs_levels = 0;                                // ... of k_band_levels
+static int g_n_cu = 0;
 
 // ===========================================================================
 // host side of the shim
@@ -105,7 +106,11 @@ static int dpp_resident_workgroups(int dev)
     g_dpp_max_wgs_px4 = std::max(0, per_cu - 1) * prop.multiProcessorCount;
     q(k_dp_tile_p<2, false, false, false>); q(k_dp_tile_p<2, false, true, false>); q(k_dp_tile_p<2, true, false, false>); q(k_dp_tile_p<2, true, true, false>);
     q(k_dp_tile_p<2, false, false, true>); q(k_dp_tile_p<2, false, true, true>); q(k_dp_tile_p<2, true, false, true>); q(k_dp_tile_p<2, true, true, true>);
+    // (round 6: the 24-halo-lane geometry of the plain 2-px kernels, px code 3)
+    q(k_dp_tile_p<2, false, false, false, 1, false, 24>); q(k_dp_tile_p<2, false, true, false, 1, false, 24>); q(k_dp_tile_p<2, true, false, false, 1, false, 24>); q(k_dp_tile_p<2, true, true, false, 1, false, 24>);
+    q(k_dp_tile_p<2, false, false, true, 1, false, 24>); q(k_dp_tile_p<2, false, true, true, 1, false, 24>); q(k_dp_tile_p<2, true, false, true, 1, false, 24>); q(k_dp_tile_p<2, true, true, true, 1, false, 24>);
     g_dpp_max_wgs_plain = std::max(0, per_cu - 1) * prop.multiProcessorCount;
+    g_n_cu = prop.multiProcessorCount;
     // the delta_x = 2 / rigidity-mask instantiations (2 px per lane only) hold more registers
     per_cu = 1 << 20;
 #define QG(LRV, UPD) q(k_dp_tile_p<2, LRV, true, UPD, 1, true>); q(k_dp_tile_p<2, LRV, false, UPD, 2, false>); q(k_dp_tile_p<2, LRV, true, UPD, 2, false>); q(k_dp_tile_p<2, LRV, true, UPD, 2, true>); \
@@ -811,7 +816,7 @@ static int g_band_levels = -1;           // k_band_levels: -1 automatic; 0 never
 extern "C" void lqrhip_set_update_mode(int mode) { g_update_mode = mode; }
 static int g_dpp_limit_override = -1;
 static int g_dpp_px_override = 0;       // test hook: 2 or 4 pins the persistent sweep's pixels per lane (0 = by batch size)
-extern "C" void lqrhip_set_dp_persistent_px(int px) { g_dpp_px_override = (px == 2 || px == 4) ? px : 0; }
+extern "C" void lqrhip_set_dp_persistent_px(int px) { g_dpp_px_override = (px == 2 || px == 3 || px == 4) ? px : 0; }
 // -1: the occupancy-derived bound (dpp_resident_workgroups); >= 0: at most that many workgroups for the persistent
 // tiled sweep -- 0 sends every full DP to k_dp_tile and every incremental update to a band kernel
 extern "C" void lqrhip_set_dp_persistent_limit(int workgroups) { g_dpp_limit_override = workgroups; }
@@ -926,9 +931,13 @@ static int dp_persistent_px(const LqrHipBatch *b, int w, bool general = false, i
     const size_t n = count < 0 ? b->cs.size() : (size_t) count;
     const int hh = b->cs[0]->wk_h;                            // the block index is DPP_BLK_BITS bits of the granule tag
     const int maxblk = (1 << DPP_BLK_BITS) - 1;
-    if ((general || g_dpp_px_override != 4) && hh <= maxblk * dpp_rb(2, delta) && (size_t) ((w + dpp_own(2) - 1) / dpp_own(2)) * n <= (size_t) limit) return 2;
+    // px code 3 (round 6): 32-column tiles with 48-column halos, 48-row blocks -- a third fewer hand-overs through memory for twice the
+    // tiles; while every tile still gets a compute unit of its own (a single 4K image: 120 tiles; measured: DESIGN.md 4.2)
+    if (!general && delta == 1 && (g_dpp_px_override == 3 || g_dpp_px_override == 0) && hh <= maxblk * dpp_rb(3, 1) &&
+        (size_t) ((w + dpp_own(3) - 1) / dpp_own(3)) * n <= (size_t) std::min(limit, g_dpp_px_override == 3 ? limit : g_n_cu)) return 3;
+    if ((general || (g_dpp_px_override != 4 && g_dpp_px_override != 3)) && hh <= maxblk * dpp_rb(2, delta) && (size_t) ((w + dpp_own(2) - 1) / dpp_own(2)) * n <= (size_t) limit) return 2;
     const int limit4 = g_dpp_limit_override >= 0 ? std::min(g_dpp_limit_override, g_dpp_max_wgs_px4) : g_dpp_max_wgs_px4;
-    if (!general && g_dpp_px_override != 2 && hh <= maxblk * dpp_halo(4) && (size_t) ((w + dpp_own(4) - 1) / dpp_own(4)) * n <= (size_t) limit4) return 4;
+    if (!general && g_dpp_px_override != 2 && g_dpp_px_override != 3 && hh <= maxblk * dpp_halo(4) && (size_t) ((w + dpp_own(4) - 1) / dpp_own(4)) * n <= (size_t) limit4) return 4;
     return 0;
 }
 static bool dp_persistent_ok(const LqrHipBatch *b, int w) { return dp_persistent_px(b, w) != 0; }
@@ -1038,7 +1047,14 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
 #undef LAUNCH_TILE_G_W
 #undef LAUNCH_TILE_G_D
     }
-    else if (px == 2) LAUNCH_TILE_PX(2); else LAUNCH_TILE_PX(4);
+    else if (px == 2) LAUNCH_TILE_PX(2);
+    else if (px == 3) {
+#define LAUNCH_TILE_W(LRV, RIGV) hipLaunchKernelGGL((k_dp_tile_p<2, LRV, RIGV, UPDATE, 1, false, 24>), grid, dim3(64 * DPP_W), 0, b->stream, b->d_desc + first, k, w, h, c0->stride, b->exch, epoch, g_dev_err)
+        if (lr) { if (k.use_rig) LAUNCH_TILE_W(true, true); else LAUNCH_TILE_W(true, false); }
+        else { if (k.use_rig) LAUNCH_TILE_W(false, true); else LAUNCH_TILE_W(false, false); }
+#undef LAUNCH_TILE_W
+    }
+    else LAUNCH_TILE_PX(4);
 #undef LAUNCH_TILE_G_LR
 #undef LAUNCH_TILE_G
 #undef LAUNCH_TILE_PX

@@ -209,8 +209,9 @@ void lqrhip_set_vpath_mode(int mode, int par_max);
  * must all be resident: -1 = the bound derived from the occupancy query at lqrhip_init, n >= 0 = min(n, that bound).
  * Grids above the cap run as k_dp_tile (one launch per 32 rows).  0 forces that path (tests). */
 void lqrhip_set_dp_persistent_limit(int workgroups);
-/* Pixels per lane of the persistent tiled sweep: 0 = by batch size (2 while twice the tiles fit the residency bound,
- * else 4), 2 or 4 = pinned (tests) */
+/* Geometry of the persistent tiled sweep: 0 = by batch size (3 = 2 px per lane, 32-column tiles with 48-column halos and 48-row blocks
+ * while every tile has a compute unit to itself; 2 = 2 px per lane, 64-column tiles, 32-row blocks while twice the tiles fit the
+ * residency bound; else 4 px per lane), 2 / 3 / 4 = pinned (tests) */
 void lqrhip_set_dp_persistent_px(int px);
 void lqrhip_prof_reset(void);
 int lqrhip_prof_get(const char *kernel, double *ms_total, long long *launches, double *bytes_total);

@@ -26,13 +26,13 @@ BUDGETS = [
     (r"^k_carve$", 96, 0, 0, "5 waves per SIMD: the carve's 0.4 of the HBM roof next to the chain kernels (DESIGN 4.9, 4.14)"),
     (r"^k_band_update_tw<4, ", 256, 0, 0, "8 waves per workgroup = 2 per SIMD; it claims all 256 registers on purpose (no sibling kernel's wave beside it); no scratch in the row loop"),
     (r"^k_band_levels<", 256, 0, 0, "2 waves per SIMD (amdgpu_waves_per_eu(2, 2)): the residency bound the slot count is taken from; one site each for loads, rows and stores or 330 VGPRs spill (DESIGN 4.16)"),
-    (r"^k_dp_tile_p<[24], (true|false), (true|false), false, 1, false>$", 128, 0, 0, "E5, plain: 4 waves per SIMD"),
-    (r"^k_dp_tile_p<2, (true|false), (true|false), true, 1, false>$", 232, 0, 0, "E9 full width, 32-row block staged in registers: 2 waves per SIMD"),
-    (r"^k_dp_tile_p<4, (true|false), (true|false), true, 1, false>$", 216, 0, 0, "E9 full width, 4 px per lane: 2 waves per SIMD"),
-    (r"^k_dp_tile_p<2, .*, [1234], (true|false)>$", 272, 0, 0, "general instantiations (delta_x 2..4, rigidity mask): at least one workgroup per SIMD pair, no scratch"),
-    (r"^k_dp_tile_p<2, (true|false), true, (true|false), ([5-9]|10), (true|false)>$", 256, 0, 0, "delta_x 5 .. 10 (round 6): 3 .. 6 staged rows, 11 .. 21 candidates per pixel; two workgroups per SIMD pair, no scratch"),
+    (r"^k_dp_tile_p<[24], (true|false), (true|false), false, 1, false, (16|24)>$", 128, 0, 0, "E5, plain: 4 waves per SIMD"),
+    (r"^k_dp_tile_p<2, (true|false), (true|false), true, 1, false, (16|24)>$", 232, 0, 0, "E9 full width, 32-row block staged in registers: 2 waves per SIMD"),
+    (r"^k_dp_tile_p<4, (true|false), (true|false), true, 1, false, 16>$", 216, 0, 0, "E9 full width, 4 px per lane: 2 waves per SIMD"),
+    (r"^k_dp_tile_p<2, .*, [1234], (true|false), 16>$", 272, 0, 0, "general instantiations (delta_x 2..4, rigidity mask): at least one workgroup per SIMD pair, no scratch"),
+    (r"^k_dp_tile_p<2, (true|false), true, (true|false), ([5-9]|10), (true|false), 16>$", 256, 0, 0, "delta_x 5 .. 10 (round 6): 3 .. 6 staged rows, 11 .. 21 candidates per pixel; two workgroups per SIMD pair, no scratch"),
     (r"^k_vp_maps<", 32, 0, 0, "the map kernel is LDS-latency-bound: many workgroups per CU (21 KB of LDS each)"),
-    (r"^k_vp_solve<", 96, 0, 0, "one workgroup per image"),
+    (r"^k_vp_solve<", 160, 0, 0, "one workgroup per image; a stage's loads are all issued before the first is stored (12 x 16 bytes in registers)"),
     (r"^k_vpath1<1>$", 192, 0, 0, "one wave chases, 2 waves per SIMD of the 4-wave workgroup"),
     (r"^k_vpath1<[234567]>$", 128, 0, 0, "shorter chunks"),
     (r"^k_emap_update<\d, 12>$", 64, 0, 0, "delta_x <= 2: 8 waves per SIMD"),
@@ -104,7 +104,7 @@ ISA_LIMITS = [
      "plane pointers in scalar registers (uni_ptr): from the descriptor's vector loads they arrive in VGPRs and every row paid "
      "4 v_readfirstlane + hazard nops (202 in the kernel)"),
     (r"^k_band_update_tw<4, ", "s_nop", 40, "as above (106 before)"),
-    (r"^k_dp_tile_p<2, (true|false), false, true, 1, false>$", "s_nop", 40, "the 32-row block loop, as k_band_levels (10 now)"),
+    (r"^k_dp_tile_p<2, (true|false), false, true, 1, false, (16|24)>$", "s_nop", 40, "the 32-row block loop, as k_band_levels (10 now)"),
     (r"^k_(band|dp_tile|dp_sweep|vpath|carve|emap)", "flat_load_dword", 0,
      "an LDS flag read through a generic pointer (volatile cast of a __shared__ variable inside a lambda): FLAT + s_waitcnt "
      "vmcnt(0) drains the wave's prefetch and waits for its write-through stores -- use LDS_FLAG (lqr_common.h)"),
@@ -142,7 +142,7 @@ def test_row_loops_keep_their_schedule_and_no_flag_goes_through_flat(meta):
 def test_isa_checker_is_red_on_doctored_counts(meta):
     fat = copy.deepcopy(isa_counts())
     fat["k_band_levels<false, false, 1, false>"]["s_nop"] = 141
-    fat["k_dp_tile_p<2, true, false, true, 1, false>"]["flat_load_dword"] = 3
+    fat["k_dp_tile_p<2, true, false, true, 1, false, 16>"]["flat_load_dword"] = 3
     fat["k_band_update_tw<4, false, false>"]["v_readfirstlane_b32"] = 202
     bad = isa_violations(fat)
     assert len(bad) == 3 and "k_band_levels" in bad[0] and "k_band_update_tw" in bad[1] and "flat_load_dword" in bad[2], bad

@@ -282,10 +282,11 @@ def test_sub_batches_on_separate_streams(oracle, engine, nsub):
         c.destroy()
 
 
-@pytest.mark.parametrize("px", [2, 4])
+@pytest.mark.parametrize("px", [2, 3, 4])
 def test_persistent_sweep_pixels_per_lane(oracle, engine, px):
     """k_dp_tile_p runs with 2 pixels per lane (128-column tiles) while twice the tiles fit the residency bound and with
-    4 (256-column tiles) beyond that; both pinned here on the same cases: full builds with both tie rules, incremental
+    4 (256-column tiles) beyond that; round 6: geometry 3 = 2 pixels per lane, 32 own columns + 48-column halos, 48-row blocks
+    (single images); all pinned here on the same cases: full builds with both tie rules, incremental
     updates, rigidity, tiles that straddle the image borders, a batch"""
     engine.lib.lqrhip_set_dp_persistent_px.argtypes = [ctypes.c_int]
     engine.lib.lqrhip_set_dp_persistent_px(px)

@@ -156,3 +156,30 @@ def test_wide_delta_4k_rows_and_8k_columns(oracle, engine, lib):
     for w, h, d in ((300, 2300, 10), (6000, 120, 7)):
         img = D.photo_like(w, h, 77)
         H.assert_same(H.run_case(oracle, img, w - 12, h, delta_x=d), H.run_case(engine, img, w - 12, h, delta_x=d), "%dx%d delta %d" % (w, h, d))
+
+
+# ---------------------------------------------------------------- the 48-column-halo geometry of k_dp_tile_p (single images)
+@pytest.mark.parametrize("w,h", [(31, 47), (33, 48), (64, 49), (97, 96), (129, 97), (700, 300), (1290, 145), (3000, 100)])
+@pytest.mark.parametrize("px", [3, 2])
+def test_wide_halo_tile_geometry_planes_and_seams(oracle, engine, lib, w, h, px):
+    """geometry 3 of the persistent tiled kernels (32 own columns, 48-column halos that reach across the adjacent tile into the one behind
+    it, 48-row blocks in two 24-row batches) against the oracle and against geometry 2: shapes around the tile (32), block (48) and
+    batch (24) sizes; DP planes after 25 incremental updates with both tie rules and rigidity; whole resizes in both directions"""
+    engine.lib.lqrhip_set_dp_persistent_px.argtypes = [ctypes.c_int]
+    engine.lib.lqrhip_set_dp_persistent_px(px)
+    img = D.photo_like(w, h, 500 + w) if w % 2 else D.noise(w, h, 500 + w)
+    k = min(25, w - 3)
+    try:
+        for kw in (dict(switch_freq=0), dict(switch_freq=1000, rigidity=3.0)):
+            oracle.lqrx_set_debug(1); engine.lqrx_set_debug(1)
+            ca, _ = H.init_carver(oracle, img, w - k, h, **kw); cb, _ = H.init_carver(engine, img, w - k, h, **kw)
+            assert ca.resize(w - k, h) == L.LQR_OK and cb.resize(w - k, h) == L.LQR_OK
+            (ea, ma, da), (eb, mb, db) = ca.debug_snapshot(), cb.debug_snapshot()
+            assert np.array_equal(ea.view(np.int32), eb.view(np.int32)) and np.array_equal(ma.view(np.int32), mb.view(np.int32)) and np.array_equal(da[1:], db[1:]), kw
+            assert np.array_equal(ca.vmap_dump()["data"], cb.vmap_dump()["data"])
+            ca.destroy(); cb.destroy()
+        oracle.lqrx_set_debug(0); engine.lqrx_set_debug(0)
+        H.assert_same(H.run_case(oracle, img, max(2, w - 9), max(2, h - 7)), H.run_case(engine, img, max(2, w - 9), max(2, h - 7)), "geometry %d, %dx%d" % (px, w, h))
+    finally:
+        oracle.lqrx_set_debug(0); engine.lqrx_set_debug(0)
+        engine.lib.lqrhip_set_dp_persistent_px(0)
