@@ -129,6 +129,20 @@ def test_manifest_is_complete():
             assert "'nrg_func': 6" in v["what"], v
 
 
+def test_precision_evidence_covers_every_vector_the_shipped_build_differs_on():
+    """PRECISION.json (scripts/ref_engine/precision_evidence.py): for each vector whose result the exe as shipped does not give, which
+    single float-only function under the 24-bit word reproduces it on top of 53-bit doubles -- the per-function evidence behind "sse""""
+    prec = json.load(open(os.path.join(REF, "PRECISION.json")))
+    have = {(v["group"], v["name"]) for v in prec["vectors"]}
+    want = {(v["group"], v["name"]) for v in MANIFEST["vectors"] if v.get("same_as_shipped") is False and v["group"] != "interactive"}
+    assert want == have
+    for v in prec["vectors"]:
+        r = v["reproduces_the_vector"]
+        assert r["sse"] and not r["shipped"], v["name"]
+        # nothing but the two DP functions (or the double arithmetic alone) ever decides a result
+        assert r["d53"] or set(v["changes_d53_result"]) <= {"lqr_carver_build_mmap", "lqr_carver_update_mmap"}, v
+
+
 @pytest.mark.parametrize("entry", SMALL, ids=ids(SMALL))
 def test_oracle_reproduces_the_genuine_engine(oracle, entry):
     check(oracle, entry)
