@@ -131,7 +131,7 @@ def test_manifest_is_complete():
 
 def test_precision_evidence_covers_every_vector_the_shipped_build_differs_on():
     """PRECISION.json (scripts/ref_engine/precision_evidence.py): for each vector whose result the exe as shipped does not give, which
-    single float-only function under the 24-bit word reproduces it on top of 53-bit doubles -- the per-function evidence behind "sse""""
+    single float-only function under the 24-bit word reproduces it on top of 53-bit doubles -- the per-function evidence behind the "sse" mode"""
     prec = json.load(open(os.path.join(REF, "PRECISION.json")))
     have = {(v["group"], v["name"]) for v in prec["vectors"]}
     want = {(v["group"], v["name"]) for v in MANIFEST["vectors"] if v.get("same_as_shipped") is False and v["group"] != "interactive"}
