@@ -315,13 +315,21 @@ __global__ __launch_bounds__(256) void k_vp_maps(const DevCarver *cs, int w, int
     const int X0 = blockIdx.x * 256, base = X0 - RD, tid = threadIdx.x;
     // stage: bytes [base, base + WIN) of the chunk's rows, as dwords (the plane's origin may make the address unaligned: fine on
     // gfx950); columns outside [0, stride) are not loaded -- no path of the image goes there
-    constexpr int WD = (WIN + 3) / 4;
-    for (int i = tid; i < nrows * WD; i += 256) {
-        const int r = i / WD, d = i - r * WD, col = base + 4 * d;
-        uint32_t v = 0u;
-        if (col >= 0 && col + 3 < stride) v = *(const gu32 *) (c.least + (size_t) (ytop - r) * stride + col);
-        else for (int k = 0; k < 4; k++) if (col + k >= 0 && col + k < stride) v |= (uint32_t) (uint8_t) c.least[(size_t) (ytop - r) * stride + col + k] << (8 * k);
-        *(uint32_t *) &s_rows[r][4 * d] = v;
+    // (all of a thread's loads are issued before the first goes to LDS: one memory round trip per workgroup instead of ~20)
+    constexpr int WD = (WIN + 3) / 4, NI = (R * WD + 255) / 256;
+    uint32_t v[NI];
+#pragma unroll
+    for (int k = 0; k < NI; k++) {
+        const int i = tid + 256 * k, r = i / WD, d = i - r * WD, col = base + 4 * d;
+        v[k] = 0u;
+        if (i >= nrows * WD) continue;
+        if (col >= 0 && col + 3 < stride) v[k] = *(const gu32 *) (c.least + (size_t) (ytop - r) * stride + col);
+        else for (int b = 0; b < 4; b++) if (col + b >= 0 && col + b < stride) v[k] |= (uint32_t) (uint8_t) c.least[(size_t) (ytop - r) * stride + col + b] << (8 * b);
+    }
+#pragma unroll
+    for (int k = 0; k < NI; k++) {
+        const int i = tid + 256 * k, r = i / WD, d = i - r * WD;
+        if (i < nrows * WD) *(uint32_t *) &s_rows[r][4 * d] = v[k];
     }
     __syncthreads();
     const int x = X0 + tid;

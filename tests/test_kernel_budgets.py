@@ -31,7 +31,7 @@ BUDGETS = [
     (r"^k_dp_tile_p<4, (true|false), (true|false), true, 1, false, 16>$", 216, 0, 0, "E9 full width, 4 px per lane: 2 waves per SIMD"),
     (r"^k_dp_tile_p<2, .*, [1234], (true|false), 16>$", 272, 0, 0, "general instantiations (delta_x 2..4, rigidity mask): at least one workgroup per SIMD pair, no scratch"),
     (r"^k_dp_tile_p<2, (true|false), true, (true|false), ([5-9]|10), (true|false), 16>$", 256, 0, 0, "delta_x 5 .. 10 (round 6): 3 .. 6 staged rows, 11 .. 21 candidates per pixel; two workgroups per SIMD pair, no scratch"),
-    (r"^k_vp_maps<", 32, 0, 0, "the map kernel is LDS-latency-bound: many workgroups per CU (21 KB of LDS each)"),
+    (r"^k_vp_maps<", 72, 0, 0, "the map kernel is LDS-latency-bound: 7 workgroups per CU (21 KB of LDS each) = 7 waves per SIMD; the staging loads of a thread (21 dwords) are in flight together"),
     (r"^k_vp_solve<", 160, 0, 0, "one workgroup per image; a stage's loads are all issued before the first is stored (12 x 16 bytes in registers)"),
     (r"^k_vpath1<1>$", 192, 0, 0, "one wave chases, 2 waves per SIMD of the 4-wave workgroup"),
     (r"^k_vpath1<[234567]>$", 128, 0, 0, "shorter chunks"),
