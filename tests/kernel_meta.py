@@ -81,8 +81,15 @@ def instruction_counts(so_path, mnemonics=("s_nop", "v_readfirstlane_b32", "flat
                 if cur is None:
                     continue
                 t = line.split()
-                if t and t[0] in cur:
+                if not t:
+                    continue
+                if t[0] in cur:
                     cur[t[0]] += 1
+                # (every width of FLAT access counts -- flat_load_dwordx2, _ubyte, _short ... -- under the dword key's family)
+                elif t[0].startswith("flat_load_") and "flat_load_dword" in cur:
+                    cur["flat_load_dword"] += 1
+                elif t[0].startswith("flat_store_") and "flat_store_dword" in cur:
+                    cur["flat_store_dword"] += 1
         mangled = sorted(counts)
         names = subprocess.run(["c++filt"], input="\n".join(mangled), capture_output=True, text=True, check=True).stdout.split("\n")
         for mn, n in zip(mangled, names):

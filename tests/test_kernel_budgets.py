@@ -132,11 +132,31 @@ def isa_violations(counts):
     return bad
 
 
+# the instruction-schedule limits (s_nop, v_readfirstlane) describe what THIS compiler makes of the row loops; another hipcc release
+# may schedule differently without anything being wrong -- then they are reported, not failed.  The FLAT limits hold for any.
+RECORDED_COMPILER = "roc-7.2.0"
+
+
+def compiler_is_the_recorded_one():
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    try:
+        return RECORDED_COMPILER in subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+    except OSError:
+        return False
+
+
 def test_row_loops_keep_their_schedule_and_no_flag_goes_through_flat(meta):
     counts = isa_counts()
     assert len(counts) > 100, "expected the whole kernel set, found %d kernels" % len(counts)
     bad = isa_violations(counts)
-    assert not bad, "\n".join(bad)
+    flat = [b for b in bad if " x flat_" in b or "no kernel matches" in b]
+    sched = [b for b in bad if b not in flat]
+    assert not flat, "\n".join(flat)
+    if sched and not compiler_is_the_recorded_one():
+        pytest.xfail("schedule limits recorded for %s; this compiler: %s" % (RECORDED_COMPILER, "; ".join(sched)))
+    assert not sched, "\n".join(sched)
 
 
 def test_isa_checker_is_red_on_doctored_counts(meta):

@@ -1,4 +1,4 @@
-"""GPU_MAX_HW_QUEUES and the library (csrc/lqr_hip.hip lqrhip_on_load, lqrhip_sub_batches): the 4-stream schedule of large
+"""GPU_MAX_HW_QUEUES and the library (csrc/lqr_shim.hip lqrhip_on_load, lqrhip_sub_batches): the 4-stream schedule of large
 lock-step groups needs 8 hardware queues, the HIP runtime reads the variable once when it comes up, and a host like the
 plug-in does not know it exists.  Loaded before the runtime is up the library sets it; a host's own value is kept; loaded
 into a process whose runtime is already up (it can no longer be changed) the library stays on one stream."""

@@ -1,6 +1,6 @@
 """Nothing the engine computes may depend on what a recycled device block held before (-m gpu).
 
-The engine's allocator hands freed blocks out again (lqr_hip.hip, pool_alloc), so a kernel that reads a cell nothing
+The engine's allocator hands freed blocks out again (csrc/lqr_shim.hip, pool_alloc), so a kernel that reads a cell nothing
 wrote yet sees another image's planes -- and passes every test that runs a case on a fresh process.  LQRHIP_POISON (read
 once, when the library is loaded: hence the child processes) fills every block handed out with a pattern first:
 
