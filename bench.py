@@ -281,6 +281,9 @@ def main():
     lib.lqrhip_set_update_mode(args.update_mode)
     lib.lqrhip_set_band_levels.argtypes = [C.c_int]
     lib.lqrhip_set_band_levels(args.band_levels)
+    if os.environ.get("LQR_NO_FUSE"):        # A/B switch: the carve and the energy update as two kernels also for small groups
+        lib.lqrhip_set_carve_fused.argtypes = [C.c_int]
+        lib.lqrhip_set_carve_fused(0)
     lib.lqrhip_set_vpath_mode.argtypes = [C.c_int, C.c_int]
     lib.lqrhip_set_vpath_mode(args.vpath_mode, 0)
     if os.environ.get("LQR_LV_DBG"):

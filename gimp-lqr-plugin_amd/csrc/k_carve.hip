@@ -249,5 +249,79 @@ __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h
     for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < h; y += gridDim.x * 4) carve_row(c, org, side, y, w, stride, delta, move_dp, lane);
 }
 
+// ---------------------------------------------------------------------------
+// k_carve_e<NRG>: k_carve and k_emap_update<NRG, 12> in ONE launch, for single images and small groups (round 6).  There a seam round is
+// a chain of dependent launches of small kernels (a 4K carve is 9 us, the energy update 9 us, each plus its dispatch), and the
+// energy of row y needs nothing but row y's own carve: the wave that has moved a row refreshes the energies next to the seam on
+// that row.  What k_emap_update does with a thread per row and LDS rows shared between neighbouring threads, a wave does alone:
+// lanes 0 .. 35 stage the 12 brightness samples of rows y - 1, y, y + 1 (each mapped back to the frozen pixel plane through the
+// seam log, as there), lanes 0 .. 11 then evaluate the gradient energy of the row's changed interval.  Same arithmetic, same
+// order of operations: bit-identical energies.  delta_x <= 2 (12 samples per row suffice); larger delta_x and larger groups keep
+// the two kernels (the carve's 96 registers and 5 waves per SIMD are what its bandwidth rests on).
+// ---------------------------------------------------------------------------
+template <int NRG>
+__global__ __launch_bounds__(256) void k_carve_e(const DevCarver *cs, DpK p, int w, int h, int stride, int move_dp, int k, int epoch)
+{
+    constexpr int NT = 12;
+    constexpr bool luma = (NRG >= 3);
+    const GCarver c = gview_phys(cs[blockIdx.y]);
+    const int org = c.flags[FLAG_ORG_PREV], side = c.flags[FLAG_SIDE];      // published by the backtrack for this seam
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ double s_n255[256];
+    __shared__ double s_bt[4][3][NT];
+    __shared__ float s_bb[4][3][NT];
+    __shared__ int s_lo[4][3];
+    fill_norm255(s_n255, threadIdx.x, 256);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) c.flags[FLAG_OVF_ROW] = h;
+    const int wn = w - 1;                                        // the frame after the carve
+    gf32 *en = c.en + org + side;                                // its logical view (the origin after this seam)
+    for (int y = blockIdx.x * 4 + wv; y < h; y += gridDim.x * 4) {
+        carve_row(c, org, side, y, w, stride, p.delta, move_dp, lane);
+        if (wn <= 1) continue;
+        // ---- the energy of row y next to the seam (k_emap_update, one row)
+        const int g = lane / NT, i = lane - g * NT, t = y - 1 + g;          // lanes 0 .. 35: sample i of row t
+        const bool samp = lane < 3 * NT && t >= 0 && t < h;
+        int lo = 0, r = -1, pos = 0;
+        if (samp) {
+            int xmin, xmax;
+            nrg_interval(c.seam_x, t, h, wn, p.radius, xmin, xmax);
+            int l = xmin - 1; r = xmax + 1;
+            if (t > 0) { int a, b; nrg_interval(c.seam_x, t - 1, h, wn, p.radius, a, b); if (b >= a) { l = min(l, a); r = max(r, b); } }
+            if (t < h - 1) { int a, b; nrg_interval(c.seam_x, t + 1, h, wn, p.radius, a, b); if (b >= a) { l = min(l, a); r = max(r, b); } }
+            lo = max(l, 0);
+            pos = lo + i;
+            const gi32 *lg = c.seam_log + t;
+            for (int j = k; j >= epoch; j -= EU_LOGB) {
+                int v[EU_LOGB];
+#pragma unroll
+                for (int u = 0; u < EU_LOGB; u++) v[u] = lg[(size_t) max(j - u, epoch) * h];
+#pragma unroll
+                for (int u = 0; u < EU_LOGB; u++) { const int vu = (j - u >= epoch) ? v[u] : 0x7fffffff; pos += (vu <= pos) ? 1 : 0; }
+            }
+            const int wf = wn + (k - epoch) + 1;                 // width of the frozen frame
+            const bool ok = (lo + i <= min(r, wn - 1)) && pos < wf;
+            const size_t o = (size_t) t * stride + (ok ? pos : 0);
+            s_bt[wv][g][i] = ok ? px_bright(c.pix[o], p.ch, luma, Norm255Lut{s_n255}) : 0.0;
+            s_bb[wv][g][i] = (ok && c.bias) ? c.bias[o] : 0.0f;
+            if (i == 0) s_lo[wv][g] = lo;
+        }
+        __builtin_amdgcn_wave_barrier();                          // (one wave: its LDS operations execute in order)
+        int xmin, xmax;
+        nrg_interval(c.seam_x, y, h, wn, p.radius, xmin, xmax);
+        const int x = xmin + lane;
+        if (x <= xmax) {
+            float e = grad_energy_f<NRG>([&](int xx, int yy) { const int gg = yy - y + 1; return s_bt[wv][gg][xx - s_lo[wv][gg]]; }, x, y, wn, h);
+            if (c.bias) e = __fadd_rn(e, __fdiv_rn(s_bb[wv][1][x - s_lo[wv][1]], (float) p.w_start));
+            // (behind the carve's stores of this row in program order; different cache policies: drain them first)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            en[(size_t) y * stride + x] = e;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- the instantiations the shim launches (lqr_kernels.h declares them)
 // (k_carve is not a template)
+#define INST_CE(N) template __global__ void k_carve_e<N>(const DevCarver *, DpK, int, int, int, int, int, int);
+INST_CE(0) INST_CE(1) INST_CE(2) INST_CE(3) INST_CE(4) INST_CE(5) INST_CE(6)

@@ -107,9 +107,6 @@ __global__ void k_mask_add(float *plane, int w0, const uint8_t *mask, int channe
 // y-1..y+1 by its own gradient and [min - 1, max] of the seam over rows y-2..y+2 by its neighbours', and the
 // seam moves at most delta_x per row: at most max(4*delta_x + 2, 2*delta_x + 4) columns.  EU_NT is a template
 // parameter chosen by the launch from delta_x: 12 (delta_x <= 2), 36 (<= 8), 68 (<= 16 = LQRHIP_MAX_DELTA).
-#ifndef EU_LOGB
-#define EU_LOGB 8            // log entries fetched per round of the walk back to the frozen frame
-#endif
 template <int NRG, int EU_NT>
 __global__ __launch_bounds__(64) void k_emap_update(const DevCarver *cs, DpK p, int w, int h, int stride, int k, int epoch)
 {

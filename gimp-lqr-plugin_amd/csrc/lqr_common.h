@@ -541,6 +541,9 @@ struct InflateDev {
     int ch;
 };
 #define EU_ROWS 62          // k_emap_update: rows per block (+2 halo rows)
+#ifndef EU_LOGB
+#define EU_LOGB 8           // k_emap_update / k_carve_e: log entries fetched per round of the walk back to the frozen frame
+#endif
 // parallel backtrack (k_backtrack.hip, k_vp_*): a chunk is VP_REACH / delta_x rows, so that a path moves at most VP_REACH columns
 // inside a chunk (the displacement fits a byte); k_vp_solve walks VP_STAGE chunks per LDS-resident stage
 constexpr int VP_REACH = 56;

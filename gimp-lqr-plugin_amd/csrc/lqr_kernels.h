@@ -23,6 +23,7 @@ template <int DELTA> __global__ __launch_bounds__(VPATH_THREADS) void k_vp_solve
 
 // k_carve.hip
 __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h, int stride, int delta, int move_dp);
+template <int NRG> __global__ __launch_bounds__(256) void k_carve_e(const DevCarver *cs, DpK p, int w, int h, int stride, int move_dp, int k, int epoch);
 
 // k_band.hip
 template <int PXT, bool UPDATE> __global__ __launch_bounds__(DP_THREADS) void k_dp_sweep(const DevCarver *cs, DpK p, int w, int h, int stride, int lr);

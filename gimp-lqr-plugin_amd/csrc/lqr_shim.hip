@@ -808,6 +808,8 @@ extern "C" void lqrhip_prof_enable(int on) { g_prof = on; }
 static int g_vpath_mode = -1;            // -1: the parallel backtrack for groups up to g_vpath_par_max images of at least g_vpath_min_rows rows; 0: never; 1: always (delta_x 1 .. 4)
 static int g_vpath_par_max = 2, g_vpath_min_rows = 1000;
 extern "C" void lqrhip_set_vpath_mode(int mode, int par_max) { g_vpath_mode = mode; if (par_max > 0) g_vpath_par_max = par_max; }
+static int g_carve_fused = 1;            // k_carve_e (carve + energy update in one launch) for groups up to 4 images (0: the two kernels always)
+extern "C" void lqrhip_set_carve_fused(int on) { g_carve_fused = on != 0; }
 static int g_update_mode = -1;
 static int g_band_levels = -1;           // k_band_levels: -1 automatic; 0 never; n: n slots per image (lqrhip_set_band_levels)
 // -1: by batch size (g_tiled_update_px); 0: band kernel (k_band_update_tw); 1: tiled full-width update whenever its
@@ -1311,7 +1313,18 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
             hipLaunchKernelGGL(k_vpath, dim3(n), dim3(VPATH_THREADS), 0, b->stream, b->d_desc, w, h, stride, leftright_pick, p->delta_x,
                                log_index, moved_unit);
     }
-    {
+    // Single images and groups up to 4: the carve and the energy update in one launch (k_carve_e, k_carve.hip) -- the wave that has moved
+    // a row refreshes that row's energies; one dependent launch less per seam.  delta_x <= 2 (12 brightness samples per row).
+    const bool fuse_e = g_carve_fused && p->delta_x <= 2 && vp_group <= 4 && wnew > 1;
+    if (fuse_e) {
+        const int lag_max = n <= 4 ? FROZEN_LAG_MAX / 4 : FROZEN_LAG_MAX;
+        if (log_index + 1 - c0->frozen_epoch > lag_max && (rc = frozen_catchup(b, log_index + 1, wnew, h))) return rc;      // (needs the seam log only: before the carve)
+        const int epoch = c0->frozen_epoch;
+        ProfScope ps("carve", b->stream, 4.0 * (double) w * h * n);
+#define LAUNCH_CE(N) hipLaunchKernelGGL((k_carve_e<N>), dim3((h + 3) / 4, n), dim3(256), 0, b->stream, b->d_desc, k, w, h, stride, move_dp, log_index, epoch)
+        NRG_DISPATCH(p->nrg_func, LAUNCH_CE)
+#undef LAUNCH_CE
+    } else {
         // algorithmic bytes of one carve launch: read + write of one 4-byte
         // plane over the half of each row right of the seam = 8 B * w*h/2 per image
         ProfScope ps("carve", b->stream, 4.0 * (double) w * h * n);
@@ -1323,7 +1336,7 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
         HIPCK(hipGetLastError());
         return 0;
     }
-    {
+    if (!fuse_e) {
         ProfScope ps("emap_update", b->stream, 0);
         // the energy update walks the seam log back to the frozen frame (O(lag) per sample); compacting the frozen planes
         // costs a pass over them.  Few images: the walk is on the critical path and the pass is cheap -> short lag

@@ -183,3 +183,48 @@ def test_wide_halo_tile_geometry_planes_and_seams(oracle, engine, lib, w, h, px)
     finally:
         oracle.lqrx_set_debug(0); engine.lqrx_set_debug(0)
         engine.lib.lqrhip_set_dp_persistent_px(0)
+
+
+# ---------------------------------------------------------------- the carve and the energy update in one launch (k_carve_e)
+@pytest.mark.parametrize("nrg", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("ch", [1, 2, 3, 4])
+def test_fused_carve_energy_planes_are_exact(oracle, engine, lib, nrg, ch):
+    """k_carve_e (groups up to 4 images, delta_x <= 2): the wave that has moved a row refreshes that row's energies.  Every energy
+    function x channel layout, with bias masks, delta_x 1 and 2: after 30 seams the energy plane (0 ULP), the cumulative minima and the
+    back pointers equal the oracle's, with the fusion on and off; then whole resizes in both directions with attached layers"""
+    engine.lib.lqrhip_set_carve_fused.argtypes = [ctypes.c_int]
+    w, h = 210, 96
+    img = (D.alpha_ramp if ch in (2, 4) else D.photo_like)(w, h, 70 + ch + nrg, channels=ch)
+    try:
+        for fused in (1, 0):
+            engine.lib.lqrhip_set_carve_fused(fused)
+            for kw in (dict(switch_freq=0), dict(switch_freq=0, delta_x=2, rigidity=2.0, pres=D.ellipse_mask(w, h), disc=D.band_mask(w, h, 40, 80))):
+                kw = dict(kw, nrg_func=nrg)
+                oracle.lqrx_set_debug(1); engine.lqrx_set_debug(1)
+                ca, _ = H.init_carver(oracle, img, w - 30, h, **kw); cb, _ = H.init_carver(engine, img, w - 30, h, **kw)
+                assert ca.resize(w - 30, h) == L.LQR_OK and cb.resize(w - 30, h) == L.LQR_OK
+                (ea, ma, da), (eb, mb, db) = ca.debug_snapshot(), cb.debug_snapshot()
+                assert np.array_equal(ea.view(np.int32), eb.view(np.int32)), ("energies", fused, kw.get("delta_x", 1))
+                assert np.array_equal(ma.view(np.int32), mb.view(np.int32)) and np.array_equal(da[1:], db[1:]), ("DP planes", fused)
+                ca.destroy(); cb.destroy()
+            oracle.lqrx_set_debug(0); engine.lqrx_set_debug(0)
+            kw = dict(nrg_func=nrg, pres=D.ellipse_mask(w, h), resize_aux_layers=True, output_seams=True)
+            H.assert_same(H.run_case(oracle, img, w - 21, h - 13, **kw), H.run_case(engine, img, w - 21, h - 13, **kw), "fused %d nrg %d ch %d" % (fused, nrg, ch))
+    finally:
+        oracle.lqrx_set_debug(0); engine.lqrx_set_debug(0)
+        engine.lib.lqrhip_set_carve_fused(1)
+
+
+@pytest.mark.parametrize("n", [2, 4, 5])
+def test_fused_carve_energy_groups(oracle, engine, lib, n):
+    """groups of 2 and 4 run the fused kernel, 5 the two kernels: every image against the oracle; 70 seams so that the frozen planes
+    are caught up (lag 32) inside the session, and the last seams go down to a width of 2"""
+    w, h = 74, 140
+    imgs = [D.noise(w, h, 40 + i) if i % 2 else D.photo_like(w, h, 40 + i) for i in range(n)]
+    cs = [L.Carver(engine, im).configure() for im in imgs]
+    assert L.resize_batch(engine, cs, 2, h) == L.LQR_OK
+    for c, im in zip(cs, imgs):
+        ref = H.run_case(oracle, im, 2, h)
+        assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"]) and np.array_equal(c.read_image(), ref["image"])
+    for c in cs:
+        c.destroy()
