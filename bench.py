@@ -281,6 +281,9 @@ def main():
     lib.lqrhip_set_update_mode(args.update_mode)
     lib.lqrhip_set_band_levels.argtypes = [C.c_int]
     lib.lqrhip_set_band_levels(args.band_levels)
+    if os.environ.get("LQR_SWEEP_THREADS"):   # A/B switch: 1024 = the k_dp_sweep<UPDATE> launch behind the band kernels as in rounds 1 - 5
+        lib.lqrhip_set_sweep_threads.argtypes = [C.c_int]
+        lib.lqrhip_set_sweep_threads(int(os.environ["LQR_SWEEP_THREADS"]))
     if os.environ.get("LQR_NO_FUSE"):        # A/B switch: the carve and the energy update as two kernels also for small groups
         lib.lqrhip_set_carve_fused.argtypes = [C.c_int]
         lib.lqrhip_set_carve_fused(0)

@@ -12,8 +12,11 @@
 // it leaves identical memory contents (pixels outside the band have unchanged
 // inputs, float ops are deterministic).
 // ---------------------------------------------------------------------------
-template <int PXT, bool UPDATE>
-__global__ __launch_bounds__(DP_THREADS) void k_dp_sweep(const DevCarver *cs, DpK p, int w, int h, int stride, int lr)
+// NTH threads: 1024 for the full sweeps; 256 (round 6) for the launch behind the band kernels, which almost always only LOOKS at
+// flags[FLAG_OVF_ROW] and leaves -- a 1024-thread workgroup needs 16 waves' worth of one compute unit free at once, and beside the
+// sibling streams' kernels that wait was 43 us per seam round at 64 images
+template <int PXT, bool UPDATE, int NTH>
+__global__ __launch_bounds__(NTH) void k_dp_sweep(const DevCarver *cs, DpK p, int w, int h, int stride, int lr)
 {
     const GCarver c = gview(cs[blockIdx.x]);
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -26,14 +29,14 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sweep(const DevCarver *cs, Dp
         if (y0 >= h) return;
     }
     if (y0 == 0) {
-        for (int x = tid; x < w; x += DP_THREADS) {
+        for (int x = tid; x < w; x += NTH) {
             float e = c.en[x];
             c.m[x] = e;
             prev[x] = e;
         }
         y0 = 1;
     } else {
-        for (int x = tid; x < w; x += DP_THREADS) prev[x] = c.m[(size_t) (y0 - 1) * stride + x];
+        for (int x = tid; x < w; x += NTH) prev[x] = c.m[(size_t) (y0 - 1) * stride + x];
     }
     __syncthreads();
 
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sweep(const DevCarver *cs, Dp
     auto prefetch = [&](int y) {
 #pragma unroll
         for (int k = 0; k < PXT; k++) {
-            int x = tid + k * DP_THREADS;
+            int x = tid + k * NTH;
             if (x < w && y < h) {
                 size_t o = (size_t) y * stride + x;
                 e_nx[k] = c.en[o];
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sweep(const DevCarver *cs, Dp
         prefetch(y + 1);
 #pragma unroll
         for (int k = 0; k < PXT; k++) {
-            int x = tid + k * DP_THREADS;
+            int x = tid + k * NTH;
             if (x < w) {
                 const int dlo = max(-x, -p.delta), dhi = min(w - 1 - x, p.delta);
                 const float rfact = c.rig ? rf[k] : 1.0f;
@@ -834,7 +837,8 @@ __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs
 
 
 // ---- the instantiations the shim launches (lqr_kernels.h declares them)
-#define INST_SWEEP(P) template __global__ void k_dp_sweep<P, false>(const DevCarver *, DpK, int, int, int, int); template __global__ void k_dp_sweep<P, true>(const DevCarver *, DpK, int, int, int, int);
+#define INST_SWEEP(P) template __global__ void k_dp_sweep<P, false, DP_THREADS>(const DevCarver *, DpK, int, int, int, int); template __global__ void k_dp_sweep<P, true, DP_THREADS>(const DevCarver *, DpK, int, int, int, int); \
+    template __global__ void k_dp_sweep<P, true, 256>(const DevCarver *, DpK, int, int, int, int);
 INST_SWEEP(1) INST_SWEEP(2) INST_SWEEP(4) INST_SWEEP(8) INST_SWEEP(16)
 #define INST_BAND(LRV, RIGV) template __global__ void k_band_update_tw<4, LRV, RIGV>(const DevCarver *, DpK, int, int, int, int *); \
     template __global__ void k_band_update_mw<2, 8, 8, LRV, RIGV>(const DevCarver *, DpK, int, int, int); \

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_carve(const DevCarver *cs, int w, int h
 template <int NRG> __global__ __launch_bounds__(256) void k_carve_e(const DevCarver *cs, DpK p, int w, int h, int stride, int move_dp, int k, int epoch);
 
 // k_band.hip
-template <int PXT, bool UPDATE> __global__ __launch_bounds__(DP_THREADS) void k_dp_sweep(const DevCarver *cs, DpK p, int w, int h, int stride, int lr);
+template <int PXT, bool UPDATE, int NTH = DP_THREADS> __global__ __launch_bounds__(NTH) void k_dp_sweep(const DevCarver *cs, DpK p, int w, int h, int stride, int lr);
 __global__ __launch_bounds__(64) void k_band_update(const DevCarver *cs, DpK p, int w, int h, int stride, int lr);
 template <int PXL, int NW, int R, bool LR, bool RIG> __global__ __launch_bounds__(64 * NW) void k_band_update_mw(const DevCarver *cs, DpK p, int w, int h, int stride);
 template <int NW, bool LR, bool RIG> __global__ __launch_bounds__(128 * NW) void k_band_update_tw(const DevCarver *cs, DpK p, int w, int h, int stride, int *dev_err);

@@ -808,6 +808,8 @@ extern "C" void lqrhip_prof_enable(int on) { g_prof = on; }
 static int g_vpath_mode = -1;            // -1: the parallel backtrack for groups up to g_vpath_par_max images of at least g_vpath_min_rows rows; 0: never; 1: always (delta_x 1 .. 4)
 static int g_vpath_par_max = 2, g_vpath_min_rows = 1000;
 extern "C" void lqrhip_set_vpath_mode(int mode, int par_max) { g_vpath_mode = mode; if (par_max > 0) g_vpath_par_max = par_max; }
+static int g_sweep_threads = 256;        // threads of the k_dp_sweep<UPDATE> launch behind the band kernels (256, or 1024 as in rounds 1 - 5)
+extern "C" void lqrhip_set_sweep_threads(int n) { g_sweep_threads = n == 256 ? 256 : DP_THREADS; }
 static int g_carve_fused = 1;            // k_carve_e (carve + energy update in one launch) for groups up to 4 images (0: the two kernels always)
 extern "C" void lqrhip_set_carve_fused(int on) { g_carve_fused = on != 0; }
 static int g_update_mode = -1;
@@ -1092,22 +1094,27 @@ static int launch_dp(LqrHipBatch *b, const DpK &k, int w, int h, int lr)
             }
         }
     }
-    int pxt = (w + DP_THREADS - 1) / DP_THREADS;
+    // the launch behind a band kernel (UPDATE) almost always only looks at flags[FLAG_OVF_ROW]: 256 threads for rows up to 4096 px (a
+    // workgroup that finds room at once beside the sibling streams' kernels), 1024 for the full sweeps and wider rows
+    const int nth = (UPDATE && g_sweep_threads == 256 && w <= 16 * 256) ? 256 : DP_THREADS;
+    int pxt = (w + nth - 1) / nth;
     size_t lds = (size_t) 2 * ((w + 3) & ~3) * sizeof(float);
-    dim3 grid((unsigned) b->cs.size()), block(DP_THREADS);
-#define LAUNCH_DP(P)                                                                                                  \
+    dim3 grid((unsigned) b->cs.size());
+#define LAUNCH_DP_T(P, T)                                                                                             \
     do {                                                                                                              \
         if (lds > 64 * 1024)                                                                                          \
-            HIPCK(hipFuncSetAttribute((const void *) k_dp_sweep<P, UPDATE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            HIPCK(hipFuncSetAttribute((const void *) k_dp_sweep<P, UPDATE, T>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int) lds));                                                                    \
-        hipLaunchKernelGGL((k_dp_sweep<P, UPDATE>), grid, block, lds, b->stream, b->d_desc, k, w, h, c0->stride, lr); \
+        hipLaunchKernelGGL((k_dp_sweep<P, UPDATE, T>), grid, dim3(T), lds, b->stream, b->d_desc, k, w, h, c0->stride, lr); \
     } while (0)
+#define LAUNCH_DP(P) do { if constexpr (UPDATE) { if (nth == 256) LAUNCH_DP_T(P, 256); else LAUNCH_DP_T(P, DP_THREADS); } else LAUNCH_DP_T(P, DP_THREADS); } while (0)
     if (pxt <= 1) LAUNCH_DP(1);
     else if (pxt <= 2) LAUNCH_DP(2);
     else if (pxt <= 4) LAUNCH_DP(4);
     else if (pxt <= 8) LAUNCH_DP(8);
     else if (pxt <= 16) LAUNCH_DP(16);
     else { g_err = "image wider than 16384 px is not supported"; return LQRHIP_EARG; }
+#undef LAUNCH_DP_T
 #undef LAUNCH_DP
     HIPCK(hipGetLastError());
     return 0;
@@ -1776,6 +1783,9 @@ extern "C" int lqrhip_carver_reset(LqrHipCarver *c, const void *device_rgb, int 
     c->w0 = w; c->h0 = h;
     c->frozen_epoch = 0;
     if ((rc = dmalloc(&c->rgb0, n * c->ch)) || (rc = dmalloc(&c->vs, n))) return rc;
+    // (round 6: these copies on four more streams side by side -- one 33 MB device-to-device copy runs at ~0.5 TB/s, 64 of them are 4 ms of a
+    // 190-ms step -- made the 64-image step 45 % LONGER: with g_stream0 and the four sub-batch streams that is nine streams on the
+    // process's eight hardware queues, and sub-batch streams that share a queue run one after the other.  One stream.)
     HIPCK(hipMemcpyAsync(c->rgb0, device_rgb, n * c->ch, hipMemcpyDeviceToDevice, g_stream0));
     HIPCK(hipMemsetAsync(c->vs, 0, n * sizeof(int32_t), g_stream0));
     if (c->batch) c->batch->dirty = true;

@@ -201,6 +201,8 @@ void lqrhip_prof_enable(int on);
  * one-wave band kernel k_band_update + k_dp_sweep (what delta_x > 4 runs on) whatever the parameters, 5 k_band_levels
  * (4 was round 4's k_band_tiles, removed in round 6: it now behaves as 0) */
 void lqrhip_set_update_mode(int mode);
+/* Test hook: threads of the k_dp_sweep<UPDATE> launch behind the band kernels: 256 (default) or 1024 */
+void lqrhip_set_sweep_threads(int n);
 /* Test hook: 0 = never fuse the carve and the energy update (k_carve_e, groups up to 4 images with delta_x <= 2); default 1 */
 void lqrhip_set_carve_fused(int on);
 /* E7 form: -1 = the parallel two-kernel backtrack (k_vp_maps / k_vp_solve) for groups of up to par_max images (default 2; 0 keeps the

@@ -39,7 +39,7 @@ BUDGETS = [
     (r"^k_dp_tile<", 96, 0, 0, "one wave per tile, 5 per SIMD"),
 ]
 # kernels that are allowed to use scratch at all (slow paths for rows wider than 8192 px / known, outside the row loops)
-SCRATCH_OK = (r"^k_dp_sweep<16, ", r"^k_dp_sweep<8, true>$")
+SCRATCH_OK = (r"^k_dp_sweep<16, ", r"^k_dp_sweep<8, true, (1024|256)>$")
 
 
 def violations(meta):
