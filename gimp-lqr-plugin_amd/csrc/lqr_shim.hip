@@ -1771,6 +1771,7 @@ extern "C" int lqrhip_read_working(LqrHipCarver *c, int w, int h, float *en, flo
 }
 
 // ---- start over from a device-resident image ---------------------------------------------------
+__global__ __launch_bounds__(256) void k_copy16(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t n16);
 extern "C" int lqrhip_carver_reset(LqrHipCarver *c, const void *device_rgb, int w, int h)
 {
     if (!c || c->root || !c->aux.empty() || w < 1 || h < 1) return LQRHIP_EARG;
@@ -1786,7 +1787,18 @@ extern "C" int lqrhip_carver_reset(LqrHipCarver *c, const void *device_rgb, int 
     // (round 6: these copies on four more streams side by side -- one 33 MB device-to-device copy runs at ~0.5 TB/s, 64 of them are 4 ms of a
     // 190-ms step -- made the 64-image step 45 % LONGER: with g_stream0 and the four sub-batch streams that is nine streams on the
     // process's eight hardware queues, and sub-batch streams that share a queue run one after the other.  One stream.)
-    HIPCK(hipMemcpyAsync(c->rgb0, device_rgb, n * c->ch, hipMemcpyDeviceToDevice, g_stream0));
+    {
+        // the runtime's device-to-device copy kernel moves a 33 MB image in 66 us (0.5 TB/s; 64 of them: 4.2 ms of a 190-ms step, one after
+        // the other); the engine's own streaming copy (k_copy16, the one that measures the HBM ceiling) takes ~10
+        const size_t bytes = n * c->ch, n16 = bytes / 16;
+        if (n16 && !(((uintptr_t) device_rgb | (uintptr_t) c->rgb0) & 15)) {
+            hipLaunchKernelGGL(k_copy16, dim3((unsigned) ((n16 + 255) / 256)), dim3(256), 0, g_stream0, (const u32x4 *) device_rgb, (u32x4 *) c->rgb0, n16);
+            HIPCK(hipGetLastError());
+            if (bytes & 15) HIPCK(hipMemcpyAsync(c->rgb0 + n16 * 16, (const uint8_t *) device_rgb + n16 * 16, bytes & 15, hipMemcpyDeviceToDevice, g_stream0));
+        } else {
+            HIPCK(hipMemcpyAsync(c->rgb0, device_rgb, bytes, hipMemcpyDeviceToDevice, g_stream0));
+        }
+    }
     HIPCK(hipMemsetAsync(c->vs, 0, n * sizeof(int32_t), g_stream0));
     if (c->batch) c->batch->dirty = true;
     if (c->active && (rc = ensure_working(c, w, h))) return rc;        // synchronises g_stream0 when it allocates
