@@ -284,9 +284,9 @@ def main():
     if os.environ.get("LQR_SWEEP_THREADS"):   # A/B switch: 1024 = the k_dp_sweep<UPDATE> launch behind the band kernels as in rounds 1 - 5
         lib.lqrhip_set_sweep_threads.argtypes = [C.c_int]
         lib.lqrhip_set_sweep_threads(int(os.environ["LQR_SWEEP_THREADS"]))
-    if os.environ.get("LQR_NO_FUSE"):        # A/B switch: the carve and the energy update as two kernels also for small groups
+    if os.environ.get("LQR_NO_FUSE") or os.environ.get("LQR_FUSE_MAX"):        # A/B switches: two kernels also for small groups / one launch up to n images
         lib.lqrhip_set_carve_fused.argtypes = [C.c_int]
-        lib.lqrhip_set_carve_fused(0)
+        lib.lqrhip_set_carve_fused(int(os.environ.get("LQR_FUSE_MAX", "0")))
     lib.lqrhip_set_vpath_mode.argtypes = [C.c_int, C.c_int]
     lib.lqrhip_set_vpath_mode(args.vpath_mode, 0)
     if os.environ.get("LQR_LV_DBG"):

@@ -810,8 +810,8 @@ static int g_vpath_par_max = 2, g_vpath_min_rows = 1000;
 extern "C" void lqrhip_set_vpath_mode(int mode, int par_max) { g_vpath_mode = mode; if (par_max > 0) g_vpath_par_max = par_max; }
 static int g_sweep_threads = 256;        // threads of the k_dp_sweep<UPDATE> launch behind the band kernels (256, or 1024 as in rounds 1 - 5)
 extern "C" void lqrhip_set_sweep_threads(int n) { g_sweep_threads = n == 256 ? 256 : DP_THREADS; }
-static int g_carve_fused = 1;            // k_carve_e (carve + energy update in one launch) for groups up to 4 images (0: the two kernels always)
-extern "C" void lqrhip_set_carve_fused(int on) { g_carve_fused = on != 0; }
+static int g_carve_fused = 4;            // k_carve_e (carve + energy update in one launch) for groups up to this many images (0: the two kernels always)
+extern "C" void lqrhip_set_carve_fused(int max_images) { g_carve_fused = max_images == 1 ? 4 : max_images < 0 ? 0 : max_images; }
 static int g_update_mode = -1;
 static int g_band_levels = -1;           // k_band_levels: -1 automatic; 0 never; n: n slots per image (lqrhip_set_band_levels)
 // -1: by batch size (g_tiled_update_px); 0: band kernel (k_band_update_tw); 1: tiled full-width update whenever its
@@ -1322,7 +1322,7 @@ static int seam_step_impl(LqrHipBatch *b, const LqrHipDpParams *p, int w, int h,
     }
     // Single images and groups up to 4: the carve and the energy update in one launch (k_carve_e, k_carve.hip) -- the wave that has moved
     // a row refreshes that row's energies; one dependent launch less per seam.  delta_x <= 2 (12 brightness samples per row).
-    const bool fuse_e = g_carve_fused && p->delta_x <= 2 && vp_group <= 4 && wnew > 1;
+    const bool fuse_e = p->delta_x <= 2 && vp_group <= (size_t) g_carve_fused && wnew > 1;
     if (fuse_e) {
         const int lag_max = n <= 4 ? FROZEN_LAG_MAX / 4 : FROZEN_LAG_MAX;
         if (log_index + 1 - c0->frozen_epoch > lag_max && (rc = frozen_catchup(b, log_index + 1, wnew, h))) return rc;      // (needs the seam log only: before the carve)

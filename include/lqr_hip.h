@@ -203,8 +203,9 @@ void lqrhip_prof_enable(int on);
 void lqrhip_set_update_mode(int mode);
 /* Test hook: threads of the k_dp_sweep<UPDATE> launch behind the band kernels: 256 (default) or 1024 */
 void lqrhip_set_sweep_threads(int n);
-/* Test hook: 0 = never fuse the carve and the energy update (k_carve_e, groups up to 4 images with delta_x <= 2); default 1 */
-void lqrhip_set_carve_fused(int on);
+/* Test hook: the largest group that runs the carve and the energy update as one launch (k_carve_e, delta_x <= 2): 0 = never, 1 = the
+ * default (4), n = groups up to n images */
+void lqrhip_set_carve_fused(int max_images);
 /* E7 form: -1 = the parallel two-kernel backtrack (k_vp_maps / k_vp_solve) for groups of up to par_max images (default 2; 0 keeps the
  * current value) of 1000 rows and more, the one-wave walk k_vpath1 otherwise; 0 = k_vpath1 always; 1 = the parallel form
  * always (delta_x 1 .. 4) */

@@ -15,4 +15,6 @@ run parity_plain    env FUZZ_COUNT=600 python scripts/fuzz_parity.py 0 60607
 run parity_general  env FUZZ_COUNT=400 python scripts/fuzz_parity.py 0 60608 0 general
 run general_poison  env FUZZ_COUNT=200 LQRHIP_POISON=r3 python scripts/fuzz_parity.py 0 60609 0 general
 run interactive     env FUZZ_COUNT=1000 python scripts/fuzz_interactive.py 0 60610
+run parity_vp       env FUZZ_COUNT=400 LQR_VP=1 python scripts/fuzz_parity.py 0 60611             # the parallel backtrack forced for every case
+run parity_extras   env FUZZ_COUNT=400 FUZZ_EXTRAS=1 python scripts/fuzz_parity.py 0 60612        # the plug-in's other switches
 date >> $L/summary.txt
