@@ -70,7 +70,9 @@ struct LqrHipBatch {
     bool shared = false;                    // other batches of the same group run concurrently on their own streams:
                                             // no persistent (spin-waiting, co-residency-dependent) kernels
     bool safe = false;                      // a session is being redone after a fault: kernels without spin waits only
+    void *pending_inflate = nullptr;        // lqrhip_inflate's staged planes, until lqrhip_inflate_commit adopts them (PendingInflate)
 };
+static void discard_pending(LqrHipBatch *b);
 static bool g_no_spin = false;             // set by a spin time-out (check_dev_error): the process stays on the non-spinning kernels
 static inline bool no_spin(const LqrHipBatch *b) { return b->safe || g_no_spin; }
 
@@ -730,6 +732,7 @@ extern "C" void lqrhip_batch_abort(LqrHipBatch *b)
     if (!b) return;
     (void) hipStreamSynchronize(b->stream);
     (void) hipGetLastError();
+    discard_pending(b);
     if (g_dev_err_host) *g_dev_err_host = 0;
     invalidate_all_batches();
 }
@@ -739,6 +742,7 @@ extern "C" void lqrhip_batch_destroy(LqrHipBatch *b)
     if (!b) return;
     g_live_batches.erase(std::remove(g_live_batches.begin(), g_live_batches.end(), b), g_live_batches.end());
     if (b->stream) { (void) hipStreamSynchronize(b->stream); (void) hipStreamDestroy(b->stream); }
+    discard_pending(b);
     dfree(b->exch);
     for (auto *c : b->cs) if (c->batch == b) c->batch = nullptr;
     if (b->d_desc) (void) hipFree(b->d_desc);
@@ -1486,6 +1490,7 @@ extern "C" int lqrhip_session_check(LqrHipBatch *b, int h, int wc0, int n_seams,
 extern "C" int lqrhip_session_rollback(LqrHipBatch *b, int w0, int h0, int first_level, int finish)
 {
     (void) hipStreamSynchronize(b->stream);
+    discard_pending(b);
     (void) hipGetLastError();
     if (g_dev_err_host) *g_dev_err_host = 0;
     invalidate_all_batches();
@@ -1517,6 +1522,7 @@ static void inject_after_step(LqrHipBatch *b, int h, int log_index)
 static void inject_after_commit(LqrHipBatch *b, int w0, int h0, int first_level)
 {
     if (g_inject_times <= 0 || (g_inject_kind != 5 && g_inject_kind != 6)) return;
+    if (g_inject_step > 0) { g_inject_step--; return; }          // (kinds 5 / 6: at_step = how many commits to let pass first -- the second sub-batch of a group)
     hipLaunchKernelGGL(k_inject, dim3(1), dim3(64), 0, b->stream, b->d_desc, g_inject_kind - 3, h0, w0, 0, first_level);
     g_inject_times--; g_fault_stats[5]++;
 }
@@ -1573,27 +1579,48 @@ struct PlaneJobs {
     }
 };
 
+// Two phases (round 6): lqrhip_inflate stages the inflated planes of the batch, runs the pass and its fused self-check, and ADOPTS NOTHING;
+// lqrhip_inflate_commit adopts what was staged.  The host runs phase one on every sub-batch of a group before it commits any: a
+// failed check in sub-batch k must not find sub-batches 0 .. k - 1 already living in their inflated layouts (the roll-back restores
+// the whole group).  lqrhip_session_rollback / lqrhip_batch_abort / lqrhip_batch_destroy discard a staged pass.
+struct PendingInflate { PlaneJobs pj; int w1 = 0; };
+static void discard_pending(LqrHipBatch *b) { delete (PendingInflate *) b->pending_inflate; b->pending_inflate = nullptr; }
 extern "C" int lqrhip_inflate(LqrHipBatch *b, int w0, int h0, int l, int max_level)
 {
     int rc;
     const int w1 = w0 + l - max_level + 1;
-    PlaneJobs pj;
-    for (auto *c : b->cs) {
-        int32_t *nvs = nullptr;
-        if ((rc = dmalloc(&nvs, (size_t) w1 * h0))) return rc;
-        pj.new_vs.push_back(nvs);
-        for (auto *a : c->aux)
-            if ((rc = pj.add(a, c->vs, nullptr, (size_t) w1 * h0))) return rc;
-        if ((rc = pj.add(c, c->vs, nvs, (size_t) w1 * h0))) return rc;
-    }
-    if ((rc = pj.upload(b->stream))) return rc;
-    const size_t lds = (size_t) ((l - max_level + 1 + 31) / 32 + 1) * sizeof(unsigned);      // one bit per level of the session (the fused self-check)
-    hipLaunchKernelGGL(k_inflate, dim3(h0, (unsigned) pj.dev.size()), dim3(256), lds, b->stream, pj.d_jobs, w0, w1, l, max_level, g_selfcheck ? g_dev_err : (int *) nullptr);
-    HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(b->stream));
-    if ((rc = check_dev_error())) return rc;        // nothing adopted: the staged planes go back to the pool, the host rolls the session back
+    discard_pending(b);
+    PendingInflate *pi = new PendingInflate();
+    b->pending_inflate = pi;                // owned by the batch from here on, whatever happens below
+    PlaneJobs &pj = pi->pj;
+    pi->w1 = w1;
+    auto run = [&]() -> int {
+        for (auto *c : b->cs) {
+            int32_t *nvs = nullptr;
+            if ((rc = dmalloc(&nvs, (size_t) w1 * h0))) return rc;
+            pj.new_vs.push_back(nvs);
+            for (auto *a : c->aux)
+                if ((rc = pj.add(a, c->vs, nullptr, (size_t) w1 * h0))) return rc;
+            if ((rc = pj.add(c, c->vs, nvs, (size_t) w1 * h0))) return rc;
+        }
+        if ((rc = pj.upload(b->stream))) return rc;
+        const size_t lds = (size_t) ((l - max_level + 1 + 31) / 32 + 1) * sizeof(unsigned);      // one bit per level of the session (the fused self-check)
+        hipLaunchKernelGGL(k_inflate, dim3(h0, (unsigned) pj.dev.size()), dim3(256), lds, b->stream, pj.d_jobs, w0, w1, l, max_level, g_selfcheck ? g_dev_err : (int *) nullptr);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(b->stream));
+        return check_dev_error();           // a failed level check: nothing is adopted, the host rolls the session back
+    };
+    rc = run();
+    if (rc) { (void) hipStreamSynchronize(b->stream); discard_pending(b); }
+    return rc;
+}
+extern "C" int lqrhip_inflate_commit(LqrHipBatch *b)
+{
+    PendingInflate *pi = (PendingInflate *) b->pending_inflate;
+    if (!pi) return LQRHIP_EARG;
+    PlaneJobs &pj = pi->pj;
     pj.commit();
-    for (auto &j : pj.jobs) j.c->w0 = w1;
+    for (auto &j : pj.jobs) j.c->w0 = pi->w1;
     size_t i = 0;
     for (auto *c : b->cs) {
         dfree(c->vs);
@@ -1601,6 +1628,7 @@ extern "C" int lqrhip_inflate(LqrHipBatch *b, int w0, int h0, int l, int max_lev
         for (auto *a : c->aux) a->vs = c->vs;
     }
     b->dirty = true;
+    discard_pending(b);                     // (committed: the destructor frees only the job table)
     return 0;
 }
 

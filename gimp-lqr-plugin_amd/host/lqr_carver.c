@@ -531,7 +531,8 @@ static LqrRetVal group_build_vsmap(Group *g, int depth, int *reported)
     HIP_ALL(g, lqrhip_batch_sync(B));
     HIP_ALL(g, lqrhip_vs_commit(B, r0->w0, r0->h0, wc0, n_seams, first_level, finish));
     /* inflate (E14): every seam of this session is doubled in the base layout */
-    HIP_ALL(g, lqrhip_inflate(B, r0->w0, r0->h0, depth - 1, r0->max_level));
+    HIP_ALL(g, lqrhip_inflate(B, r0->w0, r0->h0, depth - 1, r0->max_level));        /* every sub-batch staged and checked ... */
+    HIP_ALL(g, lqrhip_inflate_commit(B));                                           /* ... before any adopts its inflated layout */
     w1 = r0->w0 + (depth - 1) - r0->max_level + 1;
     FOR_TREE(g, i, r, {
         r->level = depth; r->max_level = depth;

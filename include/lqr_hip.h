@@ -152,10 +152,13 @@ int lqrhip_get_no_spin(void);
 int lqrhip_fault_stats(unsigned long long *out8, int reset);
 /* Test hook: provoke a fault in the next session(s).  kind 1 spin time-out / 2 failed prediction (the error word is written while
  * the kernels of seam step at_step run), 3 / 4 a seam-log entry out of the frame / disconnected, 5 / 6 a committed level cleared /
- * duplicated; times = sessions hit in a row; kind 0 disarms. */
+ * duplicated (at_step = commits to let pass first: a later sub-batch of a group); times = sessions hit in a row; kind 0 disarms. */
 void lqrhip_debug_inject(int kind, int at_step, int times);
-/* E14 lqr_carver_inflate(l) on roots and their attached carvers */
+/* E14 lqr_carver_inflate(l) on roots and their attached carvers, in two phases: lqrhip_inflate stages the inflated planes, runs the pass
+ * and its self-check (LQRHIP_EFAULT: nothing was staged); lqrhip_inflate_commit adopts them.  A group commits only after every one of its
+ * sub-batches has passed phase one. */
 int lqrhip_inflate(LqrHipBatch *b, int w0, int h0, int l, int max_level);
+int lqrhip_inflate_commit(LqrHipBatch *b);
 /* E11 lqr_carver_flatten (render.c:325,636): keep pixels visible at `level` */
 int lqrhip_flatten(LqrHipBatch *b, int w0, int h0, int w, int level);
 /* E11 lqr_carver_transpose: base planes of a flat carver, w x h -> h x w */

@@ -57,7 +57,7 @@ def test_an_injected_fault_is_recovered_from_and_the_result_is_exact(oracle, eng
     }[case]
     ref = H.run_case(oracle, img, nw, nh, progress=True, **kw)
     stats(lib, reset=True)
-    lib.lqrhip_debug_inject(kind, 7, 1)                 # the fault falls into seam step 7 of the first session that has one
+    lib.lqrhip_debug_inject(kind, 7 if kind < 5 else 0, 1)                 # the fault falls into seam step 7 of the first session that has one (5 / 6: the first commit)
     got = H.run_case(engine, img, nw, nh, progress=True, **kw)
     s = stats(lib)
     lib.lqrhip_set_no_spin(0)
@@ -76,7 +76,7 @@ def test_a_fault_in_a_lock_step_batch_is_recovered_from(oracle, engine, lib, kin
     lib.lqrhip_set_update_mode(mode)
     cs = [L.Carver(engine, im).configure() for im in imgs]
     stats(lib, reset=True)
-    lib.lqrhip_debug_inject(kind, 11, 1)
+    lib.lqrhip_debug_inject(kind, 11 if kind < 5 else 0, 1)
     assert L.resize_batch(engine, cs, w - 31, h - 9) == L.LQR_OK
     s = stats(lib)
     lib.lqrhip_set_no_spin(0)
@@ -98,7 +98,7 @@ def test_without_recovery_the_carver_is_as_before_and_the_next_resize_is_exact(o
     if not twice:
         lib.lqrhip_set_recovery(0)
     c, _ = H.init_carver(engine, img, 260, 140)
-    lib.lqrhip_debug_inject(kind, 5, 2 if twice else 1)
+    lib.lqrhip_debug_inject(kind, 5 if kind < 5 else 0, 2 if twice else 1)
     assert c.resize(260, 140) == L.LQR_ERROR
     lib.lqrhip_debug_inject(0, 0, 0); lib.lqrhip_set_no_spin(0); lib.lqrhip_set_recovery(1)
     g = c.getters()
@@ -182,3 +182,24 @@ def test_the_self_checks_can_be_switched_off(oracle, engine, lib):
     got = H.run_case(engine, img, 260, 160)
     lib.lqrhip_set_selfcheck(1)
     assert got["ret"] == L.LQR_OK and not np.array_equal(got["vmap"]["data"], ref["vmap"]["data"])
+
+
+def test_a_failed_level_check_in_the_second_sub_batch_leaves_the_first_where_it_was(oracle, engine, lib):
+    """34 images on two sub-batch streams: the level check fails in the SECOND sub-batch's inflate pass.  No sub-batch adopts its inflated
+    layout before every one has passed (lqrhip_inflate stages, lqrhip_inflate_commit adopts): the whole group is rolled back and redone"""
+    lib.lqrhip_sub_batches.argtypes = [ctypes.c_int]
+    w, h, n = 520, 140, 34
+    if lib.lqrhip_sub_batches(n) < 2:
+        pytest.skip("this process has no hardware queues for sub-batch streams")
+    imgs = [D.photo_like(w, h, 500 + i) if i % 2 else D.noise(w, h, 500 + i) for i in range(n)]
+    cs = [L.Carver(engine, im).configure() for im in imgs]
+    stats(lib, reset=True)
+    lib.lqrhip_debug_inject(5, 1, 1)              # let the first sub-batch's commit pass
+    assert L.resize_batch(engine, cs, w - 31, h) == L.LQR_OK
+    s = stats(lib)
+    assert s["injected"] == 1 and s["levels"] == 1 and s["rolled_back"] == 2 and s["redone"] == 2, s
+    for c, im in zip(cs, imgs):
+        ref = H.run_case(oracle, im, w - 31, h)
+        assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"]) and np.array_equal(c.read_image(), ref["image"])
+    for c in cs:
+        c.destroy()
