@@ -302,9 +302,13 @@ static int pool_poison(void *p, size_t sz)
     return 0;
 }
 
+// fault injection (tests/test_faults_gpu.py): the nth device allocation from now on fails with "out of memory", once (-1: disarmed)
+static long g_fail_alloc_in = -1;
+extern "C" void lqrhip_debug_fail_alloc(int nth) { g_fail_alloc_in = nth; }
 static int pool_alloc(void **p, size_t bytes)
 {
     const size_t sz = (bytes + ((size_t) 1 << 20) - 1) & ~(((size_t) 1 << 20) - 1);      // 1 MiB classes
+    if (g_fail_alloc_in >= 0 && g_fail_alloc_in-- == 0) { *p = nullptr; g_err = std::string("injected allocation failure (") + (g_alloc_name ? g_alloc_name : "?") + ")"; return LQRHIP_ENOMEM; }
     auto it = g_pool_free.find(sz);
     if (it != g_pool_free.end()) {
         *p = it->second;
@@ -810,7 +814,7 @@ struct ProfScope {
 
 extern "C" void lqrhip_prof_enable(int on) { g_prof = on; }
 static int g_vpath_mode = -1;            // -1: the parallel backtrack for groups up to g_vpath_par_max images of at least g_vpath_min_rows rows; 0: never; 1: always (delta_x 1 .. 4)
-static int g_vpath_par_max = 2, g_vpath_min_rows = 1000;
+static int g_vpath_par_max = 3, g_vpath_min_rows = 1000;     // (3 x 4K: 58 -> 46 us per seam; 4: equal; 8: slower -- the maps of n images are n times the work)
 extern "C" void lqrhip_set_vpath_mode(int mode, int par_max) { g_vpath_mode = mode; if (par_max > 0) g_vpath_par_max = par_max; }
 static int g_sweep_threads = 256;        // threads of the k_dp_sweep<UPDATE> launch behind the band kernels (256, or 1024 as in rounds 1 - 5)
 extern "C" void lqrhip_set_sweep_threads(int n) { g_sweep_threads = n == 256 ? 256 : DP_THREADS; }
@@ -1015,7 +1019,7 @@ static int launch_dp_persistent(LqrHipBatch *b, const DpK &k, int w, int h, int 
             const size_t pe = (size_t) c->stride * (c->wk_h + 1) + 1024;
             const bool fresh_m2 = !c->m2, fresh_l2 = !c->least2;
             if (!c->m2 && (rc = dmalloc(&c->m2, pe))) return rc;
-            if (!c->least2 && (rc = dmalloc(&c->least2, pe))) return rc;
+            if (!c->least2 && (rc = dmalloc(&c->least2, pe))) { if (fresh_m2) dfree(c->m2); return rc; }     // (an m2 that was never zeroed must not pass for an old one)
             // like the first planes (ensure_working): nothing in them depends on what the block held before
             if (fresh_m2) HIPCK(hipMemsetAsync(c->m2, 0, pe * sizeof(float), b->stream));
             if (fresh_l2) HIPCK(hipMemsetAsync(c->least2, 0, pe, b->stream));

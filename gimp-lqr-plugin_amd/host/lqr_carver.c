@@ -580,7 +580,8 @@ static LqrRetVal group_build_maps(Group *g, int depth)
         const int wc0 = r0->w_start - r0->max_level + 1, n_seams = (depth ? depth : r0->w_start + 1) - r0->max_level;
         /* the carver as it was before the session: the base layout (levels of this session removed if they were committed),
          * the bookkeeping; the working planes are gone */
-        if (fault)
+        /* (also after an allocation failure: the staging of the inflate pass comes after the commit of the session's levels) */
+        if (fault || g_last_rc == LQRHIP_ENOMEM)
             for (i = 0; i < g->nb; i++) (void) lqrhip_session_rollback(g->b[i], r0->w0, r0->h0, 2 * r0->max_level - 1, wc0 - n_seams <= 1);
         for (i = 0; i < g->n; i++) {
             LqrCarver *c = g->r[i];

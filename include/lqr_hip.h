@@ -154,6 +154,9 @@ int lqrhip_fault_stats(unsigned long long *out8, int reset);
  * the kernels of seam step at_step run), 3 / 4 a seam-log entry out of the frame / disconnected, 5 / 6 a committed level cleared /
  * duplicated (at_step = commits to let pass first: a later sub-batch of a group); times = sessions hit in a row; kind 0 disarms. */
 void lqrhip_debug_inject(int kind, int at_step, int times);
+/* Test hook: the nth device allocation from now on (0 = the next one) fails once with LQRHIP_ENOMEM; -1 disarms.  What the host side
+ * owes its caller then: LQR_NOMEM (the one value src/render.c:42-46 tests for) and a carver that is still consistent. */
+void lqrhip_debug_fail_alloc(int nth);
 /* E14 lqr_carver_inflate(l) on roots and their attached carvers, in two phases: lqrhip_inflate stages the inflated planes, runs the pass
  * and its self-check (LQRHIP_EFAULT: nothing was staged); lqrhip_inflate_commit adopts them.  A group commits only after every one of its
  * sub-batches has passed phase one. */
@@ -209,7 +212,7 @@ void lqrhip_set_sweep_threads(int n);
 /* Test hook: the largest group that runs the carve and the energy update as one launch (k_carve_e, delta_x <= 2): 0 = never, 1 = the
  * default (4), n = groups up to n images */
 void lqrhip_set_carve_fused(int max_images);
-/* E7 form: -1 = the parallel two-kernel backtrack (k_vp_maps / k_vp_solve) for groups of up to par_max images (default 2; 0 keeps the
+/* E7 form: -1 = the parallel two-kernel backtrack (k_vp_maps / k_vp_solve) for groups of up to par_max images (default 3; 0 keeps the
  * current value) of 1000 rows and more, the one-wave walk k_vpath1 otherwise; 0 = k_vpath1 always; 1 = the parallel form
  * always (delta_x 1 .. 4) */
 void lqrhip_set_vpath_mode(int mode, int par_max);

@@ -31,7 +31,9 @@ def lib(engine):
     for f in ("lqrhip_set_recovery", "lqrhip_set_no_spin", "lqrhip_set_selfcheck", "lqrhip_set_update_mode", "lqrhip_set_band_levels"):
         getattr(lb, f).argtypes = [ctypes.c_int]
     lb.lqrhip_get_no_spin.restype = ctypes.c_int
+    lb.lqrhip_debug_fail_alloc.argtypes = [ctypes.c_int]
     yield lb
+    lb.lqrhip_debug_fail_alloc(-1)
     lb.lqrhip_debug_inject(0, 0, 0); lb.lqrhip_set_recovery(1); lb.lqrhip_set_no_spin(0); lb.lqrhip_set_selfcheck(1)
     lb.lqrhip_set_update_mode(-1); lb.lqrhip_set_band_levels(-1)
 
@@ -203,3 +205,76 @@ def test_a_failed_level_check_in_the_second_sub_batch_leaves_the_first_where_it_
         assert np.array_equal(c.vmap_dump()["data"], ref["vmap"]["data"]) and np.array_equal(c.read_image(), ref["image"])
     for c in cs:
         c.destroy()
+
+
+@pytest.mark.parametrize("case", ["shrink-both-directions", "shrink-3-images", "enlarge-in-steps", "masks-delta2", "deeper-session"])
+def test_an_allocation_failure_anywhere_in_a_resize_leaves_consistent_carvers(oracle, engine, lib, case):
+    """lqrhip_debug_fail_alloc(n): the nth device allocation of the resize fails, once -- for every n until the resize gets through
+    (working planes, seam log, exchange areas, backtrack maps, the staging of the inflate pass AFTER the session's levels are
+    committed, flatten, transpose, the second direction ...).  Each time: LQR_NOMEM -- the one value the plug-in tests for
+    (src/render.c:42-46) -- and every carver still serves a consistent image: one of the states the genuine sequence passes through
+    (the original, the first direction's / the first enlargement step's result); asked again, the resize finishes exactly."""
+    w, h, nw, nh, n_images, kw, n_states, pre = {
+        "shrink-both-directions": (200, 120, 170, 100, 1, {}, 2, []),                       # the original, the first direction's result
+        "shrink-3-images": (200, 120, 170, 100, 3, {}, 2, []),
+        "enlarge-in-steps": (120, 90, 230, 90, 1, dict(enl_step=140.0), 2, []),             # the original, the first enlargement step's result
+        "masks-delta2": (220, 130, 190, 130, 1, dict(pres=D.ellipse_mask(220, 130), disc=D.band_mask(220, 130, 30, 55), rigmask=D.top_half_mask(220, 130),
+                                                     rigidity=6.0, delta_x=2), 1, []),
+        # an interactive-style carver (src/render.c:465-574): 200 -> 185 first, in a call of its own; the sweep runs over 185 -> 160, a deeper
+        # session of the multi-size image -- its levels are committed before the inflate pass is staged, and a stale level would be taken for a
+        # carved pixel by the next lay-out of the working planes (lqrhip_session_rollback after LQR_NOMEM as well)
+        "deeper-session": (200, 120, 160, 120, 1, {}, 1, [(185, 120)]),
+    }[case]
+    imgs = [D.photo_like(w, h, 91 + i) for i in range(n_images)]
+    states, final = [{} for im in imgs], []
+    start = pre[-1] if pre else (w, h)
+
+    def oracle_at(i, size):
+        co, _ = H.init_carver(oracle, imgs[i], nw, nh, **kw)
+        for ps in pre:
+            assert co.resize(*ps) == L.LQR_OK
+        if size != start:
+            assert co.resize(*size) == L.LQR_OK
+        return co
+    for i in range(n_images):
+        co = oracle_at(i, (nw, nh))
+        final.append((co.read_image(), co.vmap_dump()["data"]))
+        co.destroy()
+
+    def state(i, size):     # what the genuine sequence holds at that size (one call from the start: the same sessions)
+        if size not in states[i]:
+            co = oracle_at(i, size)
+            states[i][size] = co.read_image()
+            co.destroy()
+        return states[i][size]
+    resize = lambda cs, size=(nw, nh): cs[0].resize(*size) if n_images == 1 else L.resize_batch(engine, cs, *size)
+    failures, seen = 0, set()
+    for n in range(600):
+        cs = [H.init_carver(engine, im, nw, nh, **kw)[0] for im in imgs]
+        for ps in pre:
+            assert resize(cs, ps) == L.LQR_OK
+        lib.lqrhip_debug_fail_alloc(n)
+        ret = resize(cs)
+        lib.lqrhip_debug_fail_alloc(-1)
+        if ret == L.LQR_OK:
+            for c, (fi, fv) in zip(cs, final):
+                assert np.array_equal(c.read_image(), fi) and np.array_equal(c.vmap_dump()["data"], fv), n
+                c.destroy()
+            break
+        assert ret == L.LQR_NOMEM, (n, ret)
+        failures += 1
+        sizes = set()
+        for i, c in enumerate(cs):
+            g = c.getters()
+            sizes.add((g["width"], g["height"]))
+            assert np.array_equal(c.read_image(), state(i, (g["width"], g["height"]))), (n, g)
+        assert len(sizes) == 1, (n, sizes)          # a lock-step group fails as one
+        seen |= sizes
+        assert resize(cs) == L.LQR_OK, n
+        for c, (fi, fv) in zip(cs, final):
+            assert np.array_equal(c.read_image(), fi) and np.array_equal(c.vmap_dump()["data"], fv), n
+            c.destroy()
+    else:
+        pytest.fail("the resize never got through")
+    print("allocation sweep %s: %d failure points, states seen %s" % (case, failures, sorted(seen)))
+    assert failures >= 3 and len(seen) == n_states, (failures, seen)      # the sweep walked through the allocations of every stage

@@ -1,4 +1,4 @@
-"""Round 6 (-m gpu): the parallel backtrack (k_vp_maps / k_vp_solve, csrc/k_backtrack.hip) -- the engine's choice for one or two images of
+"""Round 6 (-m gpu): the parallel backtrack (k_vp_maps / k_vp_solve, csrc/k_backtrack.hip) -- the engine's choice for one to three images of
 1000 rows and more -- against the oracle and against the one-wave walk k_vpath1 it replaces there: shapes around the chunk size
 (56 / delta_x rows), the 256-column tiles of the map kernel and the stage length of the solver (20 chunks); delta_x 1 .. 4; both
 directions; groups; the moved-bytes accounting."""
