@@ -70,7 +70,7 @@ struct LqrHipBatch {
     bool shared = false;                    // other batches of the same group run concurrently on their own streams:
                                             // no persistent (spin-waiting, co-residency-dependent) kernels
     bool safe = false;                      // a session is being redone after a fault: kernels without spin waits only
-    void *pending_inflate = nullptr;        // lqrhip_inflate's staged planes, until lqrhip_inflate_commit adopts them (PendingInflate)
+    void *pending_inflate = nullptr;        // the staged planes of lqrhip_inflate / _flatten / _transpose, until lqrhip_planes_commit adopts them (PendingInflate)
 };
 static void discard_pending(LqrHipBatch *b);
 static bool g_no_spin = false;             // set by a spin time-out (check_dev_error): the process stays on the non-spinning kernels
@@ -1583,21 +1583,26 @@ struct PlaneJobs {
     }
 };
 
-// Two phases (round 6): lqrhip_inflate stages the inflated planes of the batch, runs the pass and its fused self-check, and ADOPTS NOTHING;
-// lqrhip_inflate_commit adopts what was staged.  The host runs phase one on every sub-batch of a group before it commits any: a
-// failed check in sub-batch k must not find sub-batches 0 .. k - 1 already living in their inflated layouts (the roll-back restores
-// the whole group).  lqrhip_session_rollback / lqrhip_batch_abort / lqrhip_batch_destroy discard a staged pass.
-struct PendingInflate { PlaneJobs pj; int w1 = 0; };
+// Two phases (round 6): lqrhip_inflate / lqrhip_flatten / lqrhip_transpose stage the new planes of the batch, run the pass (the inflate
+// pass with its fused self-check) and ADOPT NOTHING; lqrhip_planes_commit adopts what was staged.  The host runs phase one on every
+// sub-batch of a group before it commits any: a failed check or a failed allocation in sub-batch k must not find sub-batches 0 .. k - 1
+// already living in their new layouts (the roll-back / the error return leaves the whole group where it was).
+// lqrhip_session_rollback / lqrhip_batch_abort / lqrhip_batch_destroy discard a staged pass.
+struct PendingInflate { PlaneJobs pj; int kind = 0 /* 0 inflate, 1 flatten, 2 transpose */, w1 = 0, h1 = 0; };
 static void discard_pending(LqrHipBatch *b) { delete (PendingInflate *) b->pending_inflate; b->pending_inflate = nullptr; }
+static PendingInflate *new_pending(LqrHipBatch *b, int kind, int w1, int h1)
+{
+    discard_pending(b);
+    PendingInflate *pi = new PendingInflate();
+    b->pending_inflate = pi;                // owned by the batch from here on, whatever happens below
+    pi->kind = kind; pi->w1 = w1; pi->h1 = h1;
+    return pi;
+}
 extern "C" int lqrhip_inflate(LqrHipBatch *b, int w0, int h0, int l, int max_level)
 {
     int rc;
     const int w1 = w0 + l - max_level + 1;
-    discard_pending(b);
-    PendingInflate *pi = new PendingInflate();
-    b->pending_inflate = pi;                // owned by the batch from here on, whatever happens below
-    PlaneJobs &pj = pi->pj;
-    pi->w1 = w1;
+    PlaneJobs &pj = new_pending(b, 0, w1, h0)->pj;
     auto run = [&]() -> int {
         for (auto *c : b->cs) {
             int32_t *nvs = nullptr;
@@ -1618,71 +1623,72 @@ extern "C" int lqrhip_inflate(LqrHipBatch *b, int w0, int h0, int l, int max_lev
     if (rc) { (void) hipStreamSynchronize(b->stream); discard_pending(b); }
     return rc;
 }
-extern "C" int lqrhip_inflate_commit(LqrHipBatch *b)
+extern "C" int lqrhip_planes_commit(LqrHipBatch *b)
 {
     PendingInflate *pi = (PendingInflate *) b->pending_inflate;
     if (!pi) return LQRHIP_EARG;
     PlaneJobs &pj = pi->pj;
     pj.commit();
-    for (auto &j : pj.jobs) j.c->w0 = pi->w1;
-    size_t i = 0;
-    for (auto *c : b->cs) {
-        dfree(c->vs);
-        c->vs = pj.new_vs[i++];
-        for (auto *a : c->aux) a->vs = c->vs;
+    for (auto &j : pj.jobs) { j.c->w0 = pi->w1; j.c->h0 = pi->h1; }
+    if (pi->kind != 2) {                    // (a transpose keeps the carvers' -- all zero -- visibility maps)
+        size_t i = 0;
+        for (auto *c : b->cs) {
+            dfree(c->vs);
+            c->vs = pj.new_vs[i++];
+            for (auto *a : c->aux) a->vs = c->vs;
+        }
     }
     b->dirty = true;
     discard_pending(b);                     // (committed: the destructor frees only the job table)
     return 0;
 }
+extern "C" int lqrhip_inflate_commit(LqrHipBatch *b) { return lqrhip_planes_commit(b); }
 
 extern "C" int lqrhip_flatten(LqrHipBatch *b, int w0, int h0, int w, int level)
 {
     int rc;
-    PlaneJobs pj;
-    for (auto *c : b->cs) {
-        int32_t *nvs = nullptr;                 // the flat carver's visibility map: all zero
-        if ((rc = dmalloc(&nvs, (size_t) w * h0))) return rc;
-        pj.new_vs.push_back(nvs);
-        HIPCK(hipMemsetAsync(nvs, 0, (size_t) w * h0 * sizeof(int32_t), b->stream));
-        for (auto *a : c->aux)
-            if ((rc = pj.add(a, c->vs, nullptr, (size_t) w * h0))) return rc;
-        if ((rc = pj.add(c, c->vs, nullptr, (size_t) w * h0))) return rc;
-    }
-    if ((rc = pj.upload(b->stream))) return rc;
-    hipLaunchKernelGGL(k_compact_jobs, dim3(h0, (unsigned) pj.dev.size()), dim3(256), 0, b->stream, pj.d_jobs, w0, w, level);
-    HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(b->stream));
-    pj.commit();
-    for (auto &j : pj.jobs) j.c->w0 = w;
-    size_t i = 0;
-    for (auto *c : b->cs) {
-        dfree(c->vs);
-        c->vs = pj.new_vs[i++];
-        for (auto *a : c->aux) a->vs = c->vs;
-    }
-    b->dirty = true;
-    return 0;
+    PlaneJobs &pj = new_pending(b, 1, w, h0)->pj;
+    auto run = [&]() -> int {
+        for (auto *c : b->cs) {
+            int32_t *nvs = nullptr;                 // the flat carver's visibility map: all zero
+            if ((rc = dmalloc(&nvs, (size_t) w * h0))) return rc;
+            pj.new_vs.push_back(nvs);
+            HIPCK(hipMemsetAsync(nvs, 0, (size_t) w * h0 * sizeof(int32_t), b->stream));
+            for (auto *a : c->aux)
+                if ((rc = pj.add(a, c->vs, nullptr, (size_t) w * h0))) return rc;
+            if ((rc = pj.add(c, c->vs, nullptr, (size_t) w * h0))) return rc;
+        }
+        if ((rc = pj.upload(b->stream))) return rc;
+        hipLaunchKernelGGL(k_compact_jobs, dim3(h0, (unsigned) pj.dev.size()), dim3(256), 0, b->stream, pj.d_jobs, w0, w, level);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(b->stream));
+        return 0;
+    };
+    rc = run();
+    if (rc) { (void) hipStreamSynchronize(b->stream); discard_pending(b); }
+    return rc;
 }
 
 extern "C" int lqrhip_transpose(LqrHipBatch *b, int w, int h)
 {
     int rc;
-    PlaneJobs pj;
-    for (auto *c : b->cs) {
-        for (auto *a : c->aux)
-            if ((rc = pj.add(a, nullptr, nullptr, (size_t) w * h))) return rc;
-        if ((rc = pj.add(c, nullptr, nullptr, (size_t) w * h))) return rc;
-        HIPCK(hipMemsetAsync(c->vs, 0, (size_t) w * h * sizeof(int32_t), b->stream));   // flat carver: all zero already
-    }
-    if ((rc = pj.upload(b->stream))) return rc;
-    hipLaunchKernelGGL(k_transpose, dim3((w + 31) / 32, (h + 31) / 32, (unsigned) pj.dev.size()), dim3(32, 8), 0, b->stream, pj.d_jobs, w, h);
-    HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(b->stream));
-    pj.commit();
-    for (auto &j : pj.jobs) { j.c->w0 = h; j.c->h0 = w; }
-    b->dirty = true;
-    return 0;
+    PlaneJobs &pj = new_pending(b, 2, h, w)->pj;
+    auto run = [&]() -> int {
+        for (auto *c : b->cs) {
+            for (auto *a : c->aux)
+                if ((rc = pj.add(a, nullptr, nullptr, (size_t) w * h))) return rc;
+            if ((rc = pj.add(c, nullptr, nullptr, (size_t) w * h))) return rc;
+            HIPCK(hipMemsetAsync(c->vs, 0, (size_t) w * h * sizeof(int32_t), b->stream));   // flat carver: all zero already
+        }
+        if ((rc = pj.upload(b->stream))) return rc;
+        hipLaunchKernelGGL(k_transpose, dim3((w + 31) / 32, (h + 31) / 32, (unsigned) pj.dev.size()), dim3(32, 8), 0, b->stream, pj.d_jobs, w, h);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(b->stream));
+        return 0;
+    };
+    rc = run();
+    if (rc) { (void) hipStreamSynchronize(b->stream); discard_pending(b); }
+    return rc;
 }
 
 // ---- read-back ---------------------------------------------------------------

@@ -398,8 +398,10 @@ static LqrRetVal group_flatten(Group *g)
     int i;
     /* a carver that is already flat (nothing hidden, nothing inserted) is its own flattening */
     if (!(r0->w == r0->w0 && r0->level == 1 && r0->max_level == 1 && r0->w_start == r0->w0))
-        HIP_ALL(g, lqrhip_flatten(B, r0->w0, r0->h0, r0->w, r0->level));
-    else if (r0->wk_valid)
+    {
+        HIP_ALL(g, lqrhip_flatten(B, r0->w0, r0->h0, r0->w, r0->level));     /* every sub-batch staged ... */
+        HIP_ALL(g, lqrhip_planes_commit(B));                                 /* ... before any adopts its flat layout */
+    } else if (r0->wk_valid)
         return LQR_OK;
     FOR_TREE(g, i, r, {
         r->w0 = r->w; r->h0 = r->h;
@@ -416,6 +418,7 @@ static LqrRetVal group_transpose(Group *g)
     int i, x, d;
     if (r0->level > 1 || r0->max_level > 1 || r0->w0 != r0->w) LQR_CATCH(group_flatten(g));
     HIP_ALL(g, lqrhip_transpose(B, r0->w0, r0->h0));
+    HIP_ALL(g, lqrhip_planes_commit(B));
     FOR_TREE(g, i, r, {
         d = r->w0; r->w0 = r->h0; r->h0 = d;
         r->w = r->w0; r->h = r->h0;
@@ -532,7 +535,7 @@ static LqrRetVal group_build_vsmap(Group *g, int depth, int *reported)
     HIP_ALL(g, lqrhip_vs_commit(B, r0->w0, r0->h0, wc0, n_seams, first_level, finish));
     /* inflate (E14): every seam of this session is doubled in the base layout */
     HIP_ALL(g, lqrhip_inflate(B, r0->w0, r0->h0, depth - 1, r0->max_level));        /* every sub-batch staged and checked ... */
-    HIP_ALL(g, lqrhip_inflate_commit(B));                                           /* ... before any adopts its inflated layout */
+    HIP_ALL(g, lqrhip_planes_commit(B));                                            /* ... before any adopts its inflated layout */
     w1 = r0->w0 + (depth - 1) - r0->max_level + 1;
     FOR_TREE(g, i, r, {
         r->level = depth; r->max_level = depth;

@@ -157,15 +157,18 @@ void lqrhip_debug_inject(int kind, int at_step, int times);
 /* Test hook: the nth device allocation from now on (0 = the next one) fails once with LQRHIP_ENOMEM; -1 disarms.  What the host side
  * owes its caller then: LQR_NOMEM (the one value src/render.c:42-46 tests for) and a carver that is still consistent. */
 void lqrhip_debug_fail_alloc(int nth);
-/* E14 lqr_carver_inflate(l) on roots and their attached carvers, in two phases: lqrhip_inflate stages the inflated planes, runs the pass
- * and its self-check (LQRHIP_EFAULT: nothing was staged); lqrhip_inflate_commit adopts them.  A group commits only after every one of its
- * sub-batches has passed phase one. */
+/* The three passes that replace a batch's base planes run in TWO PHASES: the call stages the new planes and runs the pass -- nothing of
+ * the carvers changes -- and lqrhip_planes_commit adopts what was staged.  A group commits only after every one of its sub-batches has
+ * passed phase one, so that a failed self-check (LQRHIP_EFAULT) or a failed allocation (LQRHIP_ENOMEM) in one sub-batch leaves the
+ * whole group where it was.  A staged pass is discarded by the next staging call, lqrhip_session_rollback, _batch_abort, _batch_destroy.
+ * E14 lqr_carver_inflate(l) on roots and their attached carvers; carries the session's second self-check */
 int lqrhip_inflate(LqrHipBatch *b, int w0, int h0, int l, int max_level);
-int lqrhip_inflate_commit(LqrHipBatch *b);
 /* E11 lqr_carver_flatten (render.c:325,636): keep pixels visible at `level` */
 int lqrhip_flatten(LqrHipBatch *b, int w0, int h0, int w, int level);
 /* E11 lqr_carver_transpose: base planes of a flat carver, w x h -> h x w */
 int lqrhip_transpose(LqrHipBatch *b, int w, int h);
+int lqrhip_planes_commit(LqrHipBatch *b);
+int lqrhip_inflate_commit(LqrHipBatch *b);      /* = lqrhip_planes_commit */
 
 /* -- read-back (blocking) --------------------------------------------------- */
 /* E12 scan_line source: the pixels visible at `level`, packed w x h x channels

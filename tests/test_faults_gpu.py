@@ -207,7 +207,7 @@ def test_a_failed_level_check_in_the_second_sub_batch_leaves_the_first_where_it_
         c.destroy()
 
 
-@pytest.mark.parametrize("case", ["shrink-both-directions", "shrink-3-images", "enlarge-in-steps", "masks-delta2", "deeper-session"])
+@pytest.mark.parametrize("case", ["shrink-both-directions", "shrink-3-images", "enlarge-in-steps", "masks-delta2", "deeper-session", "shrink-34-images"])
 def test_an_allocation_failure_anywhere_in_a_resize_leaves_consistent_carvers(oracle, engine, lib, case):
     """lqrhip_debug_fail_alloc(n): the nth device allocation of the resize fails, once -- for every n until the resize gets through
     (working planes, seam log, exchange areas, backtrack maps, the staging of the inflate pass AFTER the session's levels are
@@ -224,7 +224,11 @@ def test_an_allocation_failure_anywhere_in_a_resize_leaves_consistent_carvers(or
         # session of the multi-size image -- its levels are committed before the inflate pass is staged, and a stale level would be taken for a
         # carved pixel by the next lay-out of the working planes (lqrhip_session_rollback after LQR_NOMEM as well)
         "deeper-session": (200, 120, 160, 120, 1, {}, 1, [(185, 120)]),
+        # two sub-batch streams where the process has the queues: flatten, transpose and inflate stage every sub-batch before any adopts its
+        # new planes (lqrhip_planes_commit), so a failure in the second leaves the first where it was; every 11th allocation point
+        "shrink-34-images": (120, 80, 104, 70, 34, {}, 2, []),
     }[case]
+    stride = 11 if n_images > 8 else 1
     imgs = [D.photo_like(w, h, 91 + i) for i in range(n_images)]
     states, final = [{} for im in imgs], []
     start = pre[-1] if pre else (w, h)
@@ -249,7 +253,7 @@ def test_an_allocation_failure_anywhere_in_a_resize_leaves_consistent_carvers(or
         return states[i][size]
     resize = lambda cs, size=(nw, nh): cs[0].resize(*size) if n_images == 1 else L.resize_batch(engine, cs, *size)
     failures, seen = 0, set()
-    for n in range(600):
+    for n in range(0, 6000, stride):
         cs = [H.init_carver(engine, im, nw, nh, **kw)[0] for im in imgs]
         for ps in pre:
             assert resize(cs, ps) == L.LQR_OK
