@@ -73,8 +73,12 @@ sys.path.insert(0, ROOT)
 # process, i.e. before torch is imported.  INTEGRATION.md says the same to a host application.
 # (The engine library sets it itself when it is loaded before the runtime is up -- `lqrhip_on_load` -- which is the case here too;
 # LQR_BENCH_NO_QUEUE_ENV=1 leaves it to the library, to show that.)
+# 16, not 8: under torch.distributed RCCL's communicator brings streams of its own into the process, and with 8 hardware queues the four
+# sub-batch streams then share queues with them -- measured at world size 1 under torchrun on one MI355X (round 6,
+# profiles/r06/q_queues_under_torchrun.txt): 400 k with 8 queues, 575 - 582 k with 12 / 16 / 24; without RCCL 8 and 16 measure the same
+# (578 / 576 k).
 if not os.environ.get("LQR_BENCH_NO_QUEUE_ENV"):
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
 def parse():
